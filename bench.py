@@ -1,0 +1,155 @@
+"""Headline benchmark: graph-steps/s of the spatial block on the synthetic drainage network
+|V|=10k, |E|=12k, d=64 (BASELINE.json metric), one process per GPU.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one batch: the L-layer spatial block
+(`emulator.py:219-235`) applied to S = B*T snapshots resident in HBM = L*S graph-steps
+(graph-step = one spatial layer on one snapshot).  With N > 1 every rank
+runs its own S snapshots of the same network (snapshots are independent inside a forward,
+`emulator.py:217-218`): weak scaling, no data-path collective.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def algorithmic_bytes_per_graph_step(g, f_in, d):
+    """compulsory read of x,e + write of x',e' + one pass over the index and
+    NodeEdge-weight arrays."""
+    N, E = g.n_node, g.n_edge
+    return 4 * (N + E) * (f_in + d) + 4 * ((N + 1) + g.adj.nnz + (E + 1) + g.edge_adj.nnz + 4 * 2 * E)
+
+
+def cpu_baseline(g, block_params, d, budget_s=12.0, S=2):
+    """The oracle (sparse-CSR PyTorch-CPU restatement of the reference forward, kind 'port': the
+    reference's TF path cannot run here) timed on this host's cores on a bounded sample."""
+    from oracle import sparse_csr as OS
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    gen = torch.Generator().manual_seed(2)
+    x = torch.rand(S, g.n_node, d, generator=gen)
+    e = torch.rand(S, g.n_edge, d, generator=gen)
+    adj, eadj = (g.adj.rowptr, g.adj.col), (g.edge_adj.rowptr, g.edge_adj.col)
+    inc_n, inc_e = (g.inc_n.rowptr, g.inc_n.col), (g.inc_e.rowptr, g.inc_e.col)
+
+    def one_pass():
+        xx, ee = x, e
+        for p in block_params:
+            xx, ee = OS.spatial_layer_csr(xx, ee, p, adj, eadj, inc_n, inc_e)
+        return xx
+
+    one_pass()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one_pass()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 50:
+            break
+    steps = n * len(block_params) * S
+    return {'value': steps / el, 'unit': 'graph-steps/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d passes of the %d-layer block on S=%d snapshots of the same network (sparse-CSR torch-CPU fp32 oracle, %.1f s)'
+                      % (n, len(block_params), S, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--nodes', type=int, default=10000)
+    ap.add_argument('--links', type=int, default=12000)
+    ap.add_argument('--embed', type=int, default=64)
+    ap.add_argument('--layers', type=int, default=3)
+    ap.add_argument('--snapshots', type=int, default=60, help='S = B*T per rank (default B=1, T=60)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the engine has no CPU path')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import gnn_uds_amd as U
+
+    g = U.DrainageGraph.from_edges(U.synthetic_drainage_network(args.nodes, args.links, seed=0))
+    d, L, S = args.embed, args.layers, args.snapshots
+    # random-init weights of the reference architecture (Keras initialisers: glorot_uniform kernels, zero
+    # biases, N(0, 0.05^2) NodeEdge weights), seed 1
+    block = U.SpatialBlock(g, d, L, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1)).to(dev)
+    params = [layer.export_params() for layer in block.layers]
+    gen = torch.Generator().manual_seed(2 + rank)
+    x = torch.rand(S, g.n_node, d, generator=gen).to(dev)
+    e = torch.rand(S, g.n_edge, d, generator=gen).to(dev)
+
+    def step():
+        return block(x, e)
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()          # events on torch's current stream = the stream the kernels are launched on
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    dev_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))      # device time of one step
+
+    if rank == 0:
+        gsteps = args.steps * L * S * world
+        bytes_gs = algorithmic_bytes_per_graph_step(g, d, d)
+        achieved = (L * S * bytes_gs) / (dev_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'graph-steps/sec (forward rollout), |V|=10k |E|=12k d=64', 'value': gsteps / wall,
+            'unit': 'graph-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'headline synthetic drainage network N=%d E=%d d=%d, %d-layer GAT spatial block, '
+                                   'S=%d snapshots per GPU (B=1,T=%d)' % (g.n_node, g.n_edge, d, L, S, S),
+                       'graph_steps_per_step': L * S, 'nnz_node': g.adj.nnz, 'nnz_line': g.edge_adj.nnz,
+                       'parallelism': 'snapshot-sharded x%d' % world},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'kernel': 'uds_spatial_layer_forward (all launches of one layer over S snapshots)',
+                         'algorithmic_bytes_per_graph_step': bytes_gs, 'device_ms_per_step': dev_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(g, params, d)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,237 @@
+"""ctypes binding of libuds_hip.so (the C ABI in include/uds_hip.h) for PyTorch-ROCm tensors.
+
+PyTorch is plumbing here: it owns device memory and the stream; every computation below is a
+hand-written HIP kernel reached through the C ABI.  There is NO fallback: if the library is
+missing or a tensor is not a contiguous fp32 CUDA(HIP) tensor the call raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the runtime we bind to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libuds_hip.so')
+
+ACT = {None: 0, 'linear': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'hard_sigmoid': 4}
+
+_c_i64 = ctypes.c_int64
+_c_int = ctypes.c_int
+_c_ptr = ctypes.c_void_p
+
+# name -> (restype, argtypes): every symbol include/uds_hip.h declares
+SYMBOLS = {
+    'uds_abi_version': (_c_int, []),
+    'uds_last_error': (ctypes.c_char_p, []),
+    'uds_csr_create': (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, ctypes.POINTER(_c_ptr)]),
+    'uds_csr_destroy': (_c_int, [_c_ptr]),
+    'uds_csr_shape': (_c_int, [_c_ptr, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64),
+                               ctypes.POINTER(ctypes.c_int32)]),
+    'uds_csr_row_order': (_c_int, [_c_ptr, _c_ptr]),
+    'uds_dense_act': (_c_int, [_c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr,
+                               _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
+    'uds_csr_spmm': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_int, _c_ptr, _c_ptr]),
+    'uds_gat_workspace_floats': (_c_i64, [_c_i64, _c_i64, _c_i64]),
+    'uds_gat_forward': (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
+                                 _c_int, _c_ptr, _c_ptr, _c_ptr]),
+    'uds_network_create': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, ctypes.POINTER(_c_ptr)]),
+    'uds_network_destroy': (_c_int, [_c_ptr]),
+    'uds_spatial_workspace_floats': (_c_i64, [_c_ptr, _c_i64, _c_i64, _c_i64]),
+    'uds_spatial_layer_forward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
+                                           _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
+}
+
+
+class SpatialParams(ctypes.Structure):
+    """uds_spatial_params_t"""
+    _fields_ = [(n, _c_ptr) for n in ('xe_k', 'xe_b', 'ex_k', 'ex_b', 'ne_n_val', 'ne_e_val',
+                                      'gx_k', 'gx_as', 'gx_an', 'gx_b', 'ge_k', 'ge_as', 'ge_an', 'ge_b')]
+
+
+class UdsError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen libuds_hip.so (built by `python -m gnn_uds_amd.build` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError('%s is missing: the HIP engine is not built (run `python -m gnn_uds_amd.build`); '
+                          'gnn_uds_amd has no CPU fallback' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.uds_abi_version() != 1:
+        raise ImportError('libuds_hip.so ABI %d, binding expects 1' % lib.uds_abi_version())
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load().uds_last_error()
+        raise UdsError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else '?'))
+
+
+def _dev(t, name, allow_none=False):
+    """Device pointer of a contiguous fp32 HIP tensor (the C ABI takes plain pointers)."""
+    if t is None:
+        if allow_none:
+            return None
+        raise UdsError('%s is required' % name)
+    if not isinstance(t, torch.Tensor):
+        raise UdsError('%s must be a torch.Tensor, got %r' % (name, type(t)))
+    if not t.is_cuda:
+        raise UdsError('%s is on %s: gnn_uds_amd runs on the MI355X only and has no CPU fallback' % (name, t.device))
+    if t.dtype != torch.float32:
+        raise UdsError('%s must be float32, got %s' % (name, t.dtype))
+    if not t.is_contiguous():
+        raise UdsError('%s must be contiguous' % name)
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class CsrHandle:
+    """uds_csr_t: a CSR pattern resident on the device, plus its degree-sorted row schedule."""
+
+    def __init__(self, csr):
+        lib = load()
+        self.n_rows, self.n_cols, self.nnz = int(csr.n_rows), int(csr.n_cols), int(csr.nnz)
+        rowptr = np.ascontiguousarray(csr.rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(csr.col, dtype=np.int32)
+        h = _c_ptr()
+        _check(lib.uds_csr_create(rowptr.ctypes.data, col.ctypes.data, self.n_rows, self.n_cols, self.nnz,
+                                  ctypes.byref(h)), 'uds_csr_create')
+        self._h = h
+
+    @property
+    def ptr(self):
+        return self._h
+
+    def row_order(self):
+        out = np.empty(self.n_rows, dtype=np.int32)
+        _check(load().uds_csr_row_order(self._h, out.ctypes.data), 'uds_csr_row_order')
+        return out
+
+    def max_degree(self):
+        md = ctypes.c_int32()
+        _check(load().uds_csr_shape(self._h, None, None, None, ctypes.byref(md)), 'uds_csr_shape')
+        return md.value
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h is not None and _lib is not None:
+            _lib.uds_csr_destroy(h)
+
+
+class NetworkHandle:
+    """uds_network_t over a gnn_uds_amd.graph.DrainageGraph."""
+
+    def __init__(self, graph):
+        lib = load()
+        self.graph = graph
+        self.adj = CsrHandle(graph.adj)
+        self.edge_adj = CsrHandle(graph.edge_adj)
+        self.inc_n = CsrHandle(graph.inc_n)
+        self.inc_e = CsrHandle(graph.inc_e)
+        h = _c_ptr()
+        _check(lib.uds_network_create(self.adj.ptr, self.edge_adj.ptr, self.inc_n.ptr, self.inc_e.ptr, ctypes.byref(h)),
+               'uds_network_create')
+        self._h = h
+
+    @property
+    def ptr(self):
+        return self._h
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h is not None and _lib is not None:
+            _lib.uds_network_destroy(h)
+
+
+def dense_act(xa, kernel, bias=None, act='linear', xb=None, attn=None):
+    """act([xa | xb] @ kernel + bias) on the last axis.  attn=(a_self, a_nbr) also returns the
+    GAT attention scalars of the pre-activation rows."""
+    lib = load()
+    fa = xa.shape[-1]
+    fb = 0 if xb is None else xb.shape[-1]
+    rows = xa.numel() // fa
+    fo = kernel.shape[-1]
+    if kernel.shape[0] != fa + fb:
+        raise UdsError('kernel has %d input features, inputs give %d' % (kernel.shape[0], fa + fb))
+    if xb is not None and xb.shape[:-1] != xa.shape[:-1]:
+        raise UdsError('xa %r and xb %r disagree on leading dims' % (tuple(xa.shape), tuple(xb.shape)))
+    out = torch.empty(xa.shape[:-1] + (fo,), device=xa.device, dtype=torch.float32)
+    s_self = s_nbr = None
+    if attn is not None:
+        s_self = torch.empty(xa.shape[:-1], device=xa.device, dtype=torch.float32)
+        s_nbr = torch.empty_like(s_self)
+    _check(lib.uds_dense_act(_dev(xa, 'xa'), fa, _dev(xb, 'xb', True), fb, rows, _dev(kernel, 'kernel'),
+                             _dev(bias, 'bias', True), fo, ACT[act],
+                             _dev(attn[0], 'a_self') if attn else None, _dev(attn[1], 'a_nbr') if attn else None,
+                             _dev(out, 'out'), _dev(s_self, 's_self', True), _dev(s_nbr, 's_nbr', True), _stream()),
+           'uds_dense_act')
+    return (out, s_self, s_nbr) if attn is not None else out
+
+
+def csr_spmm(handle, val, x, bias=None, act='linear'):
+    """out[s,r,:] = act(sum_p val[p] x[s,col[p],:] + bias); x:(S,n_cols,F) -> (S,n_rows,F)."""
+    lib = load()
+    if x.dim() != 3 or x.shape[1] != handle.n_cols:
+        raise UdsError('x must be (S,%d,F), got %r' % (handle.n_cols, tuple(x.shape)))
+    if val is not None and val.numel() != handle.nnz:
+        raise UdsError('val has %d entries, pattern has %d' % (val.numel(), handle.nnz))
+    S, _, F = x.shape
+    out = torch.empty((S, handle.n_rows, F), device=x.device, dtype=torch.float32)
+    _check(lib.uds_csr_spmm(handle.ptr, _dev(val, 'val', True), _dev(x, 'x'), S, F, _dev(bias, 'bias', True), ACT[act],
+                            _dev(out, 'out'), _stream()), 'uds_csr_spmm')
+    return out
+
+
+def gat_forward(handle, xa, kernel, a_self, a_nbr, bias=None, act='relu', xb=None):
+    """Single-head GATConv over a CSR pattern with self loops; xa:(S,n,fa) [| xb:(S,n,fb)] -> (S,n,d)."""
+    lib = load()
+    if xa.dim() != 3 or xa.shape[1] != handle.n_rows:
+        raise UdsError('x must be (S,%d,F), got %r' % (handle.n_rows, tuple(xa.shape)))
+    S, n, fa = xa.shape
+    fb = 0 if xb is None else xb.shape[-1]
+    d = kernel.shape[-1]
+    if kernel.numel() != (fa + fb) * d:
+        raise UdsError('kernel %r does not match %d input features' % (tuple(kernel.shape), fa + fb))
+    ws = torch.empty(lib.uds_gat_workspace_floats(n, S, d), device=xa.device, dtype=torch.float32)
+    out = torch.empty((S, n, d), device=xa.device, dtype=torch.float32)
+    _check(lib.uds_gat_forward(handle.ptr, _dev(xa, 'xa'), fa, _dev(xb, 'xb', True), fb, S, _dev(kernel, 'kernel'),
+                               _dev(a_self, 'a_self'), _dev(a_nbr, 'a_nbr'), _dev(bias, 'bias', True), d, ACT[act],
+                               _dev(ws, 'workspace'), _dev(out, 'out'), _stream()), 'uds_gat_forward')
+    return out
+
+
+def spatial_layer_forward(net, p, x, e, h, d, act='relu'):
+    """One spatial-block loop body (`emulator.py:225-230`).  p: dict of the 14 tensors of
+    uds_spatial_params_t.  x:(S,N,fx), e:(S,E,fe) -> (S,N,d), (S,E,d)."""
+    lib = load()
+    S, N, fx = x.shape
+    _, E, fe = e.shape
+    if e.shape[0] != S or N != net.graph.n_node or E != net.graph.n_edge:
+        raise UdsError('x %r / e %r do not match the network (N=%d, E=%d)' % (tuple(x.shape), tuple(e.shape),
+                                                                            net.graph.n_node, net.graph.n_edge))
+    sp = SpatialParams()
+    for name, _ in SpatialParams._fields_:
+        setattr(sp, name, _dev(p[name], name, allow_none=name.endswith('_b')))
+    ws = torch.empty(lib.uds_spatial_workspace_floats(net.ptr, S, h, d), device=x.device, dtype=torch.float32)
+    out_x = torch.empty((S, N, d), device=x.device, dtype=torch.float32)
+    out_e = torch.empty((S, E, d), device=x.device, dtype=torch.float32)
+    _check(lib.uds_spatial_layer_forward(net.ptr, ctypes.byref(sp), _dev(x, 'x'), fx, _dev(e, 'e'), fe, S, h, d, ACT[act],
+                                         _dev(ws, 'workspace'), _dev(out_x, 'out_x'), _dev(out_e, 'out_e'), _stream()),
+           'uds_spatial_layer_forward')
+    return out_x, out_e

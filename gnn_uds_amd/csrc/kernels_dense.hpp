@@ -1,0 +1,152 @@
+// Row-local dense kernels (gfx950): out = act([xa | xb] @ W + bias), optional GAT attention scalars.
+// Replaces keras Dense (emulator.py:225-226 ...) and the node-update einsum of Spektral GATConv.
+//
+// v1: exact-fp32 FMA tile kernel.  Each 4x4 register tile accumulates in ascending-k order with
+// one fmaf per product, i.e. the same arithmetic as a k-ordered fp32 dot product.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/uds_hip.h"
+
+namespace uds {
+
+struct DenseArgs {
+  const float *xa, *xb, *W, *bias, *a_self, *a_nbr;
+  float *out, *s_self, *s_nbr;
+  int fa, fb, fo, act;
+  int64_t rows;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case UDS_ACT_RELU: return fmaxf(v, 0.0f);
+    case UDS_ACT_TANH: return tanhf(v);
+    case UDS_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    case UDS_ACT_HARD_SIGMOID: return fminf(fmaxf(0.2f * v + 0.5f, 0.0f), 1.0f);
+    default: return v;
+  }
+}
+
+// CG = number of 4-wide column groups (power of two, <= 64).  RT row-threads x TM rows each.
+template <int CG>
+__global__ __launch_bounds__(256) void k_dense_act(DenseArgs a) {
+  constexpr int RT = (256 / CG) < 32 ? (256 / CG) : 32;
+  constexpr int TM = 4;
+  constexpr int ROWS = RT * TM;
+  constexpr int NT = RT * CG;
+  constexpr int KC = 32;
+  __shared__ float As[ROWS][KC + 1];
+  __shared__ __attribute__((aligned(16))) float Ws[KC][CG * 4];
+
+  const int tid = threadIdx.x;
+  const int cg = tid % CG;
+  const int rt = tid / CG;
+  const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+  const int F = a.fa + a.fb;
+
+  float acc[TM][4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+
+  for (int k0 = 0; k0 < F; k0 += KC) {
+    for (int idx = tid; idx < ROWS * KC; idx += NT) {
+      const int r = idx / KC, k = idx % KC;
+      const int64_t grow = row0 + r;
+      const int kk = k0 + k;
+      float v = 0.0f;
+      if (grow < a.rows) {
+        if (kk < a.fa) v = a.xa[grow * a.fa + kk];
+        else if (kk < F) v = a.xb[grow * a.fb + (kk - a.fa)];
+      }
+      As[r][k] = v;
+    }
+    for (int idx = tid; idx < KC * CG * 4; idx += NT) {
+      const int k = idx / (CG * 4), c = idx % (CG * 4);
+      Ws[k][c] = (k0 + k < F && c < a.fo) ? a.W[(int64_t)(k0 + k) * a.fo + c] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < KC; ++k) {
+      const float4 w = *reinterpret_cast<const float4 *>(&Ws[k][cg * 4]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const float av = As[rt * TM + i][k];
+        acc[i][0] = fmaf(av, w.x, acc[i][0]);
+        acc[i][1] = fmaf(av, w.y, acc[i][1]);
+        acc[i][2] = fmaf(av, w.z, acc[i][2]);
+        acc[i][3] = fmaf(av, w.w, acc[i][3]);
+      }
+    }
+    __syncthreads();
+  }
+
+  const int c0 = cg * 4;
+  float as4[4] = {0, 0, 0, 0}, an4[4] = {0, 0, 0, 0}, b4[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (c0 + j < a.fo) {
+      if (a.bias) b4[j] = a.bias[c0 + j];
+      if (a.a_self) {
+        as4[j] = a.a_self[c0 + j];
+        an4[j] = a.a_nbr[c0 + j];
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int64_t grow = row0 + rt * TM + i;
+    if (a.a_self) {  // attention scalars on the pre-activation row (GAT linear has no bias / act)
+      float ps = 0.0f, pn = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ps = fmaf(acc[i][j], as4[j], ps);
+        pn = fmaf(acc[i][j], an4[j], pn);
+      }
+#pragma unroll
+      for (int off = CG / 2; off > 0; off >>= 1) {  // the CG lanes of a row are contiguous in the wave
+        ps += __shfl_xor(ps, off);
+        pn += __shfl_xor(pn, off);
+      }
+      if (cg == 0 && grow < a.rows) {
+        a.s_self[grow] = ps;
+        a.s_nbr[grow] = pn;
+      }
+    }
+    if (grow < a.rows) {
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = apply_act(acc[i][j] + b4[j], a.act);
+      if ((a.fo & 3) == 0) {
+        if (c0 < a.fo) *reinterpret_cast<float4 *>(&a.out[grow * a.fo + c0]) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c0 + j < a.fo) a.out[grow * a.fo + c0 + j] = o[j];
+      }
+    }
+  }
+}
+
+template <int CG>
+inline hipError_t launch_dense_cg(const DenseArgs &a, hipStream_t st) {
+  constexpr int RT = (256 / CG) < 32 ? (256 / CG) : 32;
+  constexpr int ROWS = RT * 4;
+  const int64_t blocks = (a.rows + ROWS - 1) / ROWS;
+  hipLaunchKernelGGL(k_dense_act<CG>, dim3((unsigned)blocks), dim3(RT * CG), 0, st, a);
+  return hipGetLastError();
+}
+
+inline hipError_t launch_dense_act(const DenseArgs &a, hipStream_t st) {
+  const int groups = (a.fo + 3) / 4;
+  if (groups <= 1) return launch_dense_cg<1>(a, st);
+  if (groups <= 2) return launch_dense_cg<2>(a, st);
+  if (groups <= 4) return launch_dense_cg<4>(a, st);
+  if (groups <= 8) return launch_dense_cg<8>(a, st);
+  if (groups <= 16) return launch_dense_cg<16>(a, st);
+  if (groups <= 32) return launch_dense_cg<32>(a, st);
+  return launch_dense_cg<64>(a, st);
+}
+
+}  // namespace uds

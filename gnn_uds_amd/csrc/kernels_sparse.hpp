@@ -1,0 +1,111 @@
+// CSR gather kernels (gfx950): weighted neighbour sum (NodeEdge support / GCN / incidence balance)
+// and the GAT segmented softmax + aggregation (Spektral GATConv K5+K6, via emulator.py:229-230).
+//
+// Thread mapping: one lane owns one float4 feature chunk of one destination row, so a row of
+// F floats is read by F/4 adjacent lanes with 16-B accesses (a 64-float row = one 256-B request
+// from 16 lanes).  Rows are visited in the degree-sorted schedule of the handle so the lanes of
+// a wave run equal trip counts.  No cross-lane traffic, no atomics: results are deterministic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels_dense.hpp"
+
+namespace uds {
+
+struct SpmmArgs {
+  const int32_t *rowptr, *col, *order;
+  const float *val, *x, *bias;
+  float *out;
+  int n_rows, n_cols, f4, act, S;
+};
+
+__global__ __launch_bounds__(256) void k_csr_spmm(SpmmArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per_snap = (int64_t)a.n_rows * a.f4;
+  if (t >= per_snap) return;
+  const int s = blockIdx.y;
+  const int c = (int)(t % a.f4);
+  const int i = a.order[t / a.f4];
+  const int beg = a.rowptr[i], end = a.rowptr[i + 1];
+  const float4 *x4 = reinterpret_cast<const float4 *>(a.x) + (int64_t)s * a.n_cols * a.f4 + c;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = beg; p < end; ++p) {
+    const float v = a.val ? a.val[p] : 1.0f;
+    const float4 xv = x4[(int64_t)a.col[p] * a.f4];
+    acc.x = fmaf(v, xv.x, acc.x);
+    acc.y = fmaf(v, xv.y, acc.y);
+    acc.z = fmaf(v, xv.z, acc.z);
+    acc.w = fmaf(v, xv.w, acc.w);
+  }
+  if (a.bias) {
+    const float4 b = reinterpret_cast<const float4 *>(a.bias)[c];
+    acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+  }
+  acc.x = apply_act(acc.x, a.act);
+  acc.y = apply_act(acc.y, a.act);
+  acc.z = apply_act(acc.z, a.act);
+  acc.w = apply_act(acc.w, a.act);
+  reinterpret_cast<float4 *>(a.out)[((int64_t)s * a.n_rows + i) * a.f4 + c] = acc;
+}
+
+inline hipError_t launch_csr_spmm(const SpmmArgs &a, hipStream_t st) {
+  const int64_t per_snap = (int64_t)a.n_rows * a.f4;
+  hipLaunchKernelGGL(k_csr_spmm, dim3((unsigned)((per_snap + 255) / 256), (unsigned)a.S), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+struct GatArgs {
+  const int32_t *rowptr, *col, *order;
+  const float *hx, *s_self, *s_nbr, *bias;
+  float *out;
+  int n, d4, act, S;
+};
+
+__device__ __forceinline__ float leaky02(float v) { return v > 0.0f ? v : 0.2f * v; }
+
+__global__ __launch_bounds__(256) void k_gat_aggregate(GatArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per_snap = (int64_t)a.n * a.d4;
+  if (t >= per_snap) return;
+  const int s = blockIdx.y;
+  const int c = (int)(t % a.d4);
+  const int i = a.order[t / a.d4];
+  const int beg = a.rowptr[i], end = a.rowptr[i + 1];
+  const float *sn = a.s_nbr + (int64_t)s * a.n;
+  const float ss = a.s_self[(int64_t)s * a.n + i];
+  // pass 1: row maximum of the logits (softmax is shift-invariant; this is tf.nn.softmax's shift)
+  float m = -INFINITY;
+  for (int p = beg; p < end; ++p) m = fmaxf(m, leaky02(ss + sn[a.col[p]]));
+  // pass 2: exp, denominator and weighted sum of the neighbours' transformed rows
+  const float4 *hx4 = reinterpret_cast<const float4 *>(a.hx) + (int64_t)s * a.n * a.d4 + c;
+  float den = 0.0f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = beg; p < end; ++p) {
+    const int j = a.col[p];
+    const float w = expf(leaky02(ss + sn[j]) - m);
+    const float4 hv = hx4[(int64_t)j * a.d4];
+    den += w;
+    acc.x = fmaf(w, hv.x, acc.x);
+    acc.y = fmaf(w, hv.y, acc.y);
+    acc.z = fmaf(w, hv.z, acc.z);
+    acc.w = fmaf(w, hv.w, acc.w);
+  }
+  const float inv = end > beg ? 1.0f / den : 0.0f;
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.bias) b = reinterpret_cast<const float4 *>(a.bias)[c];
+  float4 o;
+  o.x = apply_act(fmaf(acc.x, inv, b.x), a.act);
+  o.y = apply_act(fmaf(acc.y, inv, b.y), a.act);
+  o.z = apply_act(fmaf(acc.z, inv, b.z), a.act);
+  o.w = apply_act(fmaf(acc.w, inv, b.w), a.act);
+  reinterpret_cast<float4 *>(a.out)[((int64_t)s * a.n + i) * a.d4 + c] = o;
+}
+
+inline hipError_t launch_gat_aggregate(const GatArgs &a, hipStream_t st) {
+  const int64_t per_snap = (int64_t)a.n * a.d4;
+  hipLaunchKernelGGL(k_gat_aggregate, dim3((unsigned)((per_snap + 255) / 256), (unsigned)a.S), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace uds

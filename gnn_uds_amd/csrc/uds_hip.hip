@@ -1,0 +1,253 @@
+// libuds_hip.so -- C ABI + launchers (gfx950 only).  Kernels live in kernels_*.hpp.
+// Interface contract and the reference call sites each entry replaces: include/uds_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/uds_hip.h"
+#include "kernels_dense.hpp"
+#include "kernels_sparse.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define UDS_HIP_TRY(call)                                                              \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) return fail(UDS_EHIP, "%s -> %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+#define UDS_REQUIRE(cond, ...) \
+  do {                         \
+    if (!(cond)) return fail(UDS_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int64_t align4(int64_t floats) { return (floats + 3) & ~int64_t(3); }  // keep 16-B carve offsets
+
+}  // namespace
+
+struct uds_csr {
+  int64_t n_rows = 0, n_cols = 0, nnz = 0;
+  int32_t max_degree = 0;
+  int32_t *d_rowptr = nullptr, *d_col = nullptr, *d_order = nullptr;
+  std::vector<int32_t> h_order;
+};
+
+struct uds_network {
+  const uds_csr *adj, *edge_adj, *inc_n, *inc_e;
+};
+
+extern "C" {
+
+int uds_abi_version(void) { return UDS_ABI_VERSION; }
+const char *uds_last_error(void) { return g_err.c_str(); }
+
+int uds_csr_create(const int32_t *rowptr, const int32_t *col, int64_t n_rows, int64_t n_cols,
+                   int64_t nnz, uds_csr_t **out) {
+  UDS_REQUIRE(out != nullptr, "uds_csr_create: out is NULL");
+  *out = nullptr;
+  UDS_REQUIRE(rowptr != nullptr && (col != nullptr || nnz == 0), "uds_csr_create: NULL index array");
+  UDS_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0 && n_rows < INT32_MAX && nnz < INT32_MAX,
+              "uds_csr_create: sizes out of int32 range");
+  UDS_REQUIRE(rowptr[0] == 0 && rowptr[n_rows] == nnz, "uds_csr_create: rowptr[0]=%d rowptr[n]=%d nnz=%lld",
+              rowptr[0], rowptr[n_rows], (long long)nnz);
+  int32_t max_deg = 0;
+  for (int64_t r = 0; r < n_rows; ++r) {
+    UDS_REQUIRE(rowptr[r + 1] >= rowptr[r], "uds_csr_create: rowptr decreases at row %lld", (long long)r);
+    max_deg = std::max(max_deg, rowptr[r + 1] - rowptr[r]);
+  }
+  for (int64_t p = 0; p < nnz; ++p)
+    UDS_REQUIRE(col[p] >= 0 && col[p] < n_cols, "uds_csr_create: col[%lld]=%d outside [0,%lld)",
+                (long long)p, col[p], (long long)n_cols);
+  uds_csr *c = new (std::nothrow) uds_csr;
+  if (!c) return fail(UDS_ENOMEM, "uds_csr_create: host allocation failed");
+  c->n_rows = n_rows;
+  c->n_cols = n_cols;
+  c->nnz = nnz;
+  c->max_degree = max_deg;
+  // degree-sorted schedule: descending degree, ties by row index (stable)
+  c->h_order.resize(n_rows);
+  std::iota(c->h_order.begin(), c->h_order.end(), 0);
+  std::stable_sort(c->h_order.begin(), c->h_order.end(), [&](int32_t a, int32_t b) {
+    return (rowptr[a + 1] - rowptr[a]) > (rowptr[b + 1] - rowptr[b]);
+  });
+  auto cleanup = [&](int code) {
+    hipFree(c->d_rowptr);
+    hipFree(c->d_col);
+    hipFree(c->d_order);
+    delete c;
+    return code;
+  };
+  hipError_t e;
+  if ((e = hipMalloc(&c->d_rowptr, sizeof(int32_t) * (n_rows + 1))) != hipSuccess ||
+      (e = hipMalloc(&c->d_col, sizeof(int32_t) * std::max<int64_t>(nnz, 1))) != hipSuccess ||
+      (e = hipMalloc(&c->d_order, sizeof(int32_t) * std::max<int64_t>(n_rows, 1))) != hipSuccess)
+    return cleanup(fail(UDS_ENOMEM, "uds_csr_create: hipMalloc -> %s", hipGetErrorString(e)));
+  if ((e = hipMemcpy(c->d_rowptr, rowptr, sizeof(int32_t) * (n_rows + 1), hipMemcpyHostToDevice)) != hipSuccess ||
+      (nnz && (e = hipMemcpy(c->d_col, col, sizeof(int32_t) * nnz, hipMemcpyHostToDevice)) != hipSuccess) ||
+      (n_rows && (e = hipMemcpy(c->d_order, c->h_order.data(), sizeof(int32_t) * n_rows, hipMemcpyHostToDevice)) != hipSuccess))
+    return cleanup(fail(UDS_EHIP, "uds_csr_create: hipMemcpy -> %s", hipGetErrorString(e)));
+  *out = c;
+  return UDS_OK;
+}
+
+int uds_csr_destroy(uds_csr_t *c) {
+  if (!c) return UDS_OK;
+  hipFree(c->d_rowptr);
+  hipFree(c->d_col);
+  hipFree(c->d_order);
+  delete c;
+  return UDS_OK;
+}
+
+int uds_csr_shape(const uds_csr_t *c, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, int32_t *max_degree) {
+  UDS_REQUIRE(c != nullptr, "uds_csr_shape: NULL handle");
+  if (n_rows) *n_rows = c->n_rows;
+  if (n_cols) *n_cols = c->n_cols;
+  if (nnz) *nnz = c->nnz;
+  if (max_degree) *max_degree = c->max_degree;
+  return UDS_OK;
+}
+
+int uds_csr_row_order(const uds_csr_t *c, int32_t *out_host) {
+  UDS_REQUIRE(c != nullptr && out_host != nullptr, "uds_csr_row_order: NULL argument");
+  std::memcpy(out_host, c->h_order.data(), sizeof(int32_t) * c->n_rows);
+  return UDS_OK;
+}
+
+int uds_dense_act(const float *xa, int64_t fa, const float *xb, int64_t fb, int64_t rows, const float *W,
+                  const float *bias, int64_t f_out, int act, const float *a_self, const float *a_nbr,
+                  float *out, float *s_self, float *s_nbr, uds_stream_t stream) {
+  UDS_REQUIRE(xa && W && out, "uds_dense_act: NULL xa/W/out");
+  UDS_REQUIRE(((f_out & 3) != 0 || aligned16(out)), "uds_dense_act: out must be 16-byte aligned");
+  UDS_REQUIRE(fa > 0 && fb >= 0 && (fb == 0) == (xb == nullptr), "uds_dense_act: fa=%lld fb=%lld xb=%p inconsistent",
+              (long long)fa, (long long)fb, (const void *)xb);
+  UDS_REQUIRE(rows >= 0 && f_out > 0 && f_out <= 256 && fa + fb <= 4096, "uds_dense_act: rows=%lld f_out=%lld (max 256) f_in=%lld",
+              (long long)rows, (long long)f_out, (long long)(fa + fb));
+  UDS_REQUIRE(act >= UDS_ACT_LINEAR && act <= UDS_ACT_HARD_SIGMOID, "uds_dense_act: unknown activation %d", act);
+  const bool attn = a_self != nullptr;
+  UDS_REQUIRE(attn == (a_nbr != nullptr) && attn == (s_self != nullptr) && attn == (s_nbr != nullptr),
+              "uds_dense_act: a_self/a_nbr/s_self/s_nbr must be given together");
+  if (rows == 0) return UDS_OK;
+  uds::DenseArgs a{xa, xb, W, bias, a_self, a_nbr, out, s_self, s_nbr, (int)fa, (int)fb, (int)f_out, act, rows};
+  hipError_t e = uds::launch_dense_act(a, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_dense_act: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
+int uds_csr_spmm(const uds_csr_t *csr, const float *val, const float *x, int64_t S, int64_t F, const float *bias,
+                 int act, float *out, uds_stream_t stream) {
+  UDS_REQUIRE(csr && x && out, "uds_csr_spmm: NULL csr/x/out");
+  UDS_REQUIRE(S >= 0 && F > 0 && F % 4 == 0, "uds_csr_spmm: S=%lld F=%lld (F must be a positive multiple of 4)",
+              (long long)S, (long long)F);
+  UDS_REQUIRE(aligned16(x) && aligned16(out) && aligned16(bias), "uds_csr_spmm: x/out/bias must be 16-byte aligned");
+  UDS_REQUIRE(act >= UDS_ACT_LINEAR && act <= UDS_ACT_HARD_SIGMOID, "uds_csr_spmm: unknown activation %d", act);
+  UDS_REQUIRE(S <= 65535, "uds_csr_spmm: S=%lld exceeds 65535 snapshots per call", (long long)S);
+  if (S == 0 || csr->n_rows == 0) return UDS_OK;
+  uds::SpmmArgs a{csr->d_rowptr, csr->d_col, csr->d_order, val, x, bias, out,
+                  (int)csr->n_rows, (int)csr->n_cols, (int)(F / 4), act, (int)S};
+  hipError_t e = uds::launch_csr_spmm(a, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_csr_spmm: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
+int64_t uds_gat_workspace_floats(int64_t n, int64_t S, int64_t d) { return align4(S * n * (d + 2)); }
+
+int uds_gat_forward(const uds_csr_t *g, const float *xa, int64_t fa, const float *xb, int64_t fb, int64_t S,
+                    const float *W, const float *a_self, const float *a_nbr, const float *bias, int64_t d, int act,
+                    float *ws, float *out, uds_stream_t stream) {
+  UDS_REQUIRE(g && xa && W && a_self && a_nbr && ws && out, "uds_gat_forward: NULL argument");
+  UDS_REQUIRE(g->n_rows == g->n_cols, "uds_gat_forward: pattern must be square (%lld x %lld)", (long long)g->n_rows,
+              (long long)g->n_cols);
+  UDS_REQUIRE(d > 0 && d % 4 == 0 && d <= 256, "uds_gat_forward: d=%lld must be a multiple of 4, at most 256", (long long)d);
+  UDS_REQUIRE(S >= 0 && S <= 65535, "uds_gat_forward: S=%lld outside [0,65535]", (long long)S);
+  UDS_REQUIRE(aligned16(ws) && aligned16(out) && aligned16(bias), "uds_gat_forward: workspace/out/bias must be 16-byte aligned");
+  if (S == 0 || g->n_rows == 0) return UDS_OK;
+  const int64_t n = g->n_rows;
+  float *hx = ws;
+  float *s_self = hx + S * n * d;
+  float *s_nbr = s_self + S * n;
+  int rc = uds_dense_act(xa, fa, xb, fb, S * n, W, nullptr, d, UDS_ACT_LINEAR, a_self, a_nbr, hx, s_self, s_nbr, stream);
+  if (rc != UDS_OK) return rc;
+  uds::GatArgs a{g->d_rowptr, g->d_col, g->d_order, hx, s_self, s_nbr, bias, out, (int)n, (int)(d / 4), act, (int)S};
+  hipError_t e = uds::launch_gat_aggregate(a, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_gat_forward: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
+int uds_network_create(const uds_csr_t *adj, const uds_csr_t *edge_adj, const uds_csr_t *inc_n, const uds_csr_t *inc_e,
+                       uds_network_t **out) {
+  UDS_REQUIRE(out != nullptr, "uds_network_create: out is NULL");
+  *out = nullptr;
+  UDS_REQUIRE(adj && edge_adj && inc_n && inc_e, "uds_network_create: NULL pattern");
+  const int64_t N = adj->n_rows, E = edge_adj->n_rows;
+  UDS_REQUIRE(adj->n_cols == N && edge_adj->n_cols == E, "uds_network_create: adjacency patterns must be square");
+  UDS_REQUIRE(inc_n->n_rows == N && inc_n->n_cols == E && inc_e->n_rows == E && inc_e->n_cols == N,
+              "uds_network_create: incidence shapes (%lld x %lld), (%lld x %lld) do not match N=%lld E=%lld",
+              (long long)inc_n->n_rows, (long long)inc_n->n_cols, (long long)inc_e->n_rows, (long long)inc_e->n_cols,
+              (long long)N, (long long)E);
+  uds_network *n = new (std::nothrow) uds_network{adj, edge_adj, inc_n, inc_e};
+  if (!n) return fail(UDS_ENOMEM, "uds_network_create: host allocation failed");
+  *out = n;
+  return UDS_OK;
+}
+
+int uds_network_destroy(uds_network_t *net) {
+  delete net;
+  return UDS_OK;
+}
+
+int64_t uds_spatial_workspace_floats(const uds_network_t *net, int64_t S, int64_t h, int64_t d) {
+  if (!net) return 0;
+  const int64_t N = net->adj->n_rows, E = net->edge_adj->n_rows;
+  // x_e (E,h) + e_x (N,h) + agg_n (N,h) + agg_e (E,h) + hx,s (N,d+2) + he,s (E,d+2)
+  return S * 2 * (N + E) * h + align4(S * N * (d + 2)) + align4(S * E * (d + 2));
+}
+
+int uds_spatial_layer_forward(const uds_network_t *net, const uds_spatial_params_t *p, const float *x, int64_t fx,
+                              const float *e, int64_t fe, int64_t S, int64_t h, int64_t d, int act, float *ws,
+                              float *out_x, float *out_e, uds_stream_t stream) {
+  UDS_REQUIRE(net && p && x && e && ws && out_x && out_e, "uds_spatial_layer_forward: NULL argument");
+  UDS_REQUIRE(p->xe_k && p->ex_k && p->ne_n_val && p->ne_e_val && p->gx_k && p->gx_as && p->gx_an && p->ge_k &&
+                  p->ge_as && p->ge_an,
+              "uds_spatial_layer_forward: NULL parameter tensor");
+  UDS_REQUIRE(h > 0 && h % 4 == 0 && d > 0 && d % 4 == 0, "uds_spatial_layer_forward: h=%lld d=%lld must be multiples of 4",
+              (long long)h, (long long)d);
+  UDS_REQUIRE(out_x != x && out_e != e, "uds_spatial_layer_forward: outputs must not alias inputs");
+  const int64_t N = net->adj->n_rows, E = net->edge_adj->n_rows;
+  float *x_e = ws;                    // (S,E,h)
+  float *e_x = x_e + S * E * h;       // (S,N,h)
+  float *agg_n = e_x + S * N * h;     // (S,N,h)
+  float *agg_e = agg_n + S * N * h;   // (S,E,h)
+  float *gat_ws_n = agg_e + S * E * h;        // S*N*(d+2)
+  float *gat_ws_e = gat_ws_n + align4(S * N * (d + 2));
+  int rc;
+  if ((rc = uds_dense_act(e, fe, nullptr, 0, S * E, p->xe_k, p->xe_b, h, act, nullptr, nullptr, x_e, nullptr, nullptr, stream))) return rc;
+  if ((rc = uds_dense_act(x, fx, nullptr, 0, S * N, p->ex_k, p->ex_b, h, act, nullptr, nullptr, e_x, nullptr, nullptr, stream))) return rc;
+  if ((rc = uds_csr_spmm(net->inc_n, p->ne_n_val, x_e, S, h, nullptr, UDS_ACT_LINEAR, agg_n, stream))) return rc;
+  if ((rc = uds_csr_spmm(net->inc_e, p->ne_e_val, e_x, S, h, nullptr, UDS_ACT_LINEAR, agg_e, stream))) return rc;
+  if ((rc = uds_gat_forward(net->adj, x, fx, agg_n, h, S, p->gx_k, p->gx_as, p->gx_an, p->gx_b, d, act, gat_ws_n, out_x, stream))) return rc;
+  if ((rc = uds_gat_forward(net->edge_adj, e, fe, agg_e, h, S, p->ge_k, p->ge_as, p->ge_an, p->ge_b, d, act, gat_ws_e, out_e, stream))) return rc;
+  return UDS_OK;
+}
+
+}  // extern "C"

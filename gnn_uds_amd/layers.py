@@ -1,0 +1,355 @@
+"""torch.nn.Module mirrors of the reference's Keras / Spektral layers, running on the HIP engine.
+
+The reference is TensorFlow/Keras + Spektral; "drop-in" therefore means: same layer
+constructor arguments, same call convention `layer([x, a]) -> x'`, same weight names and shapes,
+same tensor layouts -- re-expressed as `torch.nn.Module`s:
+
+    Dense(units, activation)                      keras.layers.Dense        emulator.py:198,203,225-226,...
+    NodeEdge(inci)                                emulator.py:27-45
+    GATConv / MixedGAT(channels, activation=..)   spektral GATConv via emulator.py:18-25,229-230
+    GCNConv(channels, activation=..) + preprocess spektral GCNConv via emulator.py:131-134
+    SpatialLayer / SpatialBlock                   the loop bodies emulator.py:219-235, 272-288
+
+Forward only (the training step, SURVEY.md a10, is a later row): parameters are created with
+requires_grad=False and no autograd graph is recorded.  All compute is HIP kernels behind the C ABI
+(gnn_uds_amd/_lib.py); CPU tensors raise.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .graph import CSR, DrainageGraph, csr_from_dense
+
+
+def _param(t):
+    return nn.Parameter(t, requires_grad=False)
+
+
+def _glorot_uniform(shape, device, generator=None):
+    """Keras glorot_uniform incl. its fan rule for >2-D kernels (receptive field = prod(shape[:-2]))."""
+    if len(shape) == 1:
+        fan_in = fan_out = shape[0]
+    elif len(shape) == 2:
+        fan_in, fan_out = shape
+    else:
+        rf = int(np.prod(shape[:-2]))
+        fan_in, fan_out = shape[-2] * rf, shape[-1] * rf
+    limit = math.sqrt(6.0 / (fan_in + fan_out))
+    t = torch.rand(shape, generator=generator, dtype=torch.float32) * (2 * limit) - limit
+    return t.to(device)
+
+
+def _flatten_snapshots(x):
+    """(..., M, F) -> (S, M, F) contiguous, plus the leading shape to restore."""
+    if x.dim() < 2:
+        raise _lib.UdsError('expected (..., elements, features), got %r' % (tuple(x.shape),))
+    lead = tuple(x.shape[:-2])
+    return x.reshape((-1,) + tuple(x.shape[-2:])).contiguous(), lead
+
+
+class Dense(nn.Module):
+    """keras.layers.Dense(units, activation): act(x @ kernel + bias) on the last axis."""
+
+    def __init__(self, units, activation=None, use_bias=True, in_features=None, generator=None):
+        super().__init__()
+        self.units, self.activation, self.use_bias = int(units), activation or 'linear', use_bias
+        self._gen = generator
+        self.kernel = self.bias = None
+        if self.activation not in _lib.ACT:
+            raise ValueError('unknown activation %r' % (activation,))
+        if in_features is not None:
+            self.build(in_features, 'cpu')
+
+    def build(self, in_features, device):
+        self.kernel = _param(_glorot_uniform((int(in_features), self.units), device, self._gen))
+        self.bias = _param(torch.zeros(self.units, device=device)) if self.use_bias else None
+
+    def forward(self, x):
+        if self.kernel is None:
+            self.build(x.shape[-1], x.device)
+        xc = x.contiguous()
+        return _lib.dense_act(xc, self.kernel, self.bias, self.activation)
+
+
+class _GraphArg:
+    """Turns the `a` of `layer([x, a])` into a device CSR handle, caching dense inputs by identity."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def handle(self, a, add_self_loops):
+        if isinstance(a, _lib.CsrHandle):
+            return a
+        if isinstance(a, CSR):
+            key = ('csr', id(a))
+            if key not in self._cache:
+                self._cache[key] = (a, _lib.CsrHandle(a))
+            return self._cache[key][1]
+        key = ('dense', id(a), add_self_loops)
+        hit = self._cache.get(key)
+        if hit is not None and hit[0] is a:
+            return hit[1]
+        dense = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+        h = _lib.CsrHandle(csr_from_dense(dense, add_self_loops=add_self_loops))
+        self._cache[key] = (a, h)
+        return h
+
+
+class GATConv(nn.Module):
+    """spektral.layers.GATConv in batch/mixed mode, single head (what the reference uses).
+
+    forward([x, a]): x (..., N, F); a = dense (N, N) 0/1 filter as in the reference
+    (`emulator.py:143-145,229`), a `graph.CSR`, or a prebuilt `_lib.CsrHandle` (CSR inputs must
+    already hold the self loops).  Weights keep Spektral's names and shapes:
+    kernel (F,1,C), attn_kernel_self (C,1,1), attn_kernel_neighs (C,1,1), bias (C)."""
+
+    def __init__(self, channels, attn_heads=1, concat_heads=True, dropout_rate=0.5, return_attn_coef=False,
+                 add_self_loops=True, activation=None, use_bias=True, in_channels=None, generator=None):
+        super().__init__()
+        if attn_heads != 1:
+            raise NotImplementedError('the HIP engine builds the single-head GAT the reference uses (attn_heads=1)')
+        if return_attn_coef:
+            raise NotImplementedError('return_attn_coef is not built')
+        self.channels, self.attn_heads, self.concat_heads = int(channels), 1, concat_heads
+        self.dropout_rate, self.add_self_loops = dropout_rate, add_self_loops
+        self.activation, self.use_bias = activation or 'linear', use_bias
+        self._gen = generator
+        self._graphs = _GraphArg()
+        self.kernel = self.attn_kernel_self = self.attn_kernel_neighs = self.bias = None
+        if in_channels is not None:
+            self.build(in_channels, 'cpu')
+
+    def build(self, in_channels, device):
+        c = self.channels
+        self.kernel = _param(_glorot_uniform((int(in_channels), 1, c), device, self._gen))
+        self.attn_kernel_self = _param(_glorot_uniform((c, 1, 1), device, self._gen))
+        self.attn_kernel_neighs = _param(_glorot_uniform((c, 1, 1), device, self._gen))
+        self.bias = _param(torch.zeros(c, device=device)) if self.use_bias else None
+
+    def forward(self, inputs, xb=None):
+        x, a = inputs
+        if self.kernel is None:
+            self.build(x.shape[-1] + (0 if xb is None else xb.shape[-1]), x.device)
+        h = self._graphs.handle(a, self.add_self_loops)
+        xs, lead = _flatten_snapshots(x)
+        xbs = None if xb is None else _flatten_snapshots(xb)[0]
+        out = _lib.gat_forward(h, xs, self.kernel, self.attn_kernel_self, self.attn_kernel_neighs, self.bias,
+                               self.activation, xbs)
+        return out.reshape(lead + out.shape[-2:])
+
+
+MixedGAT = GATConv   # emulator.py:18-25: only re-types the (inactive) attention dropout
+
+
+class GCNConv(nn.Module):
+    """spektral.layers.GCNConv: act(a_hat @ (x @ kernel) + bias); a_hat = GCNConv.preprocess(adj)."""
+
+    def __init__(self, channels, activation=None, use_bias=True, in_channels=None, generator=None):
+        super().__init__()
+        self.channels, self.activation, self.use_bias = int(channels), activation or 'linear', use_bias
+        self._gen = generator
+        self._cache = {}
+        self.kernel = self.bias = None
+        if in_channels is not None:
+            self.build(in_channels, 'cpu')
+
+    @staticmethod
+    def preprocess(adj):
+        """gcn_filter: D^-1/2 (A + I) D^-1/2, row-sum degrees, inf -> 0 (`emulator.py:133`)."""
+        a = np.asarray(adj, dtype=np.float64) + np.eye(len(adj))
+        deg = a.sum(axis=1)
+        with np.errstate(divide='ignore'):
+            dinv = np.power(deg, -0.5)
+        dinv[np.isinf(dinv)] = 0.0
+        return dinv[:, None] * a * dinv[None, :]
+
+    def build(self, in_channels, device):
+        self.kernel = _param(_glorot_uniform((int(in_channels), self.channels), device, self._gen))
+        self.bias = _param(torch.zeros(self.channels, device=device)) if self.use_bias else None
+
+    def _filter(self, a, device):
+        hit = self._cache.get(id(a))
+        if hit is not None and hit[0] is a:
+            return hit[1], hit[2]
+        dense = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+        csr = csr_from_dense(dense, keep_values=True)
+        h = _lib.CsrHandle(csr)
+        val = torch.as_tensor(csr.val, dtype=torch.float32, device=device)
+        self._cache[id(a)] = (a, h, val)
+        return h, val
+
+    def forward(self, inputs):
+        x, a = inputs
+        if self.kernel is None:
+            self.build(x.shape[-1], x.device)
+        h, val = self._filter(a, x.device)
+        xs, lead = _flatten_snapshots(x)
+        hx = _lib.dense_act(xs, self.kernel, None, 'linear')
+        out = _lib.csr_spmm(h, val, hx, self.bias, self.activation)
+        return out.reshape(lead + out.shape[-2:])
+
+
+class NodeEdge(nn.Module):
+    """`NodeEdge(inci)` (`emulator.py:27-45`): out = (weight * inci + bias) @ x, inci (R, M).
+
+    `weight`, `bias` keep the reference's dense (R, M) shape by default.  The product is evaluated on
+    the incidence support with the CSR kernel; a trained `bias` that is non-zero OFF the support makes
+    the matrix genuinely dense, and that remainder is added with one rocBLAS GEMM (the check is
+    re-done whenever the parameters change).  For networks where an (R, M) parameter cannot exist
+    (N = 50k: 13 GB each) pass sparse=True: parameters then have one entry per support element
+    (columns ascending inside a row)."""
+
+    def __init__(self, inci, sparse=False, device='cpu', generator=None):
+        super().__init__()
+        if isinstance(inci, CSR):
+            csr = inci if inci.val is not None else CSR(inci.rowptr, inci.col, inci.n_rows, inci.n_cols,
+                                                        np.ones(inci.nnz))
+        else:
+            dense = inci.detach().cpu().numpy() if isinstance(inci, torch.Tensor) else np.asarray(inci)
+            csr = csr_from_dense(dense, keep_values=True)
+        self.csr = csr
+        self.sparse = bool(sparse)
+        self.shape = (csr.n_rows, csr.n_cols)
+        rows = torch.as_tensor(csr.rows(), dtype=torch.int64)
+        cols = torch.as_tensor(csr.col.astype(np.int64))
+        self.register_buffer('_flat', rows * csr.n_cols + cols, persistent=False)
+        self.register_buffer('_ival', torch.as_tensor(csr.val, dtype=torch.float32), persistent=False)
+        shape = (csr.nnz,) if self.sparse else self.shape
+        w = torch.randn(shape, generator=generator, dtype=torch.float32) * 0.05      # 'random_normal'
+        self.weight = _param(w.to(device))
+        self.bias = _param(torch.zeros(shape, device=device))
+        self._handle = None
+        self._val_cache = None
+
+    def support_values(self):
+        """weight*inci + bias on the support (nnz,), plus the off-support remainder of bias or None."""
+        key = (self.weight._version, self.bias._version, self.weight.data_ptr(), self.bias.data_ptr())
+        if self._val_cache is not None and self._val_cache[0] == key:
+            return self._val_cache[1], self._val_cache[2]
+        flat, ival = self._flat.to(self.weight.device), self._ival.to(self.weight.device)
+        if self.sparse:
+            val, rest = self.weight * ival + self.bias, None
+        else:
+            val = self.weight.reshape(-1)[flat] * ival + self.bias.reshape(-1)[flat]
+            rest = self.bias.clone()
+            rest.reshape(-1)[flat] = 0.0
+            if not bool((rest != 0).any()):
+                rest = None
+        self._val_cache = (key, val.contiguous(), rest)
+        return self._val_cache[1], rest
+
+    def handle(self):
+        if self._handle is None:
+            self._handle = _lib.CsrHandle(self.csr)
+        return self._handle
+
+    def forward(self, x):
+        if x.shape[-2] != self.shape[1]:
+            raise _lib.UdsError('NodeEdge expects %d elements on axis -2, got %r' % (self.shape[1], tuple(x.shape)))
+        val, rest = self.support_values()
+        xs, lead = _flatten_snapshots(x)
+        out = _lib.csr_spmm(self.handle(), val, xs)
+        if rest is not None:
+            out = out + torch.matmul(rest, xs)
+        return out.reshape(lead + out.shape[-2:])
+
+
+class SpatialLayer(nn.Module):
+    """One iteration of the spatial-block loop (`emulator.py:225-230`, `:278-283`), conv = GAT:
+
+        x_e = Dense(d/2, act)(e);  e_x = Dense(d/2, act)(x)
+        x = concat[x, NodeEdge(|node_edge|)(x_e)];  e = concat[e, NodeEdge(|node_edge|^T)(e_x)]
+        x = GAT(d, act)([x, Adj]);  e = GAT(d, act)([e, Eadj])
+
+    forward(x, e): x (..., N, Fx), e (..., E, Fe) -> (..., N, d), (..., E, d).  Uses the fused C-ABI
+    entry uds_spatial_layer_forward (concats are never materialised)."""
+
+    def __init__(self, graph, embed_size, activation='relu', fx=None, fe=None, sparse_params=None, net=None,
+                 generator=None):
+        super().__init__()
+        if not isinstance(graph, DrainageGraph):
+            raise TypeError('graph must be a gnn_uds_amd.graph.DrainageGraph')
+        self.graph, self.d, self.h, self.activation = graph, int(embed_size), int(embed_size) // 2, activation
+        if self.d % 8:
+            raise ValueError('embed_size must be a multiple of 8 (float4 rows of width d/2), got %d' % self.d)
+        if sparse_params is None:
+            sparse_params = graph.n_node * graph.n_edge > (1 << 24)
+        fx = self.d if fx is None else int(fx)
+        fe = self.d if fe is None else int(fe)
+        g = generator
+        self.dense_xe = Dense(self.h, activation, in_features=fe, generator=g)          # emulator.py:225
+        self.dense_ex = Dense(self.h, activation, in_features=fx, generator=g)          # emulator.py:226
+        abs_n = CSR(graph.inc_n.rowptr, graph.inc_n.col, graph.n_node, graph.n_edge, np.abs(graph.inc_n.val))
+        abs_e = CSR(graph.inc_e.rowptr, graph.inc_e.col, graph.n_edge, graph.n_node, np.abs(graph.inc_e.val))
+        self.node_edge_n = NodeEdge(abs_n, sparse=sparse_params, generator=g)           # emulator.py:227
+        self.node_edge_e = NodeEdge(abs_e, sparse=sparse_params, generator=g)           # emulator.py:228
+        self.gat_x = GATConv(self.d, activation=activation, in_channels=fx + self.h, generator=g)   # :229
+        self.gat_e = GATConv(self.d, activation=activation, in_channels=fe + self.h, generator=g)   # :230
+        self._net = net
+
+    def network(self):
+        if self._net is None:
+            self._net = _lib.NetworkHandle(self.graph)
+        return self._net
+
+    def export_params(self):
+        """Parameters as CPU tensors under the key names of uds_spatial_params_t (NodeEdge as
+        'ne_*_w'/'ne_*_b' when dense, 'ne_*_v' support values when sparse)."""
+        c = lambda t: None if t is None else t.detach().cpu().clone()
+        p = dict(xe_k=c(self.dense_xe.kernel), xe_b=c(self.dense_xe.bias), ex_k=c(self.dense_ex.kernel),
+                 ex_b=c(self.dense_ex.bias),
+                 gx_k=c(self.gat_x.kernel), gx_as=c(self.gat_x.attn_kernel_self), gx_an=c(self.gat_x.attn_kernel_neighs),
+                 gx_b=c(self.gat_x.bias),
+                 ge_k=c(self.gat_e.kernel), ge_as=c(self.gat_e.attn_kernel_self), ge_an=c(self.gat_e.attn_kernel_neighs),
+                 ge_b=c(self.gat_e.bias))
+        for tag, ne in (('n', self.node_edge_n), ('e', self.node_edge_e)):
+            if ne.sparse:
+                p['ne_%s_v' % tag] = c(ne.support_values()[0])
+            else:
+                p['ne_%s_w' % tag], p['ne_%s_b' % tag] = c(ne.weight), c(ne.bias)
+        return p
+
+    def forward(self, x, e):
+        xs, lead_x = _flatten_snapshots(x)
+        es, lead_e = _flatten_snapshots(e)
+        vn, rest_n = self.node_edge_n.support_values()
+        ve, rest_e = self.node_edge_e.support_values()
+        if rest_n is None and rest_e is None:
+            p = dict(xe_k=self.dense_xe.kernel, xe_b=self.dense_xe.bias, ex_k=self.dense_ex.kernel, ex_b=self.dense_ex.bias,
+                     ne_n_val=vn, ne_e_val=ve,
+                     gx_k=self.gat_x.kernel, gx_as=self.gat_x.attn_kernel_self, gx_an=self.gat_x.attn_kernel_neighs,
+                     gx_b=self.gat_x.bias,
+                     ge_k=self.gat_e.kernel, ge_as=self.gat_e.attn_kernel_self, ge_an=self.gat_e.attn_kernel_neighs,
+                     ge_b=self.gat_e.bias)
+            ox, oe = _lib.spatial_layer_forward(self.network(), p, xs, es, self.h, self.d, self.activation)
+        else:   # trained dense NodeEdge bias: unfused composition with the dense remainder GEMM
+            net = self.network()
+            x_e, e_x = self.dense_xe(es), self.dense_ex(xs)
+            ox = self.gat_x([xs, net.adj], xb=self.node_edge_n(x_e))
+            oe = self.gat_e([es, net.edge_adj], xb=self.node_edge_e(e_x))
+        return ox.reshape(lead_x + ox.shape[-2:]), oe.reshape(lead_e + oe.shape[-2:])
+
+
+class SpatialBlock(nn.Module):
+    """`for _ in range(n_sp_layer)` (`emulator.py:219-235`): first layer takes (fx, fe) features."""
+
+    def __init__(self, graph, embed_size, n_sp_layer, activation='relu', fx=None, fe=None, sparse_params=None,
+                 generator=None):
+        super().__init__()
+        self._net_holder = [None]
+        layers = []
+        for i in range(n_sp_layer):
+            layers.append(SpatialLayer(graph, embed_size, activation, fx if i == 0 else None, fe if i == 0 else None,
+                                       sparse_params, generator=generator))
+        self.layers = nn.ModuleList(layers)
+        self.graph = graph
+
+    def forward(self, x, e):
+        net = self.layers[0].network()
+        for layer in self.layers:
+            layer._net = net
+            x, e = layer(x, e)
+        return x, e

@@ -1,0 +1,131 @@
+/* uds_hip.h -- C ABI of libuds_hip.so, the MI355X (gfx950) message-passing engine for the
+ * GNN-UDS graph-convolution hot path.
+ *
+ * The reference (Zhiyu014/GNN-UDS) has no FFI: its seam is the Keras layer protocol
+ * (SURVEY.md section 8b).  Each entry point below replaces the TensorFlow ops behind one
+ * reference call site (file:line relative to the reference's surrogate/ directory):
+ *
+ *   uds_dense_act            keras Dense                        emulator.py:198,203,206,212,225-226,278-279,313,317,324,329-330,336
+ *                            + the "...NI,IHO->...NHO" node-update einsum of Spektral GATConv (via emulator.py:229-230)
+ *   uds_csr_spmm             NodeEdge.call on its support       emulator.py:42-45 (used at :227-228,280-281)
+ *                            + GCNConv propagation a_hat @ (xW) emulator.py:131-134
+ *                            + post_proc_tf incidence matmuls   emulator.py:717-724
+ *   uds_gat_forward          MixedGAT(GATConv)([x, adj])        emulator.py:18-25,229-230,282-283
+ *   uds_spatial_layer_forward  one spatial-block loop body      emulator.py:225-230 / 278-283
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer owned by the caller (fp32, row-major, contiguous,
+ *     16-byte aligned); `rowptr`/`col` passed to uds_csr_create are HOST pointers and are copied;
+ *   - snapshots: S = B*T independent graph signals share one graph; node features are (S, N, F);
+ *   - all launches are asynchronous on `stream` (a hipStream_t; 0 = the null stream); the library
+ *     never synchronises, never allocates after handle creation (graph-capture safe) and starts
+ *     no host threads; handles are immutable after creation and may be shared across streams;
+ *   - return value 0 = success, negative errno-style code otherwise; nothing throws across the
+ *     boundary; uds_last_error() gives the thread-local message of the last failure.
+ */
+#ifndef UDS_HIP_H
+#define UDS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UDS_ABI_VERSION 1
+
+enum {
+  UDS_OK = 0,
+  UDS_EINVAL = -22, /* bad argument (shape, alignment, null pointer)   */
+  UDS_ENOMEM = -12, /* device allocation failed                         */
+  UDS_EHIP = -5,    /* a HIP runtime call failed (see uds_last_error)   */
+  UDS_ENOSYS = -38  /* configuration not built into this library        */
+};
+
+/* keras.activations names used by the reference (emulator.py:66,193,324,330,336) */
+enum {
+  UDS_ACT_LINEAR = 0,
+  UDS_ACT_RELU = 1,
+  UDS_ACT_TANH = 2,
+  UDS_ACT_SIGMOID = 3,
+  UDS_ACT_HARD_SIGMOID = 4 /* Keras 2.10: clip(0.2*x + 0.5, 0, 1) */
+};
+
+typedef void *uds_stream_t; /* hipStream_t */
+
+int uds_abi_version(void);
+const char *uds_last_error(void);
+
+/* ---- CSR pattern handle ------------------------------------------------------------------- */
+typedef struct uds_csr uds_csr_t;
+
+/* Copies a host CSR pattern (int32, rowptr[n_rows+1], col[nnz] < n_cols) to the device and builds
+ * the degree-sorted row schedule (descending degree, ties by row index). */
+int uds_csr_create(const int32_t *rowptr, const int32_t *col, int64_t n_rows, int64_t n_cols,
+                   int64_t nnz, uds_csr_t **out);
+int uds_csr_destroy(uds_csr_t *csr);
+int uds_csr_shape(const uds_csr_t *csr, int64_t *n_rows, int64_t *n_cols, int64_t *nnz,
+                  int32_t *max_degree);
+/* Copies the row schedule (n_rows int32) to a HOST buffer: integer bookkeeping, tested bit-exact. */
+int uds_csr_row_order(const uds_csr_t *csr, int32_t *out_host);
+
+/* ---- single ops ---------------------------------------------------------------------------- */
+
+/* out[r,:] = act([xa[r,:] | xb[r,:]] @ W + bias), r < rows.   W is (fa+fb, f_out) row-major.
+ * xb may be NULL with fb = 0; bias may be NULL.  When a_self/a_nbr (f_out each) are given,
+ * s_self[r] = <pre-activation row, a_self> and s_nbr[r] likewise are written too (the GAT
+ * attention scalars); they must be NULL together. */
+int uds_dense_act(const float *xa, int64_t fa, const float *xb, int64_t fb, int64_t rows,
+                  const float *W, const float *bias, int64_t f_out, int act, const float *a_self,
+                  const float *a_nbr, float *out, float *s_self, float *s_nbr,
+                  uds_stream_t stream);
+
+/* out[s,r,:] = act(sum_{p in row r} val[p] * x[s, col[p], :] + bias);  x is (S, n_cols, F),
+ * out is (S, n_rows, F).  val (nnz) may be NULL (all ones); bias (F) may be NULL.  F % 4 == 0. */
+int uds_csr_spmm(const uds_csr_t *csr, const float *val, const float *x, int64_t S, int64_t F,
+                 const float *bias, int act, float *out, uds_stream_t stream);
+
+/* Floats of workspace uds_gat_forward needs: S * n * (d + 2). */
+int64_t uds_gat_workspace_floats(int64_t n, int64_t S, int64_t d);
+
+/* Single-head GATConv on a CSR pattern that already contains the self loops:
+ *   hx = [xa | xb] @ W              (W: (fa+fb, d))
+ *   alpha_ij = softmax_j leaky_relu_0.2( <hx_i, a_self> + <hx_j, a_nbr> ),  j in row i
+ *   out_i = act( sum_j alpha_ij hx_j + bias )
+ * xa:(S,n,fa), xb:(S,n,fb) or NULL, out:(S,n,d), d % 4 == 0. */
+int uds_gat_forward(const uds_csr_t *graph, const float *xa, int64_t fa, const float *xb,
+                    int64_t fb, int64_t S, const float *W, const float *a_self,
+                    const float *a_nbr, const float *bias, int64_t d, int act, float *workspace,
+                    float *out, uds_stream_t stream);
+
+/* ---- one spatial layer (node side + link side) ---------------------------------------------- */
+typedef struct uds_network uds_network_t;
+
+/* Borrows the four patterns (they must outlive the network): adj (N x N) and edge_adj (E x E) with
+ * self loops, inc_n (N x E) node<-links incidence support, inc_e (E x N) its transpose. */
+int uds_network_create(const uds_csr_t *adj, const uds_csr_t *edge_adj, const uds_csr_t *inc_n,
+                       const uds_csr_t *inc_e, uds_network_t **out);
+int uds_network_destroy(uds_network_t *net);
+
+typedef struct uds_spatial_params {
+  const float *xe_k, *xe_b; /* Dense(h) on e -> x_e : (fe, h), (h)            emulator.py:225 */
+  const float *ex_k, *ex_b; /* Dense(h) on x -> e_x : (fx, h), (h)            emulator.py:226 */
+  const float *ne_n_val;    /* NodeEdge(|inci|)   on its support: nnz(inc_n)  emulator.py:227 */
+  const float *ne_e_val;    /* NodeEdge(|inci|^T) on its support: nnz(inc_e)  emulator.py:228 */
+  const float *gx_k, *gx_as, *gx_an, *gx_b; /* GAT nodes: (fx+h, d),(d),(d),(d) emulator.py:229 */
+  const float *ge_k, *ge_as, *ge_an, *ge_b; /* GAT links: (fe+h, d),(d),(d),(d) emulator.py:230 */
+} uds_spatial_params_t;
+
+/* Floats of workspace uds_spatial_layer_forward needs. */
+int64_t uds_spatial_workspace_floats(const uds_network_t *net, int64_t S, int64_t h, int64_t d);
+
+/* x:(S,N,fx), e:(S,E,fe) -> out_x:(S,N,d), out_e:(S,E,d).  out_* must not alias x / e. */
+int uds_spatial_layer_forward(const uds_network_t *net, const uds_spatial_params_t *params,
+                              const float *x, int64_t fx, const float *e, int64_t fe, int64_t S,
+                              int64_t h, int64_t d, int act, float *workspace, float *out_x,
+                              float *out_e, uds_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UDS_HIP_H */

@@ -1,0 +1,100 @@
+"""Graph-matrix oracle (TEST INFRASTRUCTURE ONLY): the reference's networkx constructions,
+restated from `surrogate/envs/scenario/base.py:367-439` on a plain link list.
+
+Integer / index bookkeeping: the product's builders (gnn_uds_amd/graph.py) must
+match these bit for bit.  Pinned by the link lists of the five SWMM `.inp` data
+files the reference ships (tests/golden/networks.json) -- the matrices themselves
+are "parity unpinned" (the reference holds no expected outputs for them).
+
+networkx is what the reference itself calls (`base.py:5`); it is used here on
+purpose, so traversal-order quirks (depth-limited DFS pre-order, `combinations`
+over `Graph.edges(n)`) are inherited rather than re-guessed.
+"""
+from itertools import combinations
+
+import networkx as nx
+import numpy as np
+
+
+def adjacency(edges, directed=False, length=0, order=1, lengths=None):
+    """`get_adj` (`base.py:367-391`).  edges:(E,2) int [from,to].  Note n_node =
+    edges.max()+1 as in the reference (`:373,384`)."""
+    edges = np.asarray(edges)
+    g = nx.DiGraph() if directed else nx.Graph()
+    n_node = int(edges.max()) + 1
+    adj = np.zeros((n_node, n_node))
+    if length:
+        sigma = np.std(lengths)
+        for (u, v), ln in zip(edges, lengths):
+            g.add_edge(int(u), int(v), length=ln)
+        for n in range(n_node):
+            reach = nx.single_source_dijkstra_path_length(g, n, weight='length', cutoff=length)
+            for a, dist in reach.items():
+                adj[n, a] = np.exp(-(dist / (sigma + 1e-5)) ** 2)
+    else:
+        for u, v in edges:
+            g.add_edge(int(u), int(v))
+        for n in range(n_node):
+            ball = list(nx.dfs_preorder_nodes(g, n, order)) if order > 0 else [n]
+            for a in ball:
+                adj[n, a] = 1
+                if not directed:
+                    adj[a, n] = 1
+    return adj
+
+
+def line_graph(edges, directed=False, lengths=None):
+    """The link graph EX of `get_edge_adj` (`base.py:394-417`): links are vertices,
+    joined when they share a node (undirected) or chain in->out (directed)."""
+    edges = np.asarray(edges)
+    g = nx.DiGraph() if directed else nx.Graph()
+    for i, (u, v) in enumerate(edges):
+        g.add_edge(int(u), int(v), edge=i)
+        if lengths is not None:
+            g[int(u)][int(v)].update(length=lengths[i])
+    ex = nx.DiGraph() if directed else nx.Graph()
+    for n in g.nodes():
+        if directed:
+            pairs = [(p, q) for p in g.in_edges(n) for q in g.out_edges(n)]
+        else:
+            pairs = list(combinations(g.edges(n), 2))
+        for (a, b), (c, d) in pairs:
+            p, q = g[a][b], g[c][d]
+            ex.add_edge(p['edge'], q['edge'])
+            if lengths is not None:
+                ex[p['edge']][q['edge']].update(length=(p['length'] + q['length']) / 2)
+    return ex
+
+
+def edge_adjacency(edges, directed=False, length=0, order=1, lengths=None):
+    """`get_edge_adj` (`base.py:393-429`).  Not symmetrised explicitly (`:428`)."""
+    edges = np.asarray(edges)
+    ex = line_graph(edges, directed, lengths if length else None)
+    n_edge = edges.shape[0]
+    adj = np.zeros((n_edge, n_edge))
+    sigma = np.std(lengths) if length else None
+    for n in range(n_edge):
+        if length:
+            reach = nx.single_source_dijkstra_path_length(ex, n, weight='length', cutoff=length)
+            for a, dist in reach.items():
+                adj[n, a] = np.exp(-(dist / (sigma + 1e-5)) ** 2)
+        else:
+            for a in (list(nx.dfs_preorder_nodes(ex, n, order)) if order > 0 else [n]):
+                adj[n, a] = 1
+    return adj
+
+
+def node_edge_incidence(n_node, edges):
+    """`get_node_edge` (`base.py:432-439`): +1 at the from-node, -1 at the to-node
+    (a self-referential link nets to 0)."""
+    edges = np.asarray(edges)
+    ne = np.zeros((n_node, len(edges)))
+    for i, (u, v) in enumerate(edges):
+        ne[u, i] += 1
+        ne[v, i] += -1
+    return ne
+
+
+def gat_filter(adj):
+    """`Emulator.get_conv` GAT branch (`emulator.py:143-145`): (adj>0).astype(int)."""
+    return (np.asarray(adj) > 0).astype(int)

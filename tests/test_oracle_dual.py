@@ -1,0 +1,137 @@
+"""The oracle is unpinned by the reference (no fixtures exist), so it is pinned by itself:
+dense-masked (Spektral op-for-op) == sparse CSR, plus closed-form known answers."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import graphs as OG
+from oracle import sparse_csr as OS
+from oracle import spektral_dense as OD
+from tests.util import cast, spatial_params
+
+
+def _random_links(rng, n_node, n_edge, allow_self=False):
+    e = rng.integers(0, n_node, size=(n_edge, 2))
+    if not allow_self:
+        e[:, 1] = np.where(e[:, 0] == e[:, 1], (e[:, 1] + 1) % n_node, e[:, 1])
+    e[0] = (n_node - 1, 0)          # make sure edges.max()+1 == n_node
+    return e
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_gat_dense_equals_sparse_fp64(seed):
+    rng = np.random.default_rng(seed)
+    n, f, c, s = 17, 6, 8, 3
+    a = (rng.random((n, n)) < 0.2).astype(float)
+    if seed % 2:
+        a[3, :] = 0; a[:, 3] = 0                   # isolated node: only the forced self loop
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(s, n, f, generator=g, dtype=torch.float64)
+    k = torch.randn(f, 1, c, generator=g, dtype=torch.float64)
+    a_s = torch.randn(c, 1, 1, generator=g, dtype=torch.float64)
+    a_n = torch.randn(c, 1, 1, generator=g, dtype=torch.float64)
+    b = torch.randn(c, generator=g, dtype=torch.float64)
+    ref, coef = OD.gat_conv_dense(x, torch.from_numpy(a), k, a_s, a_n, b, 'relu', return_attn=True)
+    rowptr, col, _ = OS.csr_from_dense(a, add_self_loops=True)
+    out = OS.gat_conv_csr(x, rowptr, col, k, a_s, a_n, b, 'relu')
+    assert torch.allclose(ref, out, rtol=0, atol=1e-12)
+    # masked entries of the dense form are exactly zero, rows sum to one
+    ahat = a.copy(); np.fill_diagonal(ahat, 1)
+    assert float(coef[:, :, 0, :][:, ahat == 0].abs().max()) == 0.0
+    assert torch.allclose(coef.sum(-1), torch.ones_like(coef.sum(-1)), atol=1e-12)
+
+
+def test_gat_known_answer_path_graph():
+    """3-node path 0-1-2, identity kernel, a_self = 0, a_nbr = e0: alpha depends only on x_j[0]."""
+    a = torch.tensor([[0., 1, 0], [1, 0, 1], [0, 1, 0]], dtype=torch.float64)
+    x = torch.tensor([[[1.0, 2.0], [0.0, -1.0], [-2.0, 3.0]]], dtype=torch.float64)
+    k = torch.eye(2, dtype=torch.float64).reshape(2, 1, 2)
+    a_s = torch.zeros(2, 1, 1, dtype=torch.float64)
+    a_n = torch.tensor([1.0, 0.0], dtype=torch.float64).reshape(2, 1, 1)
+    out = OD.gat_conv_dense(x, a, k, a_s, a_n, None, 'linear')
+    lr = lambda v: v if v > 0 else 0.2 * v
+    l0, l1, l2 = lr(1.0), lr(0.0), lr(-2.0)
+    # node 0 sees {0,1}; node 1 sees {0,1,2}; node 2 sees {1,2}
+    w = [np.exp([l0, l1]), np.exp([l0, l1, l2]), np.exp([l1, l2])]
+    rows = [[0, 1], [0, 1, 2], [1, 2]]
+    exp = np.stack([(w[i][:, None] * x[0, rows[i]].numpy()).sum(0) / w[i].sum() for i in range(3)])
+    assert np.allclose(out[0].numpy(), exp, atol=1e-14)
+
+
+def test_gat_star_uniform_attention():
+    """Zero attention kernels -> uniform softmax -> plain mean over the closed neighbourhood."""
+    n = 6
+    a = np.zeros((n, n)); a[0, 1:] = 1; a[1:, 0] = 1
+    x = torch.arange(n * 2, dtype=torch.float64).reshape(1, n, 2)
+    k = torch.eye(2, dtype=torch.float64).reshape(2, 1, 2)
+    z = torch.zeros(2, 1, 1, dtype=torch.float64)
+    out = OD.gat_conv_dense(x, torch.from_numpy(a), k, z, z, None, 'linear')[0]
+    assert torch.allclose(out[0], x[0].mean(0))
+    for i in range(1, n):
+        assert torch.allclose(out[i], (x[0, 0] + x[0, i]) / 2)
+
+
+def test_hard_sigmoid_and_mask_constant():
+    t = torch.tensor([-3.0, -2.5, 0.0, 1.0, 2.5, 3.0])
+    assert torch.allclose(OD.activation('hard_sigmoid')(t), torch.tensor([0, 0, 0.5, 0.7, 1.0, 1.0]))
+    assert OD.MASK_VALUE == -1e10 and OD.LEAKY_SLOPE == 0.2
+
+
+@pytest.mark.parametrize('trained_bias', [False, True])
+def test_node_edge_dense_equals_sparse(trained_bias):
+    rng = np.random.default_rng(3)
+    edges = _random_links(rng, 9, 12)
+    ne = torch.from_numpy(OG.node_edge_incidence(9, edges))
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(9, 12, generator=g, dtype=torch.float64) * 0.05
+    b = torch.randn(9, 12, generator=g, dtype=torch.float64) * 0.01 if trained_bias else torch.zeros(9, 12, dtype=torch.float64)
+    x = torch.rand(4, 12, 5, generator=g, dtype=torch.float64)
+    ref = OD.node_edge_dense(x, ne.abs(), w, b)
+    out = OS.node_edge_sparse(x, ne.abs(), w, b)
+    assert torch.allclose(ref, out, atol=1e-13)
+    rowptr, col, v, rest = OS.node_edge_support(ne.abs(), w, b)
+    assert (rest is None) == (not trained_bias)
+
+
+@pytest.mark.parametrize('seed,dtype,tol', [(0, torch.float64, 1e-12), (1, torch.float64, 1e-12), (2, torch.float32, 1e-5)])
+def test_spatial_layer_dense_equals_sparse(seed, dtype, tol):
+    rng = np.random.default_rng(seed)
+    n, m, d, s = 14, 18, 8, 3
+    edges = _random_links(rng, n, m)
+    adj = np.eye(n)                                  # order-1 ball, built from its definition (random links
+    adj[edges[:, 0], edges[:, 1]] = 1                # may leave a node untouched, where networkx raises)
+    adj[edges[:, 1], edges[:, 0]] = 1
+    # the reference's line-graph builder is undefined for parallel links; build the filter from the product-independent
+    # definition "links sharing a node" directly
+    eadj = np.zeros((m, m))
+    for i in range(m):
+        for j in range(m):
+            if set(edges[i]) & set(edges[j]):
+                eadj[i, j] = 1
+    ne = torch.from_numpy(OG.node_edge_incidence(n, edges)).to(dtype)
+    p = cast(spatial_params(n, m, d, d, d, seed=seed), dtype)
+    g = torch.Generator().manual_seed(seed + 10)
+    x = torch.rand(s, n, d, generator=g, dtype=torch.float64).to(dtype)
+    e = torch.rand(s, m, d, generator=g, dtype=torch.float64).to(dtype)
+    rx, re = OD.spatial_layer_dense(x, e, p, torch.from_numpy(adj), torch.from_numpy(eadj), ne)
+    a_csr = OS.csr_from_dense(adj, True)[:2]
+    ea_csr = OS.csr_from_dense(eadj, True)[:2]
+    sx, se = OS.spatial_layer_csr(x, e, p, a_csr, ea_csr, node_edge=ne)
+    assert float((rx - sx).abs().max()) <= tol * max(1.0, float(rx.abs().max()))
+    assert float((re - se).abs().max()) <= tol * max(1.0, float(re.abs().max()))
+    assert rx.shape == (s, n, d) and re.shape == (s, m, d)
+
+
+def test_gcn_preprocess_and_conv():
+    a = torch.tensor([[0., 1, 0], [1, 0, 0], [0, 0, 0]])
+    ah = OD.gcn_preprocess(a)
+    exp = torch.tensor([[0.5, 0.5, 0], [0.5, 0.5, 0], [0, 0, 1.0]], dtype=torch.float64)
+    assert torch.allclose(ah, exp)
+    x = torch.rand(2, 3, 4, dtype=torch.float64)
+    k = torch.rand(4, 5, dtype=torch.float64)
+    b = torch.rand(5, dtype=torch.float64)
+    ref = OD.gcn_conv_dense(x, ah, k, b)
+    rowptr, col, val = OS.csr_from_dense(ah.numpy())
+    assert torch.allclose(ref, OS.gcn_conv_csr(x, rowptr, col, val, k, b), atol=1e-14)
