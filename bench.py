@@ -36,7 +36,7 @@ def cpu_baseline(g, block_params, d, budget_s=12.0, S=2):
     """The oracle (sparse-CSR PyTorch-CPU restatement of the reference forward, kind 'port': the
     reference's TF path cannot run here) timed on this host's cores on a bounded sample."""
     from oracle import sparse_csr as OS
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)      # a 1-GPU box's CPU share is 16 cores; more threads only thrash
     torch.set_num_threads(cores)
     gen = torch.Generator().manual_seed(2)
     x = torch.rand(S, g.n_node, d, generator=gen)

@@ -176,6 +176,9 @@ def dense_act(xa, kernel, bias=None, act='linear', xb=None, attn=None):
     if attn is not None:
         s_self = torch.empty(xa.shape[:-1], device=xa.device, dtype=torch.float32)
         s_nbr = torch.empty_like(s_self)
+    if rows == 0:                       # nothing to launch (an empty tensor has no device pointer)
+        _dev(xa, 'xa')
+        return (out, s_self, s_nbr) if attn is not None else out
     _check(lib.uds_dense_act(_dev(xa, 'xa'), fa, _dev(xb, 'xb', True), fb, rows, _dev(kernel, 'kernel'),
                              _dev(bias, 'bias', True), fo, ACT[act],
                              _dev(attn[0], 'a_self') if attn else None, _dev(attn[1], 'a_nbr') if attn else None,
@@ -193,6 +196,9 @@ def csr_spmm(handle, val, x, bias=None, act='linear'):
         raise UdsError('val has %d entries, pattern has %d' % (val.numel(), handle.nnz))
     S, _, F = x.shape
     out = torch.empty((S, handle.n_rows, F), device=x.device, dtype=torch.float32)
+    if out.numel() == 0:
+        _dev(x, 'x')
+        return out
     _check(lib.uds_csr_spmm(handle.ptr, _dev(val, 'val', True), _dev(x, 'x'), S, F, _dev(bias, 'bias', True), ACT[act],
                             _dev(out, 'out'), _stream()), 'uds_csr_spmm')
     return out
@@ -208,8 +214,11 @@ def gat_forward(handle, xa, kernel, a_self, a_nbr, bias=None, act='relu', xb=Non
     d = kernel.shape[-1]
     if kernel.numel() != (fa + fb) * d:
         raise UdsError('kernel %r does not match %d input features' % (tuple(kernel.shape), fa + fb))
-    ws = torch.empty(lib.uds_gat_workspace_floats(n, S, d), device=xa.device, dtype=torch.float32)
     out = torch.empty((S, n, d), device=xa.device, dtype=torch.float32)
+    if out.numel() == 0:
+        _dev(xa, 'xa')
+        return out
+    ws = torch.empty(lib.uds_gat_workspace_floats(n, S, d), device=xa.device, dtype=torch.float32)
     _check(lib.uds_gat_forward(handle.ptr, _dev(xa, 'xa'), fa, _dev(xb, 'xb', True), fb, S, _dev(kernel, 'kernel'),
                                _dev(a_self, 'a_self'), _dev(a_nbr, 'a_nbr'), _dev(bias, 'bias', True), d, ACT[act],
                                _dev(ws, 'workspace'), _dev(out, 'out'), _stream()), 'uds_gat_forward')
@@ -225,6 +234,10 @@ def spatial_layer_forward(net, p, x, e, h, d, act='relu'):
     if e.shape[0] != S or N != net.graph.n_node or E != net.graph.n_edge:
         raise UdsError('x %r / e %r do not match the network (N=%d, E=%d)' % (tuple(x.shape), tuple(e.shape),
                                                                             net.graph.n_node, net.graph.n_edge))
+    if S == 0:
+        _dev(x, 'x')
+        return (torch.empty((0, N, d), device=x.device, dtype=torch.float32),
+                torch.empty((0, E, d), device=x.device, dtype=torch.float32))
     sp = SpatialParams()
     for name, _ in SpatialParams._fields_:
         setattr(sp, name, _dev(p[name], name, allow_none=name.endswith('_b')))
