@@ -74,6 +74,9 @@ def main():
     ap.add_argument('--embed', type=int, default=64)
     ap.add_argument('--layers', type=int, default=3)
     ap.add_argument('--snapshots', type=int, default=60, help='S = B*T per rank (default B=1, T=60)')
+    ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'fp32'],
+                    help="bf16x3: fused kernel, GEMM operands split into bf16 hi+lo (3 MFMA products, fp32 accumulate); "
+                         "fp32: exact-fp32 unfused kernels")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -96,7 +99,8 @@ def main():
     d, L, S = args.embed, args.layers, args.snapshots
     # random-init weights of the reference architecture (Keras initialisers: glorot_uniform kernels, zero
     # biases, N(0, 0.05^2) NodeEdge weights), seed 1
-    block = U.SpatialBlock(g, d, L, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1)).to(dev)
+    block = U.SpatialBlock(g, d, L, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1),
+                           precision=args.precision).to(dev)
     params = [layer.export_params() for layer in block.layers]
     gen = torch.Generator().manual_seed(2 + rank)
     x = torch.rand(S, g.n_node, d, generator=gen).to(dev)
@@ -134,14 +138,17 @@ def main():
             'metric': 'graph-steps/sec (forward rollout), |V|=10k |E|=12k d=64', 'value': gsteps / wall,
             'unit': 'graph-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32' if args.precision == 'fp32' else 'f32 storage/accumulate, GEMM operands as bf16 hi+lo split (3 MFMA products)',
+            'data': 'synthetic',
             'config': {'workload': 'headline synthetic drainage network N=%d E=%d d=%d, %d-layer GAT spatial block, '
                                    'S=%d snapshots per GPU (B=1,T=%d)' % (g.n_node, g.n_edge, d, L, S, S),
                        'graph_steps_per_step': L * S, 'nnz_node': g.adj.nnz, 'nnz_line': g.edge_adj.nnz,
-                       'parallelism': 'snapshot-sharded x%d' % world},
+                       'parallelism': 'snapshot-sharded x%d' % world, 'precision': args.precision,
+                       'plan': block.layers[0].network().plan_info()},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
-                         'kernel': 'uds_spatial_layer_forward (all launches of one layer over S snapshots)',
+                         'kernel': 'k_fused_side<64,64> (one launch per layer over S snapshots)' if args.precision == 'bf16x3' else
+                                   'uds_spatial_layer_forward, unfused (8 launches per layer over S snapshots)',
                          'algorithmic_bytes_per_graph_step': bytes_gs, 'device_ms_per_step': dev_ms},
         }
         if world == 1 and not args.no_cpu_baseline:

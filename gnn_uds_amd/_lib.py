@@ -13,6 +13,10 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libuds_hip.so')
 
+ABI_VERSION = 2
+FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
+PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
+
 ACT = {None: 0, 'linear': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'hard_sigmoid': 4}
 
 _c_i64 = ctypes.c_int64
@@ -36,9 +40,14 @@ SYMBOLS = {
                                  _c_int, _c_ptr, _c_ptr, _c_ptr]),
     'uds_network_create': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, ctypes.POINTER(_c_ptr)]),
     'uds_network_destroy': (_c_int, [_c_ptr]),
+    'uds_network_plan_info': (_c_int, [_c_ptr, _c_ptr]),
+    'uds_tile_plan_create': (_c_int, [_c_ptr] * 8 + [_c_i64, _c_i64, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_c_ptr)]),
+    'uds_tile_plan_destroy': (_c_int, [_c_ptr]),
+    'uds_tile_plan_sizes': (_c_int, [_c_ptr, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64), _c_ptr]),
+    'uds_tile_plan_copy': (_c_int, [_c_ptr, _c_ptr, _c_ptr]),
     'uds_spatial_workspace_floats': (_c_i64, [_c_ptr, _c_i64, _c_i64, _c_i64]),
     'uds_spatial_layer_forward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
-                                           _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
+                                           _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
 }
 
 
@@ -68,8 +77,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.uds_abi_version() != 1:
-        raise ImportError('libuds_hip.so ABI %d, binding expects 1' % lib.uds_abi_version())
+    if lib.uds_abi_version() != ABI_VERSION:
+        raise ImportError('libuds_hip.so ABI %d, binding expects %d' % (lib.uds_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 
@@ -153,10 +162,41 @@ class NetworkHandle:
     def ptr(self):
         return self._h
 
+    def plan_info(self):
+        """Tile plan of the fused kernel: dict(fused, node_tiles, link_tiles, p_cap, q_cap, meta_cap, lds_bytes, ...)."""
+        info = np.zeros(8, dtype=np.int32)
+        _check(load().uds_network_plan_info(self._h, info.ctypes.data), 'uds_network_plan_info')
+        keys = ('fused', 'node_tiles', 'link_tiles', 'p_cap', 'q_cap', 'meta_cap', 'lds_bytes', 't_code')
+        out = dict(zip(keys, (int(v) for v in info)))
+        out['t_node'], out['t_link'] = out['t_code'] // 1000, out['t_code'] % 1000
+        return out
+
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None
         if h is not None and _lib is not None:
             _lib.uds_network_destroy(h)
+
+
+def tile_plan(graph, t_node=128, t_link=120):
+    """Host-only tile plan of a DrainageGraph (no GPU needed): returns (hdr (T,8) int32, pool int32, caps).
+    hdr columns: n_own, n_prim, n_sec, n_inc, n_adj, pool_off, side, meta_len (csrc/tile_plan.hpp)."""
+    lib = load()
+    arrs = []
+    for c in (graph.adj, graph.edge_adj, graph.inc_n, graph.inc_e):
+        arrs += [np.ascontiguousarray(c.rowptr, dtype=np.int32), np.ascontiguousarray(c.col, dtype=np.int32)]
+    h = _c_ptr()
+    _check(lib.uds_tile_plan_create(*[a.ctypes.data for a in arrs], graph.n_node, graph.n_edge, t_node, t_link,
+                                    ctypes.byref(h)), 'uds_tile_plan_create')
+    try:
+        nt, pl = _c_i64(), _c_i64()
+        caps = np.zeros(3, dtype=np.int32)
+        _check(lib.uds_tile_plan_sizes(h, ctypes.byref(nt), ctypes.byref(pl), caps.ctypes.data), 'uds_tile_plan_sizes')
+        hdr = np.zeros((nt.value, 8), dtype=np.int32)
+        pool = np.zeros(pl.value, dtype=np.int32)
+        _check(lib.uds_tile_plan_copy(h, hdr.ctypes.data, pool.ctypes.data), 'uds_tile_plan_copy')
+    finally:
+        lib.uds_tile_plan_destroy(h)
+    return hdr, pool, dict(p_cap=int(caps[0]), q_cap=int(caps[1]), meta_cap=int(caps[2]))
 
 
 def dense_act(xa, kernel, bias=None, act='linear', xb=None, attn=None):
@@ -225,9 +265,9 @@ def gat_forward(handle, xa, kernel, a_self, a_nbr, bias=None, act='relu', xb=Non
     return out
 
 
-def spatial_layer_forward(net, p, x, e, h, d, act='relu'):
+def spatial_layer_forward(net, p, x, e, h, d, act='relu', flags=0):
     """One spatial-block loop body (`emulator.py:225-230`).  p: dict of the 14 tensors of
-    uds_spatial_params_t.  x:(S,N,fx), e:(S,E,fe) -> (S,N,d), (S,E,d)."""
+    uds_spatial_params_t.  x:(S,N,fx), e:(S,E,fe) -> (S,N,d), (S,E,d).  flags: FLAG_* of the C ABI."""
     lib = load()
     S, N, fx = x.shape
     _, E, fe = e.shape
@@ -245,6 +285,6 @@ def spatial_layer_forward(net, p, x, e, h, d, act='relu'):
     out_x = torch.empty((S, N, d), device=x.device, dtype=torch.float32)
     out_e = torch.empty((S, E, d), device=x.device, dtype=torch.float32)
     _check(lib.uds_spatial_layer_forward(net.ptr, ctypes.byref(sp), _dev(x, 'x'), fx, _dev(e, 'e'), fe, S, h, d, ACT[act],
-                                         _dev(ws, 'workspace'), _dev(out_x, 'out_x'), _dev(out_e, 'out_e'), _stream()),
+                                         int(flags), _dev(ws, 'workspace'), _dev(out_x, 'out_x'), _dev(out_e, 'out_e'), _stream()),
            'uds_spatial_layer_forward')
     return out_x, out_e

@@ -1,0 +1,233 @@
+// Host-side tile planner for the fused spatial-layer kernel (integer bookkeeping only).
+//
+// A "side" of a drainage network is (ADJ, INC): the GAT pattern among its primary rows and the
+// incidence support that feeds them from the secondary rows:
+//   node side : primary = nodes, ADJ = adj  (N x N), secondary = links, INC = inc_n (N x E)
+//   link side : primary = links, ADJ = edge_adj (E x E), secondary = nodes, INC = inc_e (E x N)
+// (reference: emulator.py:227-230 -- NodeEdge aggregation then GAT, on nodes and on links).
+//
+// Primary rows are clustered into tiles of at most t_max rows by a bottom-up packing of a BFS
+// spanning forest of ADJ: drainage networks are near-trees, so a cluster of T rows has O(1) cut
+// links instead of the O(T) a contiguous id range would have.  One workgroup computes one tile:
+//   own  rows  : outputs it writes                                   (first n_own of prim)
+//   halo rows  : ADJ-neighbours of own rows outside the cluster -- their transformed features are
+//                recomputed locally instead of exchanged            (rest of prim)
+//   sec  rows  : every secondary row incident to a prim row (their MLP output is recomputed too)
+// All lists are int32; local CSR indices point into prim / sec.  Tested in tests/test_tile_plan.py.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <numeric>
+#include <vector>
+
+namespace uds {
+
+struct HostCsr {
+  int64_t n_rows = 0, n_cols = 0;
+  std::vector<int32_t> rowptr, col;
+};
+
+constexpr int TILE_HDR_INTS = 8;  // n_own, n_prim, n_sec, n_inc, n_adj, pool_off, side, meta_len
+
+struct SidePlan {
+  int n_tiles = 0;
+  int p_cap = 0, q_cap = 0, meta_cap = 0;  // maxima over tiles (rows rounded up to 16, meta to 4 ints)
+  std::vector<int32_t> hdr;                // n_tiles * TILE_HDR_INTS
+  std::vector<int32_t> pool;               // per tile: prim[n_prim] sec[n_sec] inc_ptr[n_prim+1] inc_loc[n_inc]
+                                           //           inc_w[n_inc] adj_ptr[n_own+1] adj_loc[n_adj]
+  std::vector<int32_t> key;                // locality key per tile (min BFS index of a node it touches)
+  std::vector<int32_t> bfs_index;          // BFS visiting index of every primary row
+};
+
+// BFS spanning forest of adj (self loops ignored) + bottom-up packing into clusters of <= t_max rows.
+inline void cluster_rows(const HostCsr &adj, int t_max, std::vector<int32_t> &cluster_of, int &n_clusters,
+                         std::vector<int32_t> &bfs_index) {
+  const int32_t n = (int32_t)adj.n_rows;
+  cluster_of.assign(n, -1);
+  bfs_index.assign(n, -1);
+  std::vector<int32_t> order, parent(n, -1);
+  order.reserve(n);
+  for (int32_t root = 0; root < n; ++root) {
+    if (bfs_index[root] >= 0) continue;
+    bfs_index[root] = (int32_t)order.size();
+    order.push_back(root);
+    for (size_t head = order.size() - 1; head < order.size(); ++head) {
+      const int32_t v = order[head];
+      for (int32_t p = adj.rowptr[v]; p < adj.rowptr[v + 1]; ++p) {
+        const int32_t u = adj.col[p];
+        if (bfs_index[u] < 0) {
+          bfs_index[u] = (int32_t)order.size();
+          parent[u] = v;
+          order.push_back(u);
+        }
+      }
+    }
+  }
+  n_clusters = 0;
+  const int t_min = std::max(1, (3 * t_max) / 4);
+  std::vector<std::vector<int32_t>> open(n);          // rows of the still-open subtree hanging at v
+  std::vector<std::vector<int32_t>> kids(n);          // children whose open list is non-empty
+  auto close = [&](const std::vector<int32_t> &rows) {
+    if (rows.empty()) return;
+    for (int32_t r : rows) cluster_of[r] = n_clusters;
+    ++n_clusters;
+  };
+  for (int64_t k = (int64_t)order.size() - 1; k >= 0; --k) {
+    const int32_t v = order[k];
+    std::vector<int32_t> &mine = open[v];
+    mine.push_back(v);
+    std::vector<int32_t> &ch = kids[v];
+    std::stable_sort(ch.begin(), ch.end(), [&](int32_t x, int32_t y) { return open[x].size() > open[y].size(); });
+    std::vector<int32_t> spill;
+    for (int32_t c : ch) {
+      std::vector<int32_t> &lst = open[c];
+      if ((int)(mine.size() + lst.size()) <= t_max) {
+        mine.insert(mine.end(), lst.begin(), lst.end());
+      } else {
+        if ((int)(spill.size() + lst.size()) > t_max) {
+          close(spill);
+          spill.clear();
+        }
+        spill.insert(spill.end(), lst.begin(), lst.end());
+      }
+      std::vector<int32_t>().swap(lst);
+    }
+    close(spill);
+    if ((int)mine.size() >= t_min || parent[v] < 0) {
+      close(mine);
+      std::vector<int32_t>().swap(mine);
+    } else {
+      kids[parent[v]].push_back(v);
+    }
+    std::vector<int32_t>().swap(ch);
+  }
+}
+
+// node_bfs: BFS index of every NODE (for the locality key).  For the node side key_cols == nullptr
+// (keys come from the primary rows themselves); for the link side the key of a link is the smaller
+// node_bfs of its endpoints (the cols of its INC row).
+inline SidePlan build_side_plan(const HostCsr &adj, const HostCsr &inc, int t_max, int side,
+                                const std::vector<int32_t> *node_bfs) {
+  SidePlan plan;
+  std::vector<int32_t> cluster_of;
+  int n_clusters = 0;
+  cluster_rows(adj, t_max, cluster_of, n_clusters, plan.bfs_index);
+  const int32_t n = (int32_t)adj.n_rows;
+  std::vector<std::vector<int32_t>> members(n_clusters);
+  for (int32_t r = 0; r < n; ++r) members[cluster_of[r]].push_back(r);   // ascending ids
+  std::vector<int32_t> ploc(n, -1), sloc((size_t)inc.n_cols, -1);
+  plan.n_tiles = n_clusters;
+  plan.hdr.reserve((size_t)n_clusters * TILE_HDR_INTS);
+  for (int c = 0; c < n_clusters; ++c) {
+    const std::vector<int32_t> &own = members[c];
+    std::vector<int32_t> prim(own), halo, sec;
+    for (size_t i = 0; i < own.size(); ++i) ploc[own[i]] = (int32_t)i;
+    for (int32_t r : own)
+      for (int32_t p = adj.rowptr[r]; p < adj.rowptr[r + 1]; ++p) {
+        const int32_t u = adj.col[p];
+        if (ploc[u] < 0) {
+          ploc[u] = 0;  // mark, real index assigned after sorting
+          halo.push_back(u);
+        }
+      }
+    std::sort(halo.begin(), halo.end());
+    for (int32_t u : halo) {
+      ploc[u] = (int32_t)prim.size();
+      prim.push_back(u);
+    }
+    for (int32_t r : prim)
+      for (int32_t p = inc.rowptr[r]; p < inc.rowptr[r + 1]; ++p) {
+        const int32_t q = inc.col[p];
+        if (sloc[q] < 0) {
+          sloc[q] = 0;
+          sec.push_back(q);
+        }
+      }
+    std::sort(sec.begin(), sec.end());
+    for (size_t i = 0; i < sec.size(); ++i) sloc[sec[i]] = (int32_t)i;
+
+    const int32_t off = (int32_t)plan.pool.size();
+    plan.pool.insert(plan.pool.end(), prim.begin(), prim.end());
+    plan.pool.insert(plan.pool.end(), sec.begin(), sec.end());
+    std::vector<int32_t> inc_loc, inc_w, adj_loc;
+    plan.pool.push_back(0);
+    for (int32_t r : prim) {
+      for (int32_t p = inc.rowptr[r]; p < inc.rowptr[r + 1]; ++p) {
+        inc_loc.push_back(sloc[inc.col[p]]);
+        inc_w.push_back(p);                       // position in the global support-value array
+      }
+      plan.pool.push_back((int32_t)inc_loc.size());
+    }
+    plan.pool.insert(plan.pool.end(), inc_loc.begin(), inc_loc.end());
+    plan.pool.insert(plan.pool.end(), inc_w.begin(), inc_w.end());
+    plan.pool.push_back(0);
+    for (int32_t r : own) {
+      for (int32_t p = adj.rowptr[r]; p < adj.rowptr[r + 1]; ++p) adj_loc.push_back(ploc[adj.col[p]]);
+      plan.pool.push_back((int32_t)adj_loc.size());
+    }
+    plan.pool.insert(plan.pool.end(), adj_loc.begin(), adj_loc.end());
+    const int32_t meta_len = (int32_t)plan.pool.size() - off;
+    while (plan.pool.size() % 4) plan.pool.push_back(0);   // keep every tile's block 16-B aligned
+
+    int32_t key = INT32_MAX;
+    for (int32_t r : own) {
+      if (node_bfs) {
+        for (int32_t p = inc.rowptr[r]; p < inc.rowptr[r + 1]; ++p) key = std::min(key, (*node_bfs)[inc.col[p]]);
+      } else {
+        key = std::min(key, plan.bfs_index[r]);
+      }
+    }
+    plan.key.push_back(key);
+    const int32_t h[TILE_HDR_INTS] = {(int32_t)own.size(), (int32_t)prim.size(), (int32_t)sec.size(), (int32_t)inc_loc.size(),
+                                      (int32_t)adj_loc.size(), off, side, meta_len};
+    plan.hdr.insert(plan.hdr.end(), h, h + TILE_HDR_INTS);
+    plan.p_cap = std::max(plan.p_cap, ((int)prim.size() + 15) / 16 * 16);
+    plan.q_cap = std::max(plan.q_cap, ((int)sec.size() + 15) / 16 * 16);
+    plan.meta_cap = std::max(plan.meta_cap, (meta_len + 3) / 4 * 4);
+    for (int32_t r : prim) ploc[r] = -1;
+    for (int32_t q : sec) sloc[q] = -1;
+  }
+  return plan;
+}
+
+// LDS bytes the fused kernel needs for a plan: meta + s_self/s_nbr + sec rows (36-float stride) + hx rows.
+inline int64_t fused_lds_bytes(int p_cap, int q_cap, int meta_cap, int h, int d) {
+  return 4 * ((int64_t)meta_cap + 2 * p_cap + (int64_t)q_cap * (h + 4) + (int64_t)p_cap * d);
+}
+
+// Both sides of a network merged into one tile list ordered by locality key, so that the node tile and
+// the link tile that touch the same part of the network get neighbouring workgroup ids (same XCD L2).
+struct NetworkPlan {
+  SidePlan side[2];
+  std::vector<int32_t> hdr;   // merged headers (pool_off rebased into `pool`)
+  std::vector<int32_t> pool;
+  int n_tiles = 0, p_cap = 0, q_cap = 0, meta_cap = 0, t_max[2] = {0, 0};
+};
+
+inline NetworkPlan build_network_plan(const HostCsr &adj, const HostCsr &eadj, const HostCsr &inc_n, const HostCsr &inc_e,
+                                      int t_node, int t_link) {
+  NetworkPlan np;
+  np.t_max[0] = t_node;
+  np.t_max[1] = t_link;
+  np.side[0] = build_side_plan(adj, inc_n, t_node, 0, nullptr);
+  np.side[1] = build_side_plan(eadj, inc_e, t_link, 1, &np.side[0].bfs_index);
+  struct Ref { int32_t key, side, idx; };
+  std::vector<Ref> refs;
+  for (int s = 0; s < 2; ++s)
+    for (int t = 0; t < np.side[s].n_tiles; ++t) refs.push_back({np.side[s].key[t], s, t});
+  std::stable_sort(refs.begin(), refs.end(), [](const Ref &a, const Ref &b) { return a.key < b.key; });
+  const int32_t base1 = (int32_t)np.side[0].pool.size();
+  np.pool = np.side[0].pool;
+  np.pool.insert(np.pool.end(), np.side[1].pool.begin(), np.side[1].pool.end());
+  for (const Ref &r : refs) {
+    const int32_t *h = &np.side[r.side].hdr[(size_t)r.idx * TILE_HDR_INTS];
+    for (int i = 0; i < TILE_HDR_INTS; ++i) np.hdr.push_back(i == 5 ? h[i] + (r.side ? base1 : 0) : h[i]);
+  }
+  np.n_tiles = (int)refs.size();
+  np.p_cap = std::max(np.side[0].p_cap, np.side[1].p_cap);
+  np.q_cap = std::max(np.side[0].q_cap, np.side[1].q_cap);
+  np.meta_cap = std::max(np.side[0].meta_cap, np.side[1].meta_cap);
+  return np;
+}
+
+}  // namespace uds

@@ -14,6 +14,8 @@
 #include "../../include/uds_hip.h"
 #include "kernels_dense.hpp"
 #include "kernels_sparse.hpp"
+#include "kernels_fused.hpp"
+#include "tile_plan.hpp"
 
 namespace {
 
@@ -50,11 +52,65 @@ struct uds_csr {
   int32_t max_degree = 0;
   int32_t *d_rowptr = nullptr, *d_col = nullptr, *d_order = nullptr;
   std::vector<int32_t> h_order;
+  uds::HostCsr host;   // kept for the tile planner
+};
+
+struct uds_tile_plan {
+  uds::NetworkPlan plan;
 };
 
 struct uds_network {
-  const uds_csr *adj, *edge_adj, *inc_n, *inc_e;
+  const uds_csr *adj = nullptr, *edge_adj = nullptr, *inc_n = nullptr, *inc_e = nullptr;
+  bool fused_ok = false;          // a tile plan that fits the LDS budget exists
+  uds::NetworkPlan plan;
+  int32_t *d_hdr = nullptr, *d_pool = nullptr;
+  int64_t lds_bytes = 0;
 };
+
+namespace {
+
+constexpr int64_t FUSED_LDS_BUDGET = 78 * 1024;   // two workgroups per CU (160 KiB LDS)
+constexpr int64_t PACKED_WEIGHT_FLOATS = 2 * (768 + 2048) * 4;   // both sides, F_in up to 96: uint4 = 4 floats
+
+// Largest tile sizes whose plan fits the LDS budget (h = 32, d = 64 kernel).
+bool plan_network(const uds::HostCsr &adj, const uds::HostCsr &eadj, const uds::HostCsr &inc_n, const uds::HostCsr &inc_e,
+                  int t_node, int t_link, uds::NetworkPlan &out, int64_t &lds) {
+  for (int attempt = 0; attempt < 12 && t_node >= 8 && t_link >= 8; ++attempt) {
+    out = uds::build_network_plan(adj, eadj, inc_n, inc_e, t_node, t_link);
+    const int64_t ln = uds::fused_lds_bytes(out.side[0].p_cap, out.side[0].q_cap, out.side[0].meta_cap, uds::FUSED_H, uds::FUSED_D);
+    const int64_t ll = uds::fused_lds_bytes(out.side[1].p_cap, out.side[1].q_cap, out.side[1].meta_cap, uds::FUSED_H, uds::FUSED_D);
+    lds = uds::fused_lds_bytes(out.p_cap, out.q_cap, out.meta_cap, uds::FUSED_H, uds::FUSED_D);
+    if (lds <= FUSED_LDS_BUDGET) return true;
+    if (ln > FUSED_LDS_BUDGET * 9 / 10 || ln >= ll) t_node = t_node * 4 / 5;
+    if (ll > FUSED_LDS_BUDGET * 9 / 10 || ll > ln) t_link = t_link * 4 / 5;
+  }
+  return false;
+}
+
+}  // namespace
+
+namespace {
+
+template <int FP, int FS>
+hipError_t launch_fused(const uds::FusedArgs &a, int grid, int64_t lds, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&uds::k_fused_side<FP, FS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BUDGET);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((uds::k_fused_side<FP, FS>), dim3(grid), dim3(256), (size_t)lds, st, a);
+  return hipGetLastError();
+}
+
+hipError_t pack_weights(const float *W, int K, int F_out, uint4 *out, hipStream_t st) {
+  const int total = (K / 32) * (F_out / 16) * 64;
+  hipLaunchKernelGGL(uds::k_pack_weight_frags, dim3((total + 255) / 256), dim3(256), 0, st, W, K, F_out, out);
+  return hipGetLastError();
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -84,6 +140,10 @@ int uds_csr_create(const int32_t *rowptr, const int32_t *col, int64_t n_rows, in
   c->n_cols = n_cols;
   c->nnz = nnz;
   c->max_degree = max_deg;
+  c->host.n_rows = n_rows;
+  c->host.n_cols = n_cols;
+  c->host.rowptr.assign(rowptr, rowptr + n_rows + 1);
+  c->host.col.assign(col, col + nnz);
   // degree-sorted schedule: descending degree, ties by row index (stable)
   c->h_order.resize(n_rows);
   std::iota(c->h_order.begin(), c->h_order.end(), 0);
@@ -205,26 +265,110 @@ int uds_network_create(const uds_csr_t *adj, const uds_csr_t *edge_adj, const ud
               "uds_network_create: incidence shapes (%lld x %lld), (%lld x %lld) do not match N=%lld E=%lld",
               (long long)inc_n->n_rows, (long long)inc_n->n_cols, (long long)inc_e->n_rows, (long long)inc_e->n_cols,
               (long long)N, (long long)E);
-  uds_network *n = new (std::nothrow) uds_network{adj, edge_adj, inc_n, inc_e};
+  uds_network *n = new (std::nothrow) uds_network;
   if (!n) return fail(UDS_ENOMEM, "uds_network_create: host allocation failed");
+  n->adj = adj;
+  n->edge_adj = edge_adj;
+  n->inc_n = inc_n;
+  n->inc_e = inc_e;
+  // tile plan for the fused kernel (needs every row to own its self loop: GAT patterns always do)
+  if (N > 0 && E > 0 && plan_network(adj->host, edge_adj->host, inc_n->host, inc_e->host, 128, 120, n->plan, n->lds_bytes)) {
+    hipError_t e;
+    if ((e = hipMalloc(&n->d_hdr, sizeof(int32_t) * n->plan.hdr.size())) != hipSuccess ||
+        (e = hipMalloc(&n->d_pool, sizeof(int32_t) * n->plan.pool.size())) != hipSuccess ||
+        (e = hipMemcpy(n->d_hdr, n->plan.hdr.data(), sizeof(int32_t) * n->plan.hdr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(n->d_pool, n->plan.pool.data(), sizeof(int32_t) * n->plan.pool.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+      hipFree(n->d_hdr);
+      hipFree(n->d_pool);
+      delete n;
+      return fail(UDS_ENOMEM, "uds_network_create: tile plan upload -> %s", hipGetErrorString(e));
+    }
+    n->fused_ok = true;
+  }
   *out = n;
   return UDS_OK;
 }
 
 int uds_network_destroy(uds_network_t *net) {
+  if (!net) return UDS_OK;
+  hipFree(net->d_hdr);
+  hipFree(net->d_pool);
   delete net;
+  return UDS_OK;
+}
+
+int uds_network_plan_info(const uds_network_t *net, int32_t *info8) {
+  UDS_REQUIRE(net && info8, "uds_network_plan_info: NULL argument");
+  info8[0] = net->fused_ok ? 1 : 0;
+  info8[1] = net->plan.side[0].n_tiles;
+  info8[2] = net->plan.side[1].n_tiles;
+  info8[3] = net->plan.p_cap;
+  info8[4] = net->plan.q_cap;
+  info8[5] = net->plan.meta_cap;
+  info8[6] = (int32_t)net->lds_bytes;
+  info8[7] = net->plan.t_max[0] * 1000 + net->plan.t_max[1];
+  return UDS_OK;
+}
+
+// ---- host-only tile planner access (integer bookkeeping, testable without a GPU) ----
+int uds_tile_plan_create(const int32_t *adj_rowptr, const int32_t *adj_col, const int32_t *eadj_rowptr, const int32_t *eadj_col,
+                         const int32_t *incn_rowptr, const int32_t *incn_col, const int32_t *ince_rowptr, const int32_t *ince_col,
+                         int64_t n_node, int64_t n_edge, int32_t t_node, int32_t t_link, uds_tile_plan_t **out) {
+  UDS_REQUIRE(out != nullptr, "uds_tile_plan_create: out is NULL");
+  *out = nullptr;
+  UDS_REQUIRE(adj_rowptr && adj_col && eadj_rowptr && eadj_col && incn_rowptr && ince_rowptr, "uds_tile_plan_create: NULL array");
+  UDS_REQUIRE(n_node > 0 && n_edge > 0 && t_node >= 1 && t_link >= 1, "uds_tile_plan_create: bad sizes");
+  auto mk = [](const int32_t *rp, const int32_t *c, int64_t r, int64_t cc) {
+    uds::HostCsr h;
+    h.n_rows = r;
+    h.n_cols = cc;
+    h.rowptr.assign(rp, rp + r + 1);
+    h.col.assign(c, c + rp[r]);
+    return h;
+  };
+  uds_tile_plan *tp = new (std::nothrow) uds_tile_plan;
+  if (!tp) return fail(UDS_ENOMEM, "uds_tile_plan_create: host allocation failed");
+  tp->plan = uds::build_network_plan(mk(adj_rowptr, adj_col, n_node, n_node), mk(eadj_rowptr, eadj_col, n_edge, n_edge),
+                                     mk(incn_rowptr, incn_col, n_node, n_edge), mk(ince_rowptr, ince_col, n_edge, n_node),
+                                     t_node, t_link);
+  *out = tp;
+  return UDS_OK;
+}
+
+int uds_tile_plan_destroy(uds_tile_plan_t *tp) {
+  delete tp;
+  return UDS_OK;
+}
+
+int uds_tile_plan_sizes(const uds_tile_plan_t *tp, int64_t *n_tiles, int64_t *pool_len, int32_t *caps3) {
+  UDS_REQUIRE(tp != nullptr, "uds_tile_plan_sizes: NULL plan");
+  if (n_tiles) *n_tiles = tp->plan.n_tiles;
+  if (pool_len) *pool_len = (int64_t)tp->plan.pool.size();
+  if (caps3) {
+    caps3[0] = tp->plan.p_cap;
+    caps3[1] = tp->plan.q_cap;
+    caps3[2] = tp->plan.meta_cap;
+  }
+  return UDS_OK;
+}
+
+int uds_tile_plan_copy(const uds_tile_plan_t *tp, int32_t *hdr_out, int32_t *pool_out) {
+  UDS_REQUIRE(tp && hdr_out && pool_out, "uds_tile_plan_copy: NULL argument");
+  std::memcpy(hdr_out, tp->plan.hdr.data(), sizeof(int32_t) * tp->plan.hdr.size());
+  std::memcpy(pool_out, tp->plan.pool.data(), sizeof(int32_t) * tp->plan.pool.size());
   return UDS_OK;
 }
 
 int64_t uds_spatial_workspace_floats(const uds_network_t *net, int64_t S, int64_t h, int64_t d) {
   if (!net) return 0;
   const int64_t N = net->adj->n_rows, E = net->edge_adj->n_rows;
-  // x_e (E,h) + e_x (N,h) + agg_n (N,h) + agg_e (E,h) + hx,s (N,d+2) + he,s (E,d+2)
-  return S * 2 * (N + E) * h + align4(S * N * (d + 2)) + align4(S * E * (d + 2));
+  // packed weight fragments (fused path) + x_e (E,h) + e_x (N,h) + agg_n (N,h) + agg_e (E,h) + hx,s (N,d+2) + he,s (E,d+2)
+  return PACKED_WEIGHT_FLOATS + S * 2 * (N + E) * h + align4(S * N * (d + 2)) + align4(S * E * (d + 2));
 }
 
+
 int uds_spatial_layer_forward(const uds_network_t *net, const uds_spatial_params_t *p, const float *x, int64_t fx,
-                              const float *e, int64_t fe, int64_t S, int64_t h, int64_t d, int act, float *ws,
+                              const float *e, int64_t fe, int64_t S, int64_t h, int64_t d, int act, int flags, float *ws,
                               float *out_x, float *out_e, uds_stream_t stream) {
   UDS_REQUIRE(net && p && x && e && ws && out_x && out_e, "uds_spatial_layer_forward: NULL argument");
   UDS_REQUIRE(p->xe_k && p->ex_k && p->ne_n_val && p->ne_e_val && p->gx_k && p->gx_as && p->gx_an && p->ge_k &&
@@ -232,9 +376,68 @@ int uds_spatial_layer_forward(const uds_network_t *net, const uds_spatial_params
               "uds_spatial_layer_forward: NULL parameter tensor");
   UDS_REQUIRE(h > 0 && h % 4 == 0 && d > 0 && d % 4 == 0, "uds_spatial_layer_forward: h=%lld d=%lld must be multiples of 4",
               (long long)h, (long long)d);
+  UDS_REQUIRE(act >= UDS_ACT_LINEAR && act <= UDS_ACT_HARD_SIGMOID, "uds_spatial_layer_forward: unknown activation %d", act);
   UDS_REQUIRE(out_x != x && out_e != e, "uds_spatial_layer_forward: outputs must not alias inputs");
+  UDS_REQUIRE(aligned16(x) && aligned16(e) && aligned16(ws) && aligned16(out_x) && aligned16(out_e),
+              "uds_spatial_layer_forward: x/e/workspace/outputs must be 16-byte aligned");
   const int64_t N = net->adj->n_rows, E = net->edge_adj->n_rows;
-  float *x_e = ws;                    // (S,E,h)
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (S == 0) return UDS_OK;
+
+  const bool shape_ok = h == uds::FUSED_H && d == uds::FUSED_D && (fx == 64 || fx == 96) && (fe == 64 || fe == 96);
+  if (flags & UDS_FLAG_REQUIRE_FUSED)
+    UDS_REQUIRE(net->fused_ok && shape_ok && !(flags & UDS_FLAG_EXACT_FP32),
+                "uds_spatial_layer_forward: fused kernel unavailable (plan %d, fx=%lld fe=%lld h=%lld d=%lld)", (int)net->fused_ok,
+                (long long)fx, (long long)fe, (long long)h, (long long)d);
+  if (net->fused_ok && shape_ok && !(flags & UDS_FLAG_EXACT_FP32)) {
+    UDS_REQUIRE(aligned16(p->xe_b) && aligned16(p->ex_b) && aligned16(p->gx_as) && aligned16(p->gx_an) && aligned16(p->gx_b) &&
+                    aligned16(p->ge_as) && aligned16(p->ge_an) && aligned16(p->ge_b),
+                "uds_spatial_layer_forward: bias / attention vectors must be 16-byte aligned");
+    uint4 *wq = reinterpret_cast<uint4 *>(ws);
+    uint4 *w_small_n = wq, *w_big_n = wq + 768, *w_small_e = wq + 768 + 2048, *w_big_e = wq + 2 * 768 + 2048;
+    hipError_t he;
+    // node side: secondary = links (xe_k on e), big = gx_k; link side: secondary = nodes (ex_k on x), big = ge_k
+    if ((he = pack_weights(p->xe_k, (int)fe, (int)h, w_small_n, st)) != hipSuccess ||
+        (he = pack_weights(p->gx_k, (int)(fx + h), (int)d, w_big_n, st)) != hipSuccess ||
+        (he = pack_weights(p->ex_k, (int)fx, (int)h, w_small_e, st)) != hipSuccess ||
+        (he = pack_weights(p->ge_k, (int)(fe + h), (int)d, w_big_e, st)) != hipSuccess)
+      return fail(UDS_EHIP, "uds_spatial_layer_forward: weight packing -> %s", hipGetErrorString(he));
+    uds::FusedArgs a;
+    a.side[0] = uds::FusedSide{x, e, out_x, w_small_n, w_big_n, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
+    a.side[1] = uds::FusedSide{e, x, out_e, w_small_e, w_big_e, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};
+    a.hdr = net->d_hdr;
+    a.pool = net->d_pool;
+    a.n_tiles = net->plan.n_tiles;
+    a.S = (int)S;
+    a.p_cap = net->plan.p_cap;
+    a.q_cap = net->plan.q_cap;
+    a.meta_cap = net->plan.meta_cap;
+    a.act = act;
+    // enough workgroups to fill 256 CUs x 2 several times over, but >= 4 snapshots per workgroup when S allows
+    // (weights are loaded once per workgroup)
+    int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>(S, (4096 + a.n_tiles - 1) / a.n_tiles));
+    int64_t chunk = (S + n_chunks - 1) / n_chunks;
+    if (chunk < 4 && S >= 4) chunk = 4;
+    n_chunks = (S + chunk - 1) / chunk;
+    a.chunk = (int)chunk;
+    const int grid = (int)(n_chunks * a.n_tiles);
+    if (fx == fe) {
+      a.side_mask = 3;
+      he = (fx == 64) ? launch_fused<64, 64>(a, grid, net->lds_bytes, st) : launch_fused<96, 96>(a, grid, net->lds_bytes, st);
+    } else {   // node tiles: FP = fx, FS = fe; link tiles: FP = fe, FS = fx -> one launch per side
+      a.side_mask = 1;
+      he = (fx == 64) ? launch_fused<64, 96>(a, grid, net->lds_bytes, st) : launch_fused<96, 64>(a, grid, net->lds_bytes, st);
+      if (he == hipSuccess) {
+        a.side_mask = 2;
+        he = (fe == 64) ? launch_fused<64, 96>(a, grid, net->lds_bytes, st) : launch_fused<96, 64>(a, grid, net->lds_bytes, st);
+      }
+    }
+    if (he != hipSuccess) return fail(UDS_EHIP, "uds_spatial_layer_forward: fused launch -> %s", hipGetErrorString(he));
+    return UDS_OK;
+  }
+
+  float *base = ws + PACKED_WEIGHT_FLOATS;
+  float *x_e = base;                  // (S,E,h)
   float *e_x = x_e + S * E * h;       // (S,N,h)
   float *agg_n = e_x + S * N * h;     // (S,N,h)
   float *agg_e = agg_n + S * N * h;   // (S,E,h)

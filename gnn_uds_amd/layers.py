@@ -268,8 +268,12 @@ class SpatialLayer(nn.Module):
     entry uds_spatial_layer_forward (concats are never materialised)."""
 
     def __init__(self, graph, embed_size, activation='relu', fx=None, fe=None, sparse_params=None, net=None,
-                 generator=None):
+                 generator=None, precision='bf16x3'):
         super().__init__()
+        if precision not in _lib.PRECISION_FLAGS:
+            raise ValueError("precision must be 'bf16x3' (fused kernel, split-bf16 MFMA, fp32 accumulate) or 'fp32' "
+                             "(exact-fp32 unfused kernels), got %r" % (precision,))
+        self.precision = precision
         if not isinstance(graph, DrainageGraph):
             raise TypeError('graph must be a gnn_uds_amd.graph.DrainageGraph')
         self.graph, self.d, self.h, self.activation = graph, int(embed_size), int(embed_size) // 2, activation
@@ -324,7 +328,8 @@ class SpatialLayer(nn.Module):
                      gx_b=self.gat_x.bias,
                      ge_k=self.gat_e.kernel, ge_as=self.gat_e.attn_kernel_self, ge_an=self.gat_e.attn_kernel_neighs,
                      ge_b=self.gat_e.bias)
-            ox, oe = _lib.spatial_layer_forward(self.network(), p, xs, es, self.h, self.d, self.activation)
+            ox, oe = _lib.spatial_layer_forward(self.network(), p, xs, es, self.h, self.d, self.activation,
+                                                _lib.PRECISION_FLAGS[self.precision])
         else:   # trained dense NodeEdge bias: unfused composition with the dense remainder GEMM
             net = self.network()
             x_e, e_x = self.dense_xe(es), self.dense_ex(xs)
@@ -337,13 +342,12 @@ class SpatialBlock(nn.Module):
     """`for _ in range(n_sp_layer)` (`emulator.py:219-235`): first layer takes (fx, fe) features."""
 
     def __init__(self, graph, embed_size, n_sp_layer, activation='relu', fx=None, fe=None, sparse_params=None,
-                 generator=None):
+                 generator=None, precision='bf16x3'):
         super().__init__()
-        self._net_holder = [None]
         layers = []
         for i in range(n_sp_layer):
             layers.append(SpatialLayer(graph, embed_size, activation, fx if i == 0 else None, fe if i == 0 else None,
-                                       sparse_params, generator=generator))
+                                       sparse_params, generator=generator, precision=precision))
         self.layers = nn.ModuleList(layers)
         self.graph = graph
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 1
+#define UDS_ABI_VERSION 2
 
 enum {
   UDS_OK = 0,
@@ -106,6 +106,22 @@ typedef struct uds_network uds_network_t;
 int uds_network_create(const uds_csr_t *adj, const uds_csr_t *edge_adj, const uds_csr_t *inc_n,
                        const uds_csr_t *inc_e, uds_network_t **out);
 int uds_network_destroy(uds_network_t *net);
+/* info8 = {fused plan available, node tiles, link tiles, max primary rows per tile, max secondary rows per
+ * tile, max metadata ints per tile, LDS bytes per workgroup, t_node*1000 + t_link}. */
+int uds_network_plan_info(const uds_network_t *net, int32_t *info8);
+
+/* Host-only access to the tile planner (integer bookkeeping; works without a GPU).  A plan clusters the
+ * primary rows of each side (nodes under adj, links under edge_adj) into tiles of at most t_node / t_link
+ * rows and lists, per tile, own rows, halo rows, secondary rows and local CSR indices (layout:
+ * gnn_uds_amd/csrc/tile_plan.hpp).  hdr_out holds 8 ints per tile, pool_out pool_len ints. */
+typedef struct uds_tile_plan uds_tile_plan_t;
+int uds_tile_plan_create(const int32_t *adj_rowptr, const int32_t *adj_col, const int32_t *eadj_rowptr,
+                         const int32_t *eadj_col, const int32_t *incn_rowptr, const int32_t *incn_col,
+                         const int32_t *ince_rowptr, const int32_t *ince_col, int64_t n_node,
+                         int64_t n_edge, int32_t t_node, int32_t t_link, uds_tile_plan_t **out);
+int uds_tile_plan_destroy(uds_tile_plan_t *plan);
+int uds_tile_plan_sizes(const uds_tile_plan_t *plan, int64_t *n_tiles, int64_t *pool_len, int32_t *caps3);
+int uds_tile_plan_copy(const uds_tile_plan_t *plan, int32_t *hdr_out, int32_t *pool_out);
 
 typedef struct uds_spatial_params {
   const float *xe_k, *xe_b; /* Dense(h) on e -> x_e : (fe, h), (h)            emulator.py:225 */
@@ -116,14 +132,23 @@ typedef struct uds_spatial_params {
   const float *ge_k, *ge_as, *ge_an, *ge_b; /* GAT links: (fe+h, d),(d),(d),(d) emulator.py:230 */
 } uds_spatial_params_t;
 
+/* flags of uds_spatial_layer_forward */
+enum {
+  UDS_FLAG_EXACT_FP32 = 1,   /* exact-fp32 fmaf kernels (unfused); default is the fused kernel whose GEMMs
+                                run as 3-term bf16-split MFMA with fp32 accumulation (~2^-16 per product) */
+  UDS_FLAG_REQUIRE_FUSED = 2 /* fail instead of falling back when the fused kernel cannot take the shape */
+};
+
 /* Floats of workspace uds_spatial_layer_forward needs. */
 int64_t uds_spatial_workspace_floats(const uds_network_t *net, int64_t S, int64_t h, int64_t d);
 
-/* x:(S,N,fx), e:(S,E,fe) -> out_x:(S,N,d), out_e:(S,E,d).  out_* must not alias x / e. */
+/* x:(S,N,fx), e:(S,E,fe) -> out_x:(S,N,d), out_e:(S,E,d).  out_* must not alias x / e.
+ * Fused single-pass kernel for h = 32, d = 64, fx, fe in {64, 96}; other shapes (and UDS_FLAG_EXACT_FP32)
+ * run the unfused exact-fp32 kernels. */
 int uds_spatial_layer_forward(const uds_network_t *net, const uds_spatial_params_t *params,
                               const float *x, int64_t fx, const float *e, int64_t fe, int64_t S,
-                              int64_t h, int64_t d, int act, float *workspace, float *out_x,
-                              float *out_e, uds_stream_t stream);
+                              int64_t h, int64_t d, int act, int flags, float *workspace,
+                              float *out_x, float *out_e, uds_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,9 @@ from oracle import spektral_dense as OD
 from tests.util import cast, load_spatial_layer, spatial_params
 
 pytestmark = pytest.mark.gpu
-TOL = 2e-5
+TOL = 2e-5          # exact-fp32 kernels
+TOL_BF16X3 = 2e-4   # fused kernel: GEMM operands split into bf16 hi+lo, 3 products, fp32 accumulate (~2^-16/product)
+PREC_TOL = {'fp32': TOL, 'bf16x3': TOL_BF16X3}
 
 
 @pytest.fixture(scope='module')
@@ -142,8 +144,11 @@ def test_node_edge_dense_parameters(dev, networks, trained_bias):
     assert (layer.support_values()[1] is not None) == trained_bias
 
 
-@pytest.mark.parametrize('name,d,S', [('astlingen', 8, 1), ('shunqing', 64, 3), ('RedChicoSur', 64, 2), ('hague', 128, 2)])
-def test_spatial_layer_vs_dense_masked_oracle(dev, networks, name, d, S):
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+@pytest.mark.parametrize('name,d,S', [('astlingen', 8, 1), ('shunqing', 64, 3), ('RedChicoSur', 64, 2), ('hague', 128, 2),
+                                      ('chaohu', 64, 7), ('astlingen', 64, 1)])
+def test_spatial_layer_vs_dense_masked_oracle(dev, networks, name, d, S, precision):
+    tol = PREC_TOL[precision]
     net = networks[name]
     gph = U.DrainageGraph.from_edges(np.array(net['edges']), net['n_node'])
     p = spatial_params(gph.n_node, gph.n_edge, d, d, d, seed=7)
@@ -151,9 +156,12 @@ def test_spatial_layer_vs_dense_masked_oracle(dev, networks, name, d, S):
     x, e = rnd(g, S, gph.n_node, d), rnd(g, S, gph.n_edge, d)
     ne = torch.from_numpy(gph.inc_n.to_dense())
     rx, re = OD.spatial_layer_dense(x, e, p, torch.from_numpy(gph.adj.to_dense()), torch.from_numpy(gph.edge_adj.to_dense()), ne)
-    layer = load_spatial_layer(U.SpatialLayer(gph, d, 'relu', sparse_params=False), p, dev)
+    layer = load_spatial_layer(U.SpatialLayer(gph, d, 'relu', sparse_params=False, precision=precision), p, dev)
     ox, oe = layer(x.float().to(dev), e.float().to(dev))
-    close(ox, rx); close(oe, re)
+    close(ox, rx, tol); close(oe, re, tol)
+    if d == 64:
+        info = layer.network().plan_info()
+        assert info['fused'] == 1 and info['lds_bytes'] <= 78 * 1024
     # trained (dense) NodeEdge bias -> unfused composition + remainder GEMM, same answer as the dense oracle
     p['ne_n_b'] = torch.randn(p['ne_n_b'].shape, generator=g, dtype=torch.float64) * 0.01
     p['ne_e_b'] = torch.randn(p['ne_e_b'].shape, generator=g, dtype=torch.float64) * 0.01
@@ -179,18 +187,35 @@ def test_spatial_block_c1_wide_first_layer(dev):
     close(ox, rx); close(oe, re)
 
 
-def test_spatial_layer_c2_size_vs_sparse_oracle(dev):
-    """C2 scale (2k nodes / 2.5k conduits, d=64): the dense oracle is still feasible, use both."""
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+@pytest.mark.parametrize('fx,fe', [(64, 64), (96, 96), (96, 64), (64, 96)])
+def test_spatial_layer_c2_size_vs_sparse_oracle(dev, precision, fx, fe):
+    """C2 scale (2k nodes / 2.5k conduits, d=64) incl. the wide first layer of block 2 (`emulator.py:260-262`:
+    H + d/2 = 96 input features on either side): all four fused-kernel instantiations."""
     gph = U.DrainageGraph.from_edges(U.synthetic_drainage_network(2000, 2500, 0))
-    d, S = 64, 2
-    p = spatial_params(2000, 2500, d, d, d, seed=11, dense_ne=False, nnz_n=gph.inc_n.nnz, nnz_e=gph.inc_e.nnz)
+    d, S = 64, 3
+    p = spatial_params(2000, 2500, fx, fe, d, seed=11, dense_ne=False, nnz_n=gph.inc_n.nnz, nnz_e=gph.inc_e.nnz)
     g = torch.Generator().manual_seed(12)
-    x, e = rnd(g, S, 2000, d), rnd(g, S, 2500, d)
+    x, e = rnd(g, S, 2000, fx), rnd(g, S, 2500, fe)
     rx, re = OS.spatial_layer_csr(x, e, p, (gph.adj.rowptr, gph.adj.col), (gph.edge_adj.rowptr, gph.edge_adj.col),
                                   (gph.inc_n.rowptr, gph.inc_n.col), (gph.inc_e.rowptr, gph.inc_e.col))
-    layer = load_spatial_layer(U.SpatialLayer(gph, d, 'relu', sparse_params=True), p, dev)
+    layer = load_spatial_layer(U.SpatialLayer(gph, d, 'relu', fx=fx, fe=fe, sparse_params=True, precision=precision), p, dev)
     ox, oe = layer(x.float().to(dev), e.float().to(dev))
-    close(ox, rx); close(oe, re)
+    close(ox, rx, PREC_TOL[precision]); close(oe, re, PREC_TOL[precision])
+
+
+def test_fused_kernel_is_required_and_used(dev):
+    """UDS_FLAG_REQUIRE_FUSED: the call fails instead of silently falling back."""
+    gph = U.DrainageGraph.from_edges(U.synthetic_drainage_network(300, 360, 0))
+    layer = U.SpatialLayer(gph, 64, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1)).to(dev)
+    x, e = torch.rand(2, 300, 64, device=dev), torch.rand(2, 360, 64, device=dev)
+    vn, _ = layer.node_edge_n.support_values(); ve, _ = layer.node_edge_e.support_values()
+    p = {k: v.to(dev) if v is not None else None for k, v in layer.export_params().items() if not k.startswith('ne_')}
+    p.update(ne_n_val=vn, ne_e_val=ve)
+    ox, _ = _lib.spatial_layer_forward(layer.network(), p, x, e, 32, 64, 'relu', _lib.FLAG_REQUIRE_FUSED)
+    assert torch.equal(ox, layer(x, e)[0])
+    with pytest.raises(_lib.UdsError, match='fused kernel unavailable'):
+        _lib.spatial_layer_forward(layer.network(), p, x, e, 32, 64, 'relu', _lib.FLAG_REQUIRE_FUSED | _lib.FLAG_EXACT_FP32)
 
 
 def test_headline_size_properties(dev):
@@ -199,7 +224,7 @@ def test_headline_size_properties(dev):
     (2) two runs are bitwise identical (no atomics anywhere);
     (3) a spot check of 64 rows against the fp64 sparse oracle on that snapshot."""
     gph = U.DrainageGraph.from_edges(U.synthetic_drainage_network(10000, 12000, 0))
-    d, S = 64, 5
+    d, S = 64, 9
     layer = U.SpatialLayer(gph, d, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1)).to(dev)
     g = torch.Generator().manual_seed(2)
     x, e = torch.rand(S, 10000, d, generator=g).to(dev), torch.rand(S, 12000, d, generator=g).to(dev)
@@ -212,8 +237,15 @@ def test_headline_size_properties(dev):
     rx, re = OS.spatial_layer_csr(x[3:4].double().cpu(), e[3:4].double().cpu(), p, (gph.adj.rowptr, gph.adj.col),
                                   (gph.edge_adj.rowptr, gph.edge_adj.col), (gph.inc_n.rowptr, gph.inc_n.col),
                                   (gph.inc_e.rowptr, gph.inc_e.col))
-    close(ox[3:4], rx); close(oe[3:4], re)
+    close(ox[3:4], rx, TOL_BF16X3); close(oe[3:4], re, TOL_BF16X3)
     assert bool(torch.isfinite(ox).all()) and bool((ox >= 0).all())
+    # (4) the fused split-bf16 kernel and the exact-fp32 unfused kernels agree on the FULL tensors
+    exact = U.SpatialLayer(gph, d, 'relu', sparse_params=True, precision='fp32').to(dev)
+    exact.load_state_dict(layer.state_dict())
+    fx_, fe_ = exact(x, e)
+    close(fx_[3:4], rx); close(fe_[3:4], re)
+    assert float((fx_ - ox).abs().max()) <= TOL_BF16X3 * max(1.0, float(fx_.abs().max()))
+    assert float((fe_ - oe).abs().max()) <= TOL_BF16X3 * max(1.0, float(fe_.abs().max()))
 
 
 def test_cpu_tensors_are_refused(dev):

@@ -1,0 +1,79 @@
+"""Tile plans of the fused kernel: integer bookkeeping, checked on the host (no GPU) against the
+definitions -- every row owned exactly once, halos = exactly the missing neighbours, local indices
+resolve to the right global rows, weight positions address the global support arrays."""
+import numpy as np
+import pytest
+
+import gnn_uds_amd as U
+from gnn_uds_amd import _lib
+
+
+def decode(hdr, pool, t):
+    n_own, n_prim, n_sec, n_inc, n_adj, off, side, meta_len = (int(v) for v in hdr[t])
+    p = off
+    prim = pool[p:p + n_prim]; p += n_prim
+    sec = pool[p:p + n_sec]; p += n_sec
+    inc_ptr = pool[p:p + n_prim + 1]; p += n_prim + 1
+    inc_loc = pool[p:p + n_inc]; p += n_inc
+    inc_w = pool[p:p + n_inc]; p += n_inc
+    adj_ptr = pool[p:p + n_own + 1]; p += n_own + 1
+    adj_loc = pool[p:p + n_adj]; p += n_adj
+    assert p - off == meta_len and off % 4 == 0
+    return dict(n_own=n_own, prim=prim, sec=sec, inc_ptr=inc_ptr, inc_loc=inc_loc, inc_w=inc_w, adj_ptr=adj_ptr,
+                adj_loc=adj_loc, side=side)
+
+
+def check_plan(g, hdr, pool, caps, t_node, t_link):
+    sides = [(g.adj, g.inc_n, t_node), (g.edge_adj, g.inc_e, t_link)]
+    owned = [np.zeros(g.n_node, int), np.zeros(g.n_edge, int)]
+    for t in range(len(hdr)):
+        d = decode(hdr, pool, t)
+        adj, inc, t_max = sides[d['side']]
+        own = d['prim'][:d['n_own']]
+        assert 1 <= d['n_own'] <= t_max and (np.diff(own) > 0).all()
+        owned[d['side']][own] += 1
+        nb = np.unique(np.concatenate([adj.col[adj.rowptr[r]:adj.rowptr[r + 1]] for r in own]))
+        halo = np.setdiff1d(nb, own)
+        assert np.array_equal(d['prim'][d['n_own']:], halo)                 # halo = exactly the outside neighbours
+        need = np.unique(np.concatenate([inc.col[inc.rowptr[r]:inc.rowptr[r + 1]] for r in d['prim']] + [np.zeros(0, np.int32)]))
+        assert np.array_equal(d['sec'], need)                              # secondary rows = everything incident
+        for i, r in enumerate(d['prim']):
+            lo, hi = d['inc_ptr'][i], d['inc_ptr'][i + 1]
+            assert np.array_equal(d['sec'][d['inc_loc'][lo:hi]], inc.col[inc.rowptr[r]:inc.rowptr[r + 1]])
+            assert np.array_equal(d['inc_w'][lo:hi], np.arange(inc.rowptr[r], inc.rowptr[r + 1]))
+        for i, r in enumerate(own):
+            lo, hi = d['adj_ptr'][i], d['adj_ptr'][i + 1]
+            assert np.array_equal(d['prim'][d['adj_loc'][lo:hi]], adj.col[adj.rowptr[r]:adj.rowptr[r + 1]])
+        assert len(d['prim']) <= caps['p_cap'] and len(d['sec']) <= caps['q_cap'] and hdr[t, 7] <= caps['meta_cap']
+    assert (owned[0] == 1).all() and (owned[1] == 1).all()                 # a partition of nodes and of links
+
+
+@pytest.mark.parametrize('name', ['astlingen', 'shunqing', 'chaohu', 'hague', 'RedChicoSur'])
+def test_plan_on_real_networks(networks, name):
+    net = networks[name]
+    g = U.DrainageGraph.from_edges(np.array(net['edges']), net['n_node'])
+    for t_node, t_link in ((128, 120), (16, 12), (1, 1)):
+        hdr, pool, caps = _lib.tile_plan(g, t_node, t_link)
+        check_plan(g, hdr, pool, caps, t_node, t_link)
+
+
+def test_plan_with_isolated_rows_and_self_loop_link():
+    e = np.array([[0, 1], [1, 1], [1, 2], [4, 2]])
+    g = U.DrainageGraph.from_edges(e, n_node=6)            # nodes 3 and 5 isolated, link 1 self-referential
+    hdr, pool, caps = _lib.tile_plan(g, 4, 4)
+    check_plan(g, hdr, pool, caps, 4, 4)
+
+
+def test_headline_plan_has_small_halos():
+    """Near-tree clustering: halo rows stay a small fraction (what makes one-pass fusion pay)."""
+    g = U.DrainageGraph.from_edges(U.synthetic_drainage_network(10000, 12000, 0))
+    hdr, pool, caps = _lib.tile_plan(g, 112, 104)
+    check_plan(g, hdr, pool, caps, 112, 104)
+    for side, n in ((0, g.n_node), (1, g.n_edge)):
+        h = hdr[hdr[:, 6] == side]
+        assert h[:, 0].sum() == n
+        assert h[:, 1].sum() <= 1.35 * n                   # prim rows (own + halo) per side
+    lds = 4 * (caps['meta_cap'] + 2 * caps['p_cap'] + caps['q_cap'] * 36 + caps['p_cap'] * 64)
+    assert lds <= 78 * 1024
+    a, b, c = _lib.tile_plan(g, 112, 104)
+    assert np.array_equal(a, hdr) and np.array_equal(b, pool)   # deterministic
