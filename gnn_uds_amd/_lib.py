@@ -41,7 +41,7 @@ SYMBOLS = {
     'uds_network_create': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, ctypes.POINTER(_c_ptr)]),
     'uds_network_destroy': (_c_int, [_c_ptr]),
     'uds_network_plan_info': (_c_int, [_c_ptr, _c_ptr]),
-    'uds_tile_plan_create': (_c_int, [_c_ptr] * 8 + [_c_i64, _c_i64, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_c_ptr)]),
+    'uds_tile_plan_create': (_c_int, [_c_ptr] * 8 + [_c_i64, _c_i64] + [ctypes.c_int32] * 4 + [ctypes.POINTER(_c_ptr)]),
     'uds_tile_plan_destroy': (_c_int, [_c_ptr]),
     'uds_tile_plan_sizes': (_c_int, [_c_ptr, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64), _c_ptr]),
     'uds_tile_plan_copy': (_c_int, [_c_ptr, _c_ptr, _c_ptr]),
@@ -177,7 +177,7 @@ class NetworkHandle:
             _lib.uds_network_destroy(h)
 
 
-def tile_plan(graph, t_node=128, t_link=120):
+def tile_plan(graph, t_node=48, t_link=48, p_limit=0, q_limit=0):
     """Host-only tile plan of a DrainageGraph (no GPU needed): returns (hdr (T,8) int32, pool int32, caps).
     hdr columns: n_own, n_prim, n_sec, n_inc, n_adj, pool_off, side, meta_len (csrc/tile_plan.hpp)."""
     lib = load()
@@ -186,7 +186,7 @@ def tile_plan(graph, t_node=128, t_link=120):
         arrs += [np.ascontiguousarray(c.rowptr, dtype=np.int32), np.ascontiguousarray(c.col, dtype=np.int32)]
     h = _c_ptr()
     _check(lib.uds_tile_plan_create(*[a.ctypes.data for a in arrs], graph.n_node, graph.n_edge, t_node, t_link,
-                                    ctypes.byref(h)), 'uds_tile_plan_create')
+                                    p_limit, q_limit, ctypes.byref(h)), 'uds_tile_plan_create')
     try:
         nt, pl = _c_i64(), _c_i64()
         caps = np.zeros(3, dtype=np.int32)

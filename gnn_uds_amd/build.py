@@ -36,6 +36,10 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=' + ARCH, '-fPIC', '-shared', '-fgpu-rdc' if False else '-fno-gpu-rdc',
            '-Wall', '-Wno-unused-function', '-I', os.path.join(ROOT, 'include'), '-o', LIB] + sources()
+    for extra in os.environ.get('UDS_DEFINES', '').split():   # experiment switches, e.g. UDS_DEFINES='-DUDS_P3_PIPE'
+        cmd.insert(1, extra)
+    if os.environ.get('UDS_PHASE_TIMING'):      # diagnostic build: per-phase cycle stamps into the workspace
+        cmd.insert(1, '-DUDS_PHASE_TIMING')
     if verbose:
         cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -1,14 +1,19 @@
-// Fused spatial-layer kernel (gfx950): one workgroup = one tile of one side of the network,
-// looping over a chunk of snapshots.  Replaces, per side, the whole chain
+// Fused spatial-layer kernel (gfx950): one workgroup (8 waves, one per CU) = one tile of one side of the
+// network, looping over a chunk of snapshots.  Replaces, per side, the whole chain
 //   Dense(d/2,relu) on the secondary rows -> NodeEdge aggregation -> concat -> GAT linear ->
 //   attention logits / segmented softmax / neighbour sum -> bias -> activation
 // (emulator.py:225-230) with ONE pass over HBM: inputs are read, the only global writes are the
 // layer outputs; x_e / e_x / agg / hx / attention scalars live in LDS or registers.
 //
 // Per snapshot, per tile:
-//   P1  secondary MLP   sec[q]  = relu(in_sec[q] @ Wsmall + b)        rows gathered from HBM -> MFMA -> LDS
+//   P1  secondary MLP   sec[q]  = relu(in_sec[q] @ Wsmall + b)                      stage -> MFMA -> LDS
 //   P2  primary linear  hx[p]   = [in_prim[p] | sum_q w_pq sec[q]] @ Wbig ; s_self, s_nbr -> LDS
 //   P3  GAT aggregate   out[i]  = act(sum_j softmax_j(leaky(s_self_i+s_nbr_j)) hx[j] + bias)  LDS -> HBM
+//
+// HBM -> LDS: every input row of snapshot s+1 is fetched by LDS-DMA (global_load_lds_dwordx4, no VGPRs)
+// while snapshot s is being computed, into a staging image laid out in MFMA-fragment order: the lane that
+// issues a 16-B piece is the lane that later reads it back (ds_read_b128, conflict-free, no cross-wave
+// hand-off: the issuing wave's own counted vmcnt is the only synchronisation the stage needs).
 //
 // GEMMs: v_mfma_f32_16x16x32_bf16 with the WEIGHTS as the A operand and 16 data rows as the B operand
 // (result lane layout = 4 consecutive features of one row -> 16-B LDS / HBM accesses).  fp32 operands
@@ -16,11 +21,12 @@
 // error ~2^-16 relative per product: MORE mantissa than the TF32 path TensorFlow uses by default on
 // the reference's GPUs, cheaper than the 157 TF fp32 MFMA that would cap the layer below the HBM
 // roofline -- SURVEY.md section 7).  Weight fragments (32 + 96 VGPRs per lane at F=64) are loaded once
-// per workgroup and stay in registers across the snapshot loop; data fragments are loaded straight
-// from HBM in fragment shape (each row read once, 64 B per lane per k-step pair), never via LDS.
+// per workgroup and stay in registers across the snapshot loop.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "kernels_dense.hpp"
 #include "kernels_sparse.hpp"
@@ -33,6 +39,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int FUSED_H = 32;             // d/2
 constexpr int FUSED_D = 64;             // d
+constexpr int FUSED_WAVES = 8;          // 512 threads: one workgroup per CU owns the whole 160 KiB LDS
+constexpr int FUSED_U = 4;              // P3: row groups (of 4 rows) a wave keeps in flight (the trip code assumes 4)
 constexpr int SEC_STRIDE = FUSED_H + 4; // floats; 144-B rows make the 16-B fragment writes conflict-free
 
 struct FusedSide {
@@ -47,6 +55,7 @@ struct FusedArgs {
   FusedSide side[2];
   const int32_t *hdr, *pool;
   int n_tiles, S, chunk, p_cap, q_cap, meta_cap, act, side_mask;
+  unsigned long long *dbg;   // diagnostic builds only (UDS_PHASE_TIMING): 8 cycle sums per wave
 };
 
 // k index a lane's element jj (0..7) of k-step t stands for: two 16-B pieces per lane so that one
@@ -90,11 +99,80 @@ __device__ __forceinline__ f32x4 mfma3(const bf16x8 &wh, const bf16x8 &wl, const
   return acc;
 }
 
-template <int FP, int FS>
-__global__ __launch_bounds__(256, (FP + FS <= 128) ? 2 : 1) void k_fused_side(FusedArgs a) {
-  constexpr int KT_S = FS / 32, MB_S = FUSED_H / 16;          // small GEMM: FS -> 32
+// 16-lane all-reduce (max / sum) with DPP row operations: no LDS traffic, VALU latency only.
+template <int CTRL>
+__device__ __forceinline__ float row_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, row_dpp<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = fmaxf(v, row_dpp<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = fmaxf(v, row_dpp<0x124>(v));   // row_ror:4
+  v = fmaxf(v, row_dpp<0x128>(v));   // row_ror:8
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += row_dpp<0xB1>(v);
+  v += row_dpp<0x4E>(v);
+  v += row_dpp<0x124>(v);
+  v += row_dpp<0x128>(v);
+  return v;
+}
+
+// ACT: UDS_ACT_* known at compile time (relu / linear fast paths), or -1 = decide at run time from a.act.
+template <int ACT>
+__device__ __forceinline__ float fused_act(float v, int act_rt) {
+  if constexpr (ACT == UDS_ACT_RELU) return fmaxf(v, 0.0f);
+  else if constexpr (ACT == UDS_ACT_LINEAR) return v;
+  else return apply_act(v, act_rt);
+}
+
+// workgroup barrier that does NOT drain the vector-memory counter: LDS-DMA prefetches stay in flight across it
+// (a __syncthreads() would wait vmcnt(0) while an LDS-DMA is outstanding).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// wait until all but the n youngest vector-memory operations of this wave are done (n = the output stores it
+// issued last: CDNA4 counts stores in vmcnt too, and the DMA pieces are older than they are)
+__device__ __forceinline__ void wait_all_but(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+  }
+}
+
+// One 16-B-per-lane LDS-DMA piece (1 KiB per wave): global `src` (per lane) -> LDS `lds_byte` + lane * 16 (wave-
+// uniform base in M0).  Written as inline asm on purpose: hipcc orders every later LDS read behind a DMA it can see
+// (it inserted `s_waitcnt vmcnt(0)` in front of the first ds_read after each __builtin_amdgcn_global_load_lds, which
+// serialised the whole prefetch); an asm DMA is invisible to that bookkeeping, so completion is tracked by hand with
+// wait_all_but() -- the loop below issues no compiler-visible vector-memory LOADS, only stores.  M0 is saved and
+// restored inside the statement (the compiler owns it).
+__device__ __forceinline__ void glds16(const float *src, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(src), "s"(lds_byte)
+               : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+
+template <int FP, int FS, int ACT>
+__global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a) {
+  constexpr int NW = FUSED_WAVES, NT = FUSED_WAVES * 64;
+  constexpr int KT_S = FS / 32, MB_S = FUSED_H / 16;                    // small GEMM: FS -> 32
   constexpr int KT_X = FP / 32, KT_B = KT_X + 1, MB_B = FUSED_D / 16;   // big GEMM: FP + 32 -> 64
+  constexpr int U = FUSED_U;
   extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+#ifdef UDS_PHASE_TIMING
+  unsigned long long tm_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tl_ = clock64();
+#define UDS_STAMP(k) do { const unsigned long long n_ = clock64(); tm_[k] += n_ - tl_; tl_ = n_; } while (0)
+#else
+#define UDS_STAMP(k) do { } while (0)
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,10 +192,21 @@ __global__ __launch_bounds__(256, (FP + FS <= 128) ? 2 : 1) void k_fused_side(Fu
   int32_t *meta = smem;
   float *s_self = reinterpret_cast<float *>(smem + a.meta_cap);
   float *s_nbr = s_self + a.p_cap;
-  float *sec = s_nbr + a.p_cap;
+  float *attn = s_nbr + a.p_cap;                 // a_self[64] | a_nbr[64]
+  float *scratch = attn + 2 * FUSED_D + FUSED_H; // P3: per wave U x 64 (weight, neighbour) pairs = 2 KiB
+  float *sec = scratch + NW * U * 64 * 2;
   float *hx = sec + a.q_cap * SEC_STRIDE;
+  float *stage_s = hx + a.p_cap * FUSED_D;       // (q_cap/16) blocks x KT_S x 2 pieces x 1 KiB, fragment order
+  float *stage_p = stage_s + a.q_cap * FS;       // (p_cap/16) blocks x KT_X x 2 pieces x 1 KiB
 
-  for (int i = tid; i < meta_len; i += 256) meta[i] = a.pool[pool_off + i];
+  for (int i = tid; i < meta_len; i += NT) meta[i] = a.pool[pool_off + i];
+  // weights: one copy global -> LDS (the stage is still free), then every lane picks its fragments
+  {
+    constexpr int NS = KT_S * MB_S * 2 * 64, NB = KT_B * MB_B * 2 * 64;
+    uint4 *wst = reinterpret_cast<uint4 *>(stage_s);
+    for (int i = tid; i < NS; i += NT) wst[i] = S_.w_small[i];
+    for (int i = tid; i < NB; i += NT) wst[NS + i] = S_.w_big[i];
+  }
   __syncthreads();
   const int32_t *prim_ids = meta;
   const int32_t *sec_ids = prim_ids + n_prim;
@@ -126,58 +215,102 @@ __global__ __launch_bounds__(256, (FP + FS <= 128) ? 2 : 1) void k_fused_side(Fu
   int32_t *inc_w = const_cast<int32_t *>(inc_loc) + n_inc;
   const int32_t *adj_ptr = inc_w + n_inc;
   const int32_t *adj_loc = adj_ptr + n_own + 1;
-  for (int i = tid; i < n_inc; i += 256) reinterpret_cast<float *>(inc_w)[i] = S_.ne_val[inc_w[i]];
+  for (int i = tid; i < n_inc; i += NT) reinterpret_cast<float *>(inc_w)[i] = S_.ne_val[inc_w[i]];
   const float *inc_val = reinterpret_cast<const float *>(inc_w);
 
-  // weights -> registers, once per workgroup
   bf16x8 wsh[KT_S][MB_S], wsl[KT_S][MB_S], wbh[KT_B][MB_B], wbl[KT_B][MB_B];
+  {
+    const uint4 *wst = reinterpret_cast<const uint4 *>(stage_s);
+    constexpr int NS = KT_S * MB_S * 2 * 64;
 #pragma unroll
-  for (int t = 0; t < KT_S; ++t)
+    for (int t = 0; t < KT_S; ++t)
 #pragma unroll
-    for (int m = 0; m < MB_S; ++m) {
-      wsh[t][m] = __builtin_bit_cast(bf16x8, S_.w_small[((t * MB_S + m) * 2 + 0) * 64 + lane]);
-      wsl[t][m] = __builtin_bit_cast(bf16x8, S_.w_small[((t * MB_S + m) * 2 + 1) * 64 + lane]);
-    }
+      for (int m = 0; m < MB_S; ++m) {
+        wsh[t][m] = __builtin_bit_cast(bf16x8, wst[((t * MB_S + m) * 2 + 0) * 64 + lane]);
+        wsl[t][m] = __builtin_bit_cast(bf16x8, wst[((t * MB_S + m) * 2 + 1) * 64 + lane]);
+      }
 #pragma unroll
-  for (int t = 0; t < KT_B; ++t)
+    for (int t = 0; t < KT_B; ++t)
 #pragma unroll
-    for (int m = 0; m < MB_B; ++m) {
-      wbh[t][m] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + m) * 2 + 0) * 64 + lane]);
-      wbl[t][m] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + m) * 2 + 1) * 64 + lane]);
-    }
-  f32x4 bs[MB_S], as4[MB_B], an4[MB_B];
-#pragma unroll
-  for (int m = 0; m < MB_S; ++m) {
-    bs[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (S_.b_small) bs[m] = *reinterpret_cast<const f32x4 *>(S_.b_small + 16 * m + 4 * qd);
+      for (int m = 0; m < MB_B; ++m) {
+        wbh[t][m] = __builtin_bit_cast(bf16x8, wst[NS + ((t * MB_B + m) * 2 + 0) * 64 + lane]);
+        wbl[t][m] = __builtin_bit_cast(bf16x8, wst[NS + ((t * MB_B + m) * 2 + 1) * 64 + lane]);
+      }
   }
-#pragma unroll
-  for (int m = 0; m < MB_B; ++m) {
-    as4[m] = *reinterpret_cast<const f32x4 *>(S_.a_self + 16 * m + 4 * qd);
-    an4[m] = *reinterpret_cast<const f32x4 *>(S_.a_nbr + 16 * m + 4 * qd);
+  if (tid < FUSED_D) {   // attention vectors and the small GEMM's bias live in LDS (read once per 16-row block)
+    attn[tid] = S_.a_self[tid];
+    attn[FUSED_D + tid] = S_.a_nbr[tid];
+    if (tid < FUSED_H) attn[2 * FUSED_D + tid] = S_.b_small ? S_.b_small[tid] : 0.f;
   }
-  const int c16 = lane & 15, rs = lane >> 4;     // P3 mapping: 16 lanes x float4 per output row, 4 rows per wave
+  const int c16 = lane & 15, rs = lane >> 4;     // P3 mapping: 16 lanes x float4 per output row, 4 rows per group
   f32x4 bo = f32x4{0.f, 0.f, 0.f, 0.f};
   if (S_.b_out) bo = *reinterpret_cast<const f32x4 *>(S_.b_out + 4 * c16);
-  __syncthreads();
+  __syncthreads();   // weights are in registers: the stage may now be overwritten by the DMA
 
-  const int s_end = min(a.S, (chunk_id + 1) * a.chunk);
-  for (int s = chunk_id * a.chunk; s < s_end; ++s) {
+  // LDS-DMA of one 16-row block in fragment order: piece (t, i) of lane (r16, qd) = floats 32t + 16i + 4qd .. +3
+  // of row r16 of the block.  The destination is wave-uniform (base + lane * 16 B is implicit).  Row offsets do not
+  // change from snapshot to snapshot, so a wave keeps those of its first two P1 blocks and first P2 block in registers.
+  auto sec_off = [&](int blk) { return sec_ids[min(blk * 16 + r16, n_sec - 1)] * FS + 4 * qd; };       // < 2^31 floats
+  auto prim_off = [&](int blk) { return prim_ids[min(blk * 16 + r16, n_prim - 1)] * FP + 4 * qd; };
+  const int soff0 = wave * 16 < n_sec ? sec_off(wave) : 0, soff1 = (wave + NW) * 16 < n_sec ? sec_off(wave + NW) : 0;
+  const int poff0 = wave * 16 < n_prim ? prim_off(wave) : 0;
+  auto dma_sec = [&](int blk, int s) {
+    const int off = blk == wave ? soff0 : (blk == wave + NW ? soff1 : sec_off(blk));
+    const float *src = S_.sec_in + (int64_t)s * S_.n_sec_glob * FS + off;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(stage_s) + (unsigned)blk * (KT_S * 2 * 1024));
+#pragma unroll
+    for (int t = 0; t < KT_S; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) glds16(src + 32 * t + 16 * i, dst + (t * 2 + i) * 1024);
+  };
+  auto dma_prim = [&](int blk, int s) {
+    const int off = blk == wave ? poff0 : prim_off(blk);
+    const float *src = S_.prim_in + (int64_t)s * S_.n_prim_glob * FP + off;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(stage_p) + (unsigned)blk * (KT_X * 2 * 1024));
+#pragma unroll
+    for (int t = 0; t < KT_X; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) glds16(src + 32 * t + 16 * i, dst + (t * 2 + i) * 1024);
+  };
+
+  // P3 (the planner keeps n_own <= 4*NW*U, so one trip covers the tile: row = wave*4 + 4*NW*u + rs): the (wave-
+  // uniform) largest degree of each of this wave's row groups never changes, keep it in SGPRs
+  int p3_dmax[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int i = wave * 4 + 4 * NW * u + rs;
+    const int ic = min(i, n_own - 1);
+    int dmx = i < n_own ? adj_ptr[ic + 1] - adj_ptr[ic] : 0;
+    dmx = max(dmx, __shfl_xor(dmx, 16));
+    dmx = max(dmx, __shfl_xor(dmx, 32));
+    p3_dmax[u] = __builtin_amdgcn_readfirstlane(dmx);
+  }
+
+  const int s_begin = chunk_id * a.chunk, s_end = min(a.S, (chunk_id + 1) * a.chunk);
+  if (s_begin < s_end) {
+    for (int blk = wave; blk * 16 < n_sec; blk += NW) dma_sec(blk, s_begin);
+    for (int blk = wave; blk * 16 < n_prim; blk += NW) dma_prim(blk, s_begin);
+  }
+  int n_st = 0;   // output-store instructions this wave issued in the previous P3 (still in flight, younger than the DMA)
+  UDS_STAMP(0);   // setup: metadata, weights, first DMA issue
+
+  for (int s = s_begin; s < s_end; ++s) {
+    wait_all_but(n_st);    // this wave's stage slots for snapshot s have landed
+    UDS_STAMP(1);
     // ---------------- P1: secondary MLP -> LDS ----------------
-    for (int blk = wave; blk * 16 < n_sec; blk += 4) {
-      const int lrow = blk * 16 + r16;
-      const int id = sec_ids[min(lrow, n_sec - 1)];
-      const float *src = S_.sec_in + ((int64_t)s * S_.n_sec_glob + id) * FS + 4 * qd;
+    for (int blk = wave; blk * 16 < n_sec; blk += NW) {
+      const float4 *st = reinterpret_cast<const float4 *>(stage_s + blk * (KT_S * 2 * 256)) + lane;
       bf16x8 dh[KT_S], dl[KT_S];
 #pragma unroll
-      for (int t = 0; t < KT_S; ++t) {
-        const float4 v0 = *reinterpret_cast<const float4 *>(src + 32 * t);
-        const float4 v1 = *reinterpret_cast<const float4 *>(src + 32 * t + 16);
-        split8(v0, v1, dh[t], dl[t]);
+      for (int t = 0; t < KT_S; ++t) split8(st[(2 * t) * 64], st[(2 * t + 1) * 64], dh[t], dl[t]);
+      if (s + 1 < s_end) {   // slot consumed (values are in VGPRs): refill it with the next snapshot's rows
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dma_sec(blk, s + 1);
       }
+      const int lrow = blk * 16 + r16;
       f32x4 acc[MB_S];
 #pragma unroll
-      for (int m = 0; m < MB_S; ++m) acc[m] = bs[m];
+      for (int m = 0; m < MB_S; ++m) acc[m] = *reinterpret_cast<const f32x4 *>(attn + 2 * FUSED_D + 16 * m + 4 * qd);
 #pragma unroll
       for (int t = 0; t < KT_S; ++t)
 #pragma unroll
@@ -187,34 +320,50 @@ __global__ __launch_bounds__(256, (FP + FS <= 128) ? 2 : 1) void k_fused_side(Fu
         for (int m = 0; m < MB_S; ++m) {
           f32x4 o;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = apply_act(acc[m][j], a.act);
+          for (int j = 0; j < 4; ++j) o[j] = fused_act<ACT>(acc[m][j], a.act);
           *reinterpret_cast<f32x4 *>(sec + lrow * SEC_STRIDE + 16 * m + 4 * qd) = o;
         }
       }
     }
-    __syncthreads();
+    // index lists do not depend on the data: fetch the head of this wave's first P2 incidence list now, so the
+    // reads are back by the time the barrier releases (loads on clamped indices, no branches)
+    const int lr0 = min(wave * 16 + r16, n_prim - 1);
+    const int ag_beg = inc_ptr[lr0], ag_end = inc_ptr[lr0 + 1];
+    const int ag_i0 = min(ag_beg, n_inc - 1), ag_i1 = min(ag_beg + 1, n_inc - 1);
+    const int ag_l0r = inc_loc[ag_i0], ag_l1r = inc_loc[ag_i1];
+    const float ag_w0r = inc_val[ag_i0], ag_w1r = inc_val[ag_i1];
+    UDS_STAMP(2);
+    lds_barrier();
+    UDS_STAMP(3);
+    const int ag_l0 = ag_beg < ag_end ? ag_l0r : 0, ag_l1 = ag_beg + 1 < ag_end ? ag_l1r : 0;
+    const float ag_w0 = ag_beg < ag_end ? ag_w0r : 0.f, ag_w1 = ag_beg + 1 < ag_end ? ag_w1r : 0.f;
     // ---------------- P2: [prim | agg] @ Wbig -> hx, attention scalars -> LDS ----------------
-    for (int blk = wave; blk * 16 < n_prim; blk += 4) {
+    for (int blk = wave; blk * 16 < n_prim; blk += NW) {
+      const float4 *st = reinterpret_cast<const float4 *>(stage_p + blk * (KT_X * 2 * 256)) + lane;
+      bf16x8 dh[KT_B], dl[KT_B];
+#pragma unroll
+      for (int t = 0; t < KT_X; ++t) split8(st[(2 * t) * 64], st[(2 * t + 1) * 64], dh[t], dl[t]);
+      if (s + 1 < s_end) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dma_prim(blk, s + 1);
+      }
       const int lrow = blk * 16 + r16;
       const bool valid = lrow < n_prim;
       const int lr = min(lrow, n_prim - 1);
-      const int id = prim_ids[lr];
-      const float *src = S_.prim_in + ((int64_t)s * S_.n_prim_glob + id) * FP + 4 * qd;
-      bf16x8 dh[KT_B], dl[KT_B];
-#pragma unroll
-      for (int t = 0; t < KT_X; ++t) {
-        const float4 v0 = *reinterpret_cast<const float4 *>(src + 32 * t);
-        const float4 v1 = *reinterpret_cast<const float4 *>(src + 32 * t + 16);
-        split8(v0, v1, dh[t], dl[t]);
-      }
       float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;   // this lane's 8 aggregate features (fragment shape)
-      for (int p = inc_ptr[lr]; p < inc_ptr[lr + 1]; ++p) {
-        const float wv = inc_val[p];
-        const float *row = sec + inc_loc[p] * SEC_STRIDE + 4 * qd;
+      auto add_row = [&](int loc, float wv) {
+        const float *row = sec + loc * SEC_STRIDE + 4 * qd;
         const float4 u0 = *reinterpret_cast<const float4 *>(row);
         const float4 u1 = *reinterpret_cast<const float4 *>(row + 16);
         g0.x = fmaf(wv, u0.x, g0.x); g0.y = fmaf(wv, u0.y, g0.y); g0.z = fmaf(wv, u0.z, g0.z); g0.w = fmaf(wv, u0.w, g0.w);
         g1.x = fmaf(wv, u1.x, g1.x); g1.y = fmaf(wv, u1.y, g1.y); g1.z = fmaf(wv, u1.z, g1.z); g1.w = fmaf(wv, u1.w, g1.w);
+      };
+      if (blk == wave) {   // list head is in registers: both rows are fetched together (weight 0 / row 0 pad short lists)
+        add_row(ag_l0, ag_w0);
+        add_row(ag_l1, ag_w1);
+        for (int p = ag_beg + 2; p < ag_end; ++p) add_row(inc_loc[p], inc_val[p]);
+      } else {
+        for (int p = inc_ptr[lr]; p < inc_ptr[lr + 1]; ++p) add_row(inc_loc[p], inc_val[p]);
       }
       split8(g0, g1, dh[KT_X], dl[KT_X]);
       f32x4 acc[MB_B];
@@ -226,12 +375,15 @@ __global__ __launch_bounds__(256, (FP + FS <= 128) ? 2 : 1) void k_fused_side(Fu
         for (int m = 0; m < MB_B; ++m) acc[m] = mfma3(wbh[t][m], wbl[t][m], dh[t], dl[t], acc[m]);
       float ps = 0.f, pn = 0.f;
 #pragma unroll
-      for (int m = 0; m < MB_B; ++m)
+      for (int m = 0; m < MB_B; ++m) {
+        const f32x4 as4 = *reinterpret_cast<const f32x4 *>(attn + 16 * m + 4 * qd);
+        const f32x4 an4 = *reinterpret_cast<const f32x4 *>(attn + FUSED_D + 16 * m + 4 * qd);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          ps = fmaf(acc[m][j], as4[m][j], ps);
-          pn = fmaf(acc[m][j], an4[m][j], pn);
+          ps = fmaf(acc[m][j], as4[j], ps);
+          pn = fmaf(acc[m][j], an4[j], pn);
         }
+      }
       ps += __shfl_xor(ps, 16); pn += __shfl_xor(pn, 16);
       ps += __shfl_xor(ps, 32); pn += __shfl_xor(pn, 32);
       if (valid) {
@@ -244,35 +396,149 @@ __global__ __launch_bounds__(256, (FP + FS <= 128) ? 2 : 1) void k_fused_side(Fu
           *reinterpret_cast<f32x4 *>(hx + lrow * FUSED_D + (((4 * m + qd) ^ (lrow & 7)) << 2)) = acc[m];
       }
     }
-    __syncthreads();
+    int p3_deg[U], p3_jn[U], p3_row[U];   // P3 index lists, fetched ahead of the barrier like the P2 ones
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = wave * 4 + 4 * NW * u + rs;
+      const int ic = min(i, n_own - 1);
+      const int b0 = adj_ptr[ic];
+      p3_deg[u] = i < n_own ? adj_ptr[ic + 1] - b0 : 0;
+      p3_jn[u] = adj_loc[b0 + min(c16, max(p3_deg[u] - 1, 0))];
+      p3_row[u] = prim_ids[ic];
+    }
+    UDS_STAMP(4);
+    lds_barrier();
+    UDS_STAMP(5);
     // ---------------- P3: segmented softmax + neighbour sum -> HBM ----------------
-    for (int i0 = wave * 4; i0 < n_own; i0 += 16) {
-      const int i = i0 + rs;
-      if (i < n_own) {
-        const float ss = s_self[i];
-        const int beg = adj_ptr[i], end = adj_ptr[i + 1];
-        float mx = -INFINITY;
-        for (int p = beg; p < end; ++p) mx = fmaxf(mx, leaky02(ss + s_nbr[adj_loc[p]]));
-        float den = 0.f;
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int p = beg; p < end; ++p) {
-          const int j = adj_loc[p];
-          const float wgt = expf(leaky02(ss + s_nbr[j]) - mx);
-          const f32x4 hv = *reinterpret_cast<const f32x4 *>(hx + j * FUSED_D + ((c16 ^ (j & 7)) << 2));
-          den += wgt;
+    // 16 lanes per output row, U row groups (4*U rows) per wave in flight at once so the dependent LDS reads of
+    // one group hide behind the others.  Lane c scores neighbour c (one exp per neighbour, not per lane); the row
+    // max / sum are DPP all-reduces inside the 16-lane group; weights and neighbour indices are then broadcast
+    // lane by lane while every lane accumulates its own float4 feature chunk.
+    n_st = 0;
+    // rows are degree-sorted inside the tile; 4-row groups are dealt round-robin to the waves (group g -> wave g % NW),
+    // so every wave gets the same mix of degrees and its groups come in descending degree
+    {   // the planner keeps n_own <= 4*NW*U (= p_limit 128), so one trip covers the tile: row = wave*4 + 4*NW*u + rs
+      constexpr int i0 = 0;
+      int deg[U], jn[U], dmax[U], orow[U];
+      float ss[U], lg[U], wgt[U], den[U];
+      bool ok[U];
+      int dm = 0;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) acc[k] = fmaf(wgt, hv[k], acc[k]);
+      for (int u = 0; u < U; ++u) {   // unconditional loads on clamped indices: the four groups' reads overlap
+        const int i = wave * 4 + 4 * NW * u + rs;
+        const int ic = min(i, n_own - 1);
+        ok[u] = i < n_own;
+        deg[u] = p3_deg[u]; jn[u] = c16 < p3_deg[u] ? p3_jn[u] : 0; dmax[u] = p3_dmax[u];
+        ss[u] = s_self[ic];
+        orow[u] = p3_row[u] * FUSED_D + 4 * c16;
+        dm = max(dm, dmax[u]);
+      }
+      f32x4 acc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (dm <= 16) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float sc = leaky02(ss[u] + s_nbr[jn[u]]);
+          lg[u] = c16 < deg[u] ? sc : -INFINITY;
         }
-        const float inv = 1.0f / den;
-        f32x4 o;
+        UDS_STAMP(8);
+        float2 *scr = reinterpret_cast<float2 *>(scratch) + wave * (U * 64);   // (weight, neighbour) per (u, lane)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = apply_act(fmaf(acc[k], inv, bo[k]), a.act);
-        *reinterpret_cast<f32x4 *>(S_.out + ((int64_t)s * S_.n_prim_glob + prim_ids[i]) * FUSED_D + 4 * c16) = o;
+        for (int u = 0; u < U; ++u) {
+          const float mx = row16_max(lg[u]);
+          const float ex = __builtin_amdgcn_exp2f((lg[u] - mx) * 1.44269504088896340736f);
+          wgt[u] = c16 < deg[u] ? ex : 0.f;     // rows past the tile have degree 0: every weight 0, the NaN of -inf - -inf dropped
+          den[u] = row16_sum(wgt[u]);
+          // neighbour stored as the byte offset of its hx row with the swizzle key in the low bits: j*256 + (j&7)*16
+          scr[u * 64 + lane] = make_float2(wgt[u], __int_as_float(jn[u] * (FUSED_D * 4) + ((jn[u] & 7) << 4)));
+        }
+        // Two neighbours per trip and row group: one 16-B broadcast read fetches (w_k, j_k, w_k+1, j_k+1) for the 16
+        // lanes of a group, two row reads follow.  Groups whose longest list is exhausted are skipped (wave-uniform).
+        // Slots beyond a row's degree hold weight 0 and row 0.
+        const float4 *pair = reinterpret_cast<const float4 *>(scr) + (lane >> 4) * 8;
+        const char *hxb = reinterpret_cast<const char *>(hx);
+        const int cx = c16 << 4;
+        // Straight-line trips over the first A groups (no branches inside a trip, so all its LDS reads are in flight
+        // together); A shrinks as the shorter groups run out: e[u] = longest list among groups u..U-1.
+        auto trip = [&](auto A_, int k) {
+          constexpr int A = decltype(A_)::value;
+#pragma unroll
+          for (int u0 = 0; u0 < A; u0 += 2) {       // two groups at a time: 2 pair reads, then 4 row reads in flight
+            constexpr int Z = 0;
+            const int n = (A - u0) < 2 ? (A - u0) : 2;
+            float4 wj[2];
+            f32x4 h0[2], h1[2];
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+              if (v < n) wj[v] = pair[(u0 + v) * 32 + (k >> 1)];
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+              if (v < n) {
+                const int j0 = __float_as_int(wj[v].y), j1 = __float_as_int(wj[v].w);
+                h0[v] = *reinterpret_cast<const f32x4 *>(hxb + ((cx ^ (j0 & 0x70)) + (j0 & ~0xff)));
+                h1[v] = *reinterpret_cast<const f32x4 *>(hxb + ((cx ^ (j1 & 0x70)) + (j1 & ~0xff)));
+              }
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+              if (v < n) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                  acc[u0 + v][q] = fmaf(wj[v].z, h1[v][q], fmaf(wj[v].x, h0[v][q], acc[u0 + v][q]));
+              }
+            (void)Z;
+          }
+        };
+        const int e3 = dmax[3], e2 = max(e3, dmax[2]), e1 = max(e2, dmax[1]), e0 = max(e1, dmax[0]);
+        int k = 0;
+        for (; k < e3; k += 2) trip(std::integral_constant<int, 4>{}, k);
+        for (; k < e2; k += 2) trip(std::integral_constant<int, 3>{}, k);
+        for (; k < e1; k += 2) trip(std::integral_constant<int, 2>{}, k);
+        for (; k < e0; k += 2) trip(std::integral_constant<int, 1>{}, k);
+        UDS_STAMP(9);
+      } else {   // some row has more than 16 neighbours: every lane walks its row's whole list
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = i0 + wave * 4 + 4 * NW * u + rs;
+          const int b0 = i < n_own ? adj_ptr[i] : 0;
+          float mx = -INFINITY;
+          for (int p = b0; p < b0 + deg[u]; ++p) mx = fmaxf(mx, leaky02(ss[u] + s_nbr[adj_loc[p]]));
+          den[u] = 0.f;
+          for (int p = b0; p < b0 + deg[u]; ++p) {
+            const int jj = adj_loc[p];
+            const float wv = __builtin_amdgcn_exp2f((leaky02(ss[u] + s_nbr[jj]) - mx) * 1.44269504088896340736f);
+            const f32x4 hv = *reinterpret_cast<const f32x4 *>(hx + jj * FUSED_D + ((c16 ^ (jj & 7)) << 2));
+            den[u] += wv;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[u][q] = fmaf(wv, hv[q], acc[u][q]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (dmax[u] > 0) ++n_st;       // wave-uniform: one store instruction per row group that has a valid row
+        if (ok[u]) {
+          const float inv = __builtin_amdgcn_rcpf(den[u]);
+          f32x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = fused_act<ACT>(fmaf(acc[u][q], inv, bo[q]), a.act);
+          *reinterpret_cast<f32x4 *>(S_.out + ((int64_t)s * S_.n_prim_glob * FUSED_D + orow[u])) = o;
+        }
       }
     }
+    UDS_STAMP(6);
     // no barrier needed here: the next snapshot's P1 only writes `sec`, whose readers (P2) all passed the barrier
     // above; its P2 writes hx / s_* only after the next P1->P2 barrier, which every wave reaches after its own P3.
   }
+#ifdef UDS_PHASE_TIMING
+  if (a.dbg && lane == 0) {
+    unsigned long long *o = a.dbg + ((size_t)blockIdx.x * NW + wave) * 12;
+    for (int k = 0; k < 7; ++k) o[k] = tm_[k];
+    o[8] = tm_[8]; o[9] = tm_[9]; o[10] = wave;
+    o[7] = 1ull | ((unsigned long long)sd << 8) | ((unsigned long long)n_own << 16) | ((unsigned long long)n_prim << 32) |
+           ((unsigned long long)n_sec << 48);
+  }
+#endif
 }
 
 }  // namespace uds

@@ -106,8 +106,37 @@ inline void cluster_rows(const HostCsr &adj, int t_max, std::vector<int32_t> &cl
 // node_bfs: BFS index of every NODE (for the locality key).  For the node side key_cols == nullptr
 // (keys come from the primary rows themselves); for the link side the key of a link is the smaller
 // node_bfs of its endpoints (the cols of its INC row).
+// Rows a tile of `own` rows would stage: primary (own + outside ADJ-neighbours) and secondary (INC-incident) counts.
+inline void tile_footprint(const HostCsr &adj, const HostCsr &inc, const std::vector<int32_t> &own, std::vector<int32_t> &mark_p,
+                           std::vector<int32_t> &mark_s, int &n_prim, int &n_sec) {
+  std::vector<int32_t> prim, sec;
+  for (int32_t r : own)
+    for (int32_t p = adj.rowptr[r]; p < adj.rowptr[r + 1]; ++p)
+      if (!mark_p[adj.col[p]]) {
+        mark_p[adj.col[p]] = 1;
+        prim.push_back(adj.col[p]);
+      }
+  for (int32_t r : own)
+    if (!mark_p[r]) {   // a row always counts itself (patterns normally hold the self loop already)
+      mark_p[r] = 1;
+      prim.push_back(r);
+    }
+  for (int32_t r : prim)
+    for (int32_t p = inc.rowptr[r]; p < inc.rowptr[r + 1]; ++p)
+      if (!mark_s[inc.col[p]]) {
+        mark_s[inc.col[p]] = 1;
+        sec.push_back(inc.col[p]);
+      }
+  n_prim = (int)prim.size();
+  n_sec = (int)sec.size();
+  for (int32_t r : prim) mark_p[r] = 0;
+  for (int32_t q : sec) mark_s[q] = 0;
+}
+
+// p_limit / q_limit (0 = none): a cluster whose primary or secondary footprint exceeds them is bisected in BFS
+// order until it fits, so one outlier cluster does not set the LDS size of every workgroup.
 inline SidePlan build_side_plan(const HostCsr &adj, const HostCsr &inc, int t_max, int side,
-                                const std::vector<int32_t> *node_bfs) {
+                                const std::vector<int32_t> *node_bfs, int p_limit = 0, int q_limit = 0) {
   SidePlan plan;
   std::vector<int32_t> cluster_of;
   int n_clusters = 0;
@@ -115,6 +144,35 @@ inline SidePlan build_side_plan(const HostCsr &adj, const HostCsr &inc, int t_ma
   const int32_t n = (int32_t)adj.n_rows;
   std::vector<std::vector<int32_t>> members(n_clusters);
   for (int32_t r = 0; r < n; ++r) members[cluster_of[r]].push_back(r);   // ascending ids
+  if (p_limit > 0 || q_limit > 0) {
+    std::vector<int32_t> mark_p(n, 0), mark_s((size_t)inc.n_cols, 0);
+    std::vector<std::vector<int32_t>> fitted;
+    std::vector<std::vector<int32_t>> work(members.rbegin(), members.rend());
+    while (!work.empty()) {
+      std::vector<int32_t> c = std::move(work.back());
+      work.pop_back();
+      int np_ = 0, nq_ = 0;
+      tile_footprint(adj, inc, c, mark_p, mark_s, np_, nq_);
+      const bool too_big = (p_limit > 0 && np_ > p_limit) || (q_limit > 0 && nq_ > q_limit);
+      if (!too_big || c.size() <= 1) {
+        fitted.push_back(std::move(c));
+        continue;
+      }
+      std::stable_sort(c.begin(), c.end(), [&](int32_t x, int32_t y) { return plan.bfs_index[x] < plan.bfs_index[y]; });
+      const size_t half = c.size() / 2;
+      work.emplace_back(c.begin() + half, c.end());
+      work.emplace_back(c.begin(), c.begin() + half);
+    }
+    members.swap(fitted);
+    n_clusters = (int)members.size();
+    for (auto &m : members) std::sort(m.begin(), m.end());
+  }
+  // degree-sorted schedule inside a tile: descending degree, ties by id (stable), so the 16 rows one wave aggregates
+  // together have near-equal neighbour counts
+  for (auto &m : members)
+    std::stable_sort(m.begin(), m.end(), [&](int32_t x, int32_t y) {
+      return (adj.rowptr[x + 1] - adj.rowptr[x]) > (adj.rowptr[y + 1] - adj.rowptr[y]);
+    });
   std::vector<int32_t> ploc(n, -1), sloc((size_t)inc.n_cols, -1);
   plan.n_tiles = n_clusters;
   plan.hdr.reserve((size_t)n_clusters * TILE_HDR_INTS);
@@ -190,9 +248,14 @@ inline SidePlan build_side_plan(const HostCsr &adj, const HostCsr &inc, int t_ma
   return plan;
 }
 
-// LDS bytes the fused kernel needs for a plan: meta + s_self/s_nbr + sec rows (36-float stride) + hx rows.
-inline int64_t fused_lds_bytes(int p_cap, int q_cap, int meta_cap, int h, int d) {
-  return 4 * ((int64_t)meta_cap + 2 * p_cap + (int64_t)q_cap * (h + 4) + (int64_t)p_cap * d);
+// LDS bytes the fused kernel needs for a plan: meta + s_self/s_nbr + attention vectors + sec rows (h+4 stride) +
+// hx rows + the DMA stage (raw secondary rows of width fs and raw primary rows of width fp of the NEXT snapshot,
+// at least as large as the packed weights that pass through it once at workgroup start).
+inline int64_t fused_lds_bytes(int p_cap, int q_cap, int meta_cap, int h, int d, int fp, int fs) {
+  const int64_t weights = 16 * 64 * 2 * ((int64_t)(fs / 32) * (h / 16) + (int64_t)((fp + h) / 32) * (d / 16));
+  const int64_t stage = std::max<int64_t>(4 * ((int64_t)q_cap * fs + (int64_t)p_cap * fp), weights);
+  const int64_t scratch = 8 * 4 * 64 * 2;   // P3: 8 waves x 4 row groups x 64 (weight, neighbour) pairs (floats)
+  return 4 * ((int64_t)meta_cap + 2 * p_cap + 2 * d + h + scratch + (int64_t)q_cap * (h + 4) + (int64_t)p_cap * d) + stage;
 }
 
 // Both sides of a network merged into one tile list ordered by locality key, so that the node tile and
@@ -205,12 +268,12 @@ struct NetworkPlan {
 };
 
 inline NetworkPlan build_network_plan(const HostCsr &adj, const HostCsr &eadj, const HostCsr &inc_n, const HostCsr &inc_e,
-                                      int t_node, int t_link) {
+                                      int t_node, int t_link, int p_limit = 0, int q_limit = 0) {
   NetworkPlan np;
   np.t_max[0] = t_node;
   np.t_max[1] = t_link;
-  np.side[0] = build_side_plan(adj, inc_n, t_node, 0, nullptr);
-  np.side[1] = build_side_plan(eadj, inc_e, t_link, 1, &np.side[0].bfs_index);
+  np.side[0] = build_side_plan(adj, inc_n, t_node, 0, nullptr, p_limit, q_limit);
+  np.side[1] = build_side_plan(eadj, inc_e, t_link, 1, &np.side[0].bfs_index, p_limit, q_limit);
   struct Ref { int32_t key, side, idx; };
   std::vector<Ref> refs;
   for (int s = 0; s < 2; ++s)

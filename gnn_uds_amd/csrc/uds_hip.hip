@@ -59,30 +59,39 @@ struct uds_tile_plan {
   uds::NetworkPlan plan;
 };
 
-struct uds_network {
-  const uds_csr *adj = nullptr, *edge_adj = nullptr, *inc_n = nullptr, *inc_e = nullptr;
-  bool fused_ok = false;          // a tile plan that fits the LDS budget exists
+// One tile plan per input width class: the DMA stage holds raw rows, so wider rows need smaller tiles.
+struct uds_plan_slot {
+  bool ok = false;                // a tile plan that fits the LDS budget exists
+  int f_max = 0;                  // widest input row (floats) the plan was sized for
   uds::NetworkPlan plan;
   int32_t *d_hdr = nullptr, *d_pool = nullptr;
   int64_t lds_bytes = 0;
 };
 
+struct uds_network {
+  const uds_csr *adj = nullptr, *edge_adj = nullptr, *inc_n = nullptr, *inc_e = nullptr;
+  uds_plan_slot slot[2];          // [0]: rows of 64 floats, [1]: rows of 96 floats
+};
+
 namespace {
 
-constexpr int64_t FUSED_LDS_BUDGET = 78 * 1024;   // two workgroups per CU (160 KiB LDS)
+constexpr int64_t FUSED_LDS_BUDGET = 160 * 1024;   // one 8-wave workgroup per CU owns the whole 160 KiB LDS
 constexpr int64_t PACKED_WEIGHT_FLOATS = 2 * (768 + 2048) * 4;   // both sides, F_in up to 96: uint4 = 4 floats
 
-// Largest tile sizes whose plan fits the LDS budget (h = 32, d = 64 kernel).
+// Tile plan for input rows of f_max floats under the LDS budget: fix the footprint limits (primary / secondary rows
+// staged per tile, multiples of 16) first, then cluster with a row target that typically fills them; clusters that
+// overshoot are bisected by the planner.
 bool plan_network(const uds::HostCsr &adj, const uds::HostCsr &eadj, const uds::HostCsr &inc_n, const uds::HostCsr &inc_e,
-                  int t_node, int t_link, uds::NetworkPlan &out, int64_t &lds) {
-  for (int attempt = 0; attempt < 12 && t_node >= 8 && t_link >= 8; ++attempt) {
-    out = uds::build_network_plan(adj, eadj, inc_n, inc_e, t_node, t_link);
-    const int64_t ln = uds::fused_lds_bytes(out.side[0].p_cap, out.side[0].q_cap, out.side[0].meta_cap, uds::FUSED_H, uds::FUSED_D);
-    const int64_t ll = uds::fused_lds_bytes(out.side[1].p_cap, out.side[1].q_cap, out.side[1].meta_cap, uds::FUSED_H, uds::FUSED_D);
-    lds = uds::fused_lds_bytes(out.p_cap, out.q_cap, out.meta_cap, uds::FUSED_H, uds::FUSED_D);
-    if (lds <= FUSED_LDS_BUDGET) return true;
-    if (ln > FUSED_LDS_BUDGET * 9 / 10 || ln >= ll) t_node = t_node * 4 / 5;
-    if (ll > FUSED_LDS_BUDGET * 9 / 10 || ll > ln) t_link = t_link * 4 / 5;
+                  int f_max, uds::NetworkPlan &out, int64_t &lds) {
+  // candidate (p_limit, q_limit) pairs, largest first; meta is bounded by the limits (checked after planning)
+  const int cand[][2] = {{128, 176}, {112, 160}, {96, 144}, {80, 128}, {64, 96}, {48, 64}, {32, 48}, {16, 32}};
+  for (const auto &c : cand) {
+    const int p_lim = c[0], q_lim = c[1];
+    if (uds::fused_lds_bytes(p_lim, q_lim, 0, uds::FUSED_H, uds::FUSED_D, f_max, f_max) > FUSED_LDS_BUDGET) continue;
+    const int t = std::max(8, std::min(p_lim * 4 / 5, q_lim * 3 / 5));
+    out = uds::build_network_plan(adj, eadj, inc_n, inc_e, t, t, p_lim, q_lim);
+    lds = uds::fused_lds_bytes(out.p_cap, out.q_cap, out.meta_cap, uds::FUSED_H, uds::FUSED_D, f_max, f_max);
+    if (lds <= FUSED_LDS_BUDGET && out.p_cap <= 4 * uds::FUSED_WAVES * uds::FUSED_U) return true;   // P3 covers a tile in one trip
   }
   return false;
 }
@@ -91,17 +100,24 @@ bool plan_network(const uds::HostCsr &adj, const uds::HostCsr &eadj, const uds::
 
 namespace {
 
-template <int FP, int FS>
-hipError_t launch_fused(const uds::FusedArgs &a, int grid, int64_t lds, hipStream_t st) {
+template <int FP, int FS, int ACT>
+hipError_t launch_fused_act(const uds::FusedArgs &a, int grid, int64_t lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&uds::k_fused_side<FP, FS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&uds::k_fused_tile<FP, FS, ACT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BUDGET);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((uds::k_fused_side<FP, FS>), dim3(grid), dim3(256), (size_t)lds, st, a);
+  hipLaunchKernelGGL((uds::k_fused_tile<FP, FS, ACT>), dim3(grid), dim3(uds::FUSED_WAVES * 64), (size_t)lds, st, a);
   return hipGetLastError();
+}
+
+// relu (the reference's activation in every shipped model) is compiled in; other activations are decided at run time
+template <int FP, int FS>
+hipError_t launch_fused(const uds::FusedArgs &a, int grid, int64_t lds, hipStream_t st) {
+  if (a.act == UDS_ACT_RELU) return launch_fused_act<FP, FS, UDS_ACT_RELU>(a, grid, lds, st);
+  return launch_fused_act<FP, FS, -1>(a, grid, lds, st);
 }
 
 hipError_t pack_weights(const float *W, int K, int F_out, uint4 *out, hipStream_t st) {
@@ -271,19 +287,21 @@ int uds_network_create(const uds_csr_t *adj, const uds_csr_t *edge_adj, const ud
   n->edge_adj = edge_adj;
   n->inc_n = inc_n;
   n->inc_e = inc_e;
-  // tile plan for the fused kernel (needs every row to own its self loop: GAT patterns always do)
-  if (N > 0 && E > 0 && plan_network(adj->host, edge_adj->host, inc_n->host, inc_e->host, 128, 120, n->plan, n->lds_bytes)) {
+  // tile plans for the fused kernel, one per input-width class
+  const int widths[2] = {64, 96};
+  for (int k = 0; k < 2 && N > 0 && E > 0; ++k) {
+    uds_plan_slot &sl = n->slot[k];
+    sl.f_max = widths[k];
+    if (!plan_network(adj->host, edge_adj->host, inc_n->host, inc_e->host, widths[k], sl.plan, sl.lds_bytes)) continue;
     hipError_t e;
-    if ((e = hipMalloc(&n->d_hdr, sizeof(int32_t) * n->plan.hdr.size())) != hipSuccess ||
-        (e = hipMalloc(&n->d_pool, sizeof(int32_t) * n->plan.pool.size())) != hipSuccess ||
-        (e = hipMemcpy(n->d_hdr, n->plan.hdr.data(), sizeof(int32_t) * n->plan.hdr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(n->d_pool, n->plan.pool.data(), sizeof(int32_t) * n->plan.pool.size(), hipMemcpyHostToDevice)) != hipSuccess) {
-      hipFree(n->d_hdr);
-      hipFree(n->d_pool);
-      delete n;
+    if ((e = hipMalloc(&sl.d_hdr, sizeof(int32_t) * sl.plan.hdr.size())) != hipSuccess ||
+        (e = hipMalloc(&sl.d_pool, sizeof(int32_t) * sl.plan.pool.size())) != hipSuccess ||
+        (e = hipMemcpy(sl.d_hdr, sl.plan.hdr.data(), sizeof(int32_t) * sl.plan.hdr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(sl.d_pool, sl.plan.pool.data(), sizeof(int32_t) * sl.plan.pool.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+      uds_network_destroy(n);
       return fail(UDS_ENOMEM, "uds_network_create: tile plan upload -> %s", hipGetErrorString(e));
     }
-    n->fused_ok = true;
+    sl.ok = true;
   }
   *out = n;
   return UDS_OK;
@@ -291,29 +309,33 @@ int uds_network_create(const uds_csr_t *adj, const uds_csr_t *edge_adj, const ud
 
 int uds_network_destroy(uds_network_t *net) {
   if (!net) return UDS_OK;
-  hipFree(net->d_hdr);
-  hipFree(net->d_pool);
+  for (uds_plan_slot &sl : net->slot) {
+    hipFree(sl.d_hdr);
+    hipFree(sl.d_pool);
+  }
   delete net;
   return UDS_OK;
 }
 
 int uds_network_plan_info(const uds_network_t *net, int32_t *info8) {
   UDS_REQUIRE(net && info8, "uds_network_plan_info: NULL argument");
-  info8[0] = net->fused_ok ? 1 : 0;
-  info8[1] = net->plan.side[0].n_tiles;
-  info8[2] = net->plan.side[1].n_tiles;
-  info8[3] = net->plan.p_cap;
-  info8[4] = net->plan.q_cap;
-  info8[5] = net->plan.meta_cap;
-  info8[6] = (int32_t)net->lds_bytes;
-  info8[7] = net->plan.t_max[0] * 1000 + net->plan.t_max[1];
+  const uds_plan_slot &sl = net->slot[0];   // the plan for 64-float rows (d = 64 layers)
+  info8[0] = (sl.ok ? 1 : 0) | (net->slot[1].ok ? 2 : 0);
+  info8[1] = sl.plan.side[0].n_tiles;
+  info8[2] = sl.plan.side[1].n_tiles;
+  info8[3] = sl.plan.p_cap;
+  info8[4] = sl.plan.q_cap;
+  info8[5] = sl.plan.meta_cap;
+  info8[6] = (int32_t)sl.lds_bytes;
+  info8[7] = sl.plan.t_max[0] * 1000 + sl.plan.t_max[1];
   return UDS_OK;
 }
 
 // ---- host-only tile planner access (integer bookkeeping, testable without a GPU) ----
 int uds_tile_plan_create(const int32_t *adj_rowptr, const int32_t *adj_col, const int32_t *eadj_rowptr, const int32_t *eadj_col,
                          const int32_t *incn_rowptr, const int32_t *incn_col, const int32_t *ince_rowptr, const int32_t *ince_col,
-                         int64_t n_node, int64_t n_edge, int32_t t_node, int32_t t_link, uds_tile_plan_t **out) {
+                         int64_t n_node, int64_t n_edge, int32_t t_node, int32_t t_link, int32_t p_limit, int32_t q_limit,
+                         uds_tile_plan_t **out) {
   UDS_REQUIRE(out != nullptr, "uds_tile_plan_create: out is NULL");
   *out = nullptr;
   UDS_REQUIRE(adj_rowptr && adj_col && eadj_rowptr && eadj_col && incn_rowptr && ince_rowptr, "uds_tile_plan_create: NULL array");
@@ -330,7 +352,7 @@ int uds_tile_plan_create(const int32_t *adj_rowptr, const int32_t *adj_col, cons
   if (!tp) return fail(UDS_ENOMEM, "uds_tile_plan_create: host allocation failed");
   tp->plan = uds::build_network_plan(mk(adj_rowptr, adj_col, n_node, n_node), mk(eadj_rowptr, eadj_col, n_edge, n_edge),
                                      mk(incn_rowptr, incn_col, n_node, n_edge), mk(ince_rowptr, ince_col, n_edge, n_node),
-                                     t_node, t_link);
+                                     t_node, t_link, p_limit, q_limit);
   *out = tp;
   return UDS_OK;
 }
@@ -385,11 +407,12 @@ int uds_spatial_layer_forward(const uds_network_t *net, const uds_spatial_params
   if (S == 0) return UDS_OK;
 
   const bool shape_ok = h == uds::FUSED_H && d == uds::FUSED_D && (fx == 64 || fx == 96) && (fe == 64 || fe == 96);
+  const uds_plan_slot &sl = net->slot[(fx > 64 || fe > 64) ? 1 : 0];
   if (flags & UDS_FLAG_REQUIRE_FUSED)
-    UDS_REQUIRE(net->fused_ok && shape_ok && !(flags & UDS_FLAG_EXACT_FP32),
-                "uds_spatial_layer_forward: fused kernel unavailable (plan %d, fx=%lld fe=%lld h=%lld d=%lld)", (int)net->fused_ok,
+    UDS_REQUIRE(sl.ok && shape_ok && !(flags & UDS_FLAG_EXACT_FP32),
+                "uds_spatial_layer_forward: fused kernel unavailable (plan %d, fx=%lld fe=%lld h=%lld d=%lld)", (int)sl.ok,
                 (long long)fx, (long long)fe, (long long)h, (long long)d);
-  if (net->fused_ok && shape_ok && !(flags & UDS_FLAG_EXACT_FP32)) {
+  if (sl.ok && shape_ok && !(flags & UDS_FLAG_EXACT_FP32)) {
     UDS_REQUIRE(aligned16(p->xe_b) && aligned16(p->ex_b) && aligned16(p->gx_as) && aligned16(p->gx_an) && aligned16(p->gx_b) &&
                     aligned16(p->ge_as) && aligned16(p->ge_an) && aligned16(p->ge_b),
                 "uds_spatial_layer_forward: bias / attention vectors must be 16-byte aligned");
@@ -405,31 +428,36 @@ int uds_spatial_layer_forward(const uds_network_t *net, const uds_spatial_params
     uds::FusedArgs a;
     a.side[0] = uds::FusedSide{x, e, out_x, w_small_n, w_big_n, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
     a.side[1] = uds::FusedSide{e, x, out_e, w_small_e, w_big_e, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};
-    a.hdr = net->d_hdr;
-    a.pool = net->d_pool;
-    a.n_tiles = net->plan.n_tiles;
+    a.hdr = sl.d_hdr;
+    a.pool = sl.d_pool;
+    a.n_tiles = sl.plan.n_tiles;
     a.S = (int)S;
-    a.p_cap = net->plan.p_cap;
-    a.q_cap = net->plan.q_cap;
-    a.meta_cap = net->plan.meta_cap;
+    a.p_cap = sl.plan.p_cap;
+    a.q_cap = sl.plan.q_cap;
+    a.meta_cap = sl.plan.meta_cap;
     a.act = act;
-    // enough workgroups to fill 256 CUs x 2 several times over, but >= 4 snapshots per workgroup when S allows
-    // (weights are loaded once per workgroup)
-    int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>(S, (4096 + a.n_tiles - 1) / a.n_tiles));
+    a.dbg = nullptr;
+#ifdef UDS_PHASE_TIMING
+    a.dbg = reinterpret_cast<unsigned long long *>(ws + PACKED_WEIGHT_FLOATS);   // diagnostic build: stamps go to the (otherwise unused) workspace
+#endif
+    // one workgroup per CU: ~5 rounds of 256 workgroups keep the tail short, while a workgroup stays on its tile
+    // for as many snapshots as that allows (metadata, weights and the DMA pipeline are set up once per workgroup)
+    int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>(S, (1280 + a.n_tiles - 1) / a.n_tiles));
     int64_t chunk = (S + n_chunks - 1) / n_chunks;
-    if (chunk < 4 && S >= 4) chunk = 4;
     n_chunks = (S + chunk - 1) / chunk;
     a.chunk = (int)chunk;
     const int grid = (int)(n_chunks * a.n_tiles);
+    const int64_t lds_need = uds::fused_lds_bytes(a.p_cap, a.q_cap, a.meta_cap, uds::FUSED_H, uds::FUSED_D, (int)std::max(fx, fe),
+                                                  (int)std::max(fx, fe));
     if (fx == fe) {
       a.side_mask = 3;
-      he = (fx == 64) ? launch_fused<64, 64>(a, grid, net->lds_bytes, st) : launch_fused<96, 96>(a, grid, net->lds_bytes, st);
+      he = (fx == 64) ? launch_fused<64, 64>(a, grid, lds_need, st) : launch_fused<96, 96>(a, grid, lds_need, st);
     } else {   // node tiles: FP = fx, FS = fe; link tiles: FP = fe, FS = fx -> one launch per side
       a.side_mask = 1;
-      he = (fx == 64) ? launch_fused<64, 96>(a, grid, net->lds_bytes, st) : launch_fused<96, 64>(a, grid, net->lds_bytes, st);
+      he = (fx == 64) ? launch_fused<64, 96>(a, grid, lds_need, st) : launch_fused<96, 64>(a, grid, lds_need, st);
       if (he == hipSuccess) {
         a.side_mask = 2;
-        he = (fe == 64) ? launch_fused<64, 96>(a, grid, net->lds_bytes, st) : launch_fused<96, 64>(a, grid, net->lds_bytes, st);
+        he = (fe == 64) ? launch_fused<64, 96>(a, grid, lds_need, st) : launch_fused<96, 64>(a, grid, lds_need, st);
       }
     }
     if (he != hipSuccess) return fail(UDS_EHIP, "uds_spatial_layer_forward: fused launch -> %s", hipGetErrorString(he));

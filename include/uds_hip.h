@@ -112,13 +112,15 @@ int uds_network_plan_info(const uds_network_t *net, int32_t *info8);
 
 /* Host-only access to the tile planner (integer bookkeeping; works without a GPU).  A plan clusters the
  * primary rows of each side (nodes under adj, links under edge_adj) into tiles of at most t_node / t_link
- * rows and lists, per tile, own rows, halo rows, secondary rows and local CSR indices (layout:
+ * rows (clusters whose primary / secondary footprint exceeds p_limit / q_limit > 0 are bisected) and lists, per
+ * tile, own rows, halo rows, secondary rows and local CSR indices (layout:
  * gnn_uds_amd/csrc/tile_plan.hpp).  hdr_out holds 8 ints per tile, pool_out pool_len ints. */
 typedef struct uds_tile_plan uds_tile_plan_t;
 int uds_tile_plan_create(const int32_t *adj_rowptr, const int32_t *adj_col, const int32_t *eadj_rowptr,
                          const int32_t *eadj_col, const int32_t *incn_rowptr, const int32_t *incn_col,
                          const int32_t *ince_rowptr, const int32_t *ince_col, int64_t n_node,
-                         int64_t n_edge, int32_t t_node, int32_t t_link, uds_tile_plan_t **out);
+                         int64_t n_edge, int32_t t_node, int32_t t_link, int32_t p_limit,
+                         int32_t q_limit, uds_tile_plan_t **out);
 int uds_tile_plan_destroy(uds_tile_plan_t *plan);
 int uds_tile_plan_sizes(const uds_tile_plan_t *plan, int64_t *n_tiles, int64_t *pool_len, int32_t *caps3);
 int uds_tile_plan_copy(const uds_tile_plan_t *plan, int32_t *hdr_out, int32_t *pool_out);

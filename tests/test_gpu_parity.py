@@ -161,7 +161,7 @@ def test_spatial_layer_vs_dense_masked_oracle(dev, networks, name, d, S, precisi
     close(ox, rx, tol); close(oe, re, tol)
     if d == 64:
         info = layer.network().plan_info()
-        assert info['fused'] == 1 and info['lds_bytes'] <= 78 * 1024
+        assert info['fused'] & 1 and info['lds_bytes'] <= 160 * 1024
     # trained (dense) NodeEdge bias -> unfused composition + remainder GEMM, same answer as the dense oracle
     p['ne_n_b'] = torch.randn(p['ne_n_b'].shape, generator=g, dtype=torch.float64) * 0.01
     p['ne_e_b'] = torch.randn(p['ne_e_b'].shape, generator=g, dtype=torch.float64) * 0.01

@@ -30,7 +30,10 @@ def check_plan(g, hdr, pool, caps, t_node, t_link):
         d = decode(hdr, pool, t)
         adj, inc, t_max = sides[d['side']]
         own = d['prim'][:d['n_own']]
-        assert 1 <= d['n_own'] <= t_max and (np.diff(own) > 0).all()
+        assert 1 <= d['n_own'] <= t_max and len(set(own.tolist())) == len(own)
+        deg = (adj.rowptr[own + 1] - adj.rowptr[own]).astype(int)
+        order = sorted(range(len(own)), key=lambda k: (-deg[k], own[k]))          # degree-sorted schedule, ties by id
+        assert order == list(range(len(own)))
         owned[d['side']][own] += 1
         nb = np.unique(np.concatenate([adj.col[adj.rowptr[r]:adj.rowptr[r + 1]] for r in own]))
         halo = np.setdiff1d(nb, own)
@@ -52,9 +55,12 @@ def check_plan(g, hdr, pool, caps, t_node, t_link):
 def test_plan_on_real_networks(networks, name):
     net = networks[name]
     g = U.DrainageGraph.from_edges(np.array(net['edges']), net['n_node'])
-    for t_node, t_link in ((128, 120), (16, 12), (1, 1)):
-        hdr, pool, caps = _lib.tile_plan(g, t_node, t_link)
+    for t_node, t_link, p_lim, q_lim in ((128, 120, 0, 0), (48, 48, 64, 80), (16, 12, 0, 0), (1, 1, 0, 0), (40, 40, 16, 16)):
+        hdr, pool, caps = _lib.tile_plan(g, t_node, t_link, p_lim, q_lim)
         check_plan(g, hdr, pool, caps, t_node, t_link)
+        if p_lim:                                                # limits hold unless a single row already exceeds them
+            multi = hdr[:, 0] > 1
+            assert (hdr[multi, 1] <= p_lim).all() and (hdr[multi, 2] <= q_lim).all()
 
 
 def test_plan_with_isolated_rows_and_self_loop_link():
@@ -64,16 +70,20 @@ def test_plan_with_isolated_rows_and_self_loop_link():
     check_plan(g, hdr, pool, caps, 4, 4)
 
 
-def test_headline_plan_has_small_halos():
-    """Near-tree clustering: halo rows stay a small fraction (what makes one-pass fusion pay)."""
+def test_headline_plan_fits_the_cu_lds():
+    """The plan uds_network_create builds for 64-float rows: footprint limits (128 primary / 176 secondary rows)
+    are enforced by bisecting outlier clusters, halos stay a modest fraction, LDS <= 160 KiB (one 8-wave workgroup per CU)."""
     g = U.DrainageGraph.from_edges(U.synthetic_drainage_network(10000, 12000, 0))
-    hdr, pool, caps = _lib.tile_plan(g, 112, 104)
-    check_plan(g, hdr, pool, caps, 112, 104)
+    hdr, pool, caps = _lib.tile_plan(g, 102, 102, 128, 176)
+    check_plan(g, hdr, pool, caps, 102, 102)
+    assert caps['p_cap'] <= 128 and caps['q_cap'] <= 176
     for side, n in ((0, g.n_node), (1, g.n_edge)):
         h = hdr[hdr[:, 6] == side]
         assert h[:, 0].sum() == n
-        assert h[:, 1].sum() <= 1.35 * n                   # prim rows (own + halo) per side
-    lds = 4 * (caps['meta_cap'] + 2 * caps['p_cap'] + caps['q_cap'] * 36 + caps['p_cap'] * 64)
-    assert lds <= 78 * 1024
-    a, b, c = _lib.tile_plan(g, 112, 104)
+        assert h[:, 1].sum() <= 1.5 * n                    # prim rows (own + halo) per side
+    # LDS of the fused kernel at F = 64: meta + scalars + P3 scratch + sec rows + hx rows + DMA stage of raw rows
+    lds = 4 * (160 + 4096 + caps["meta_cap"] + 2 * caps["p_cap"] + caps['q_cap'] * 36 + caps['p_cap'] * 64) + \
+        256 * (caps['q_cap'] + caps['p_cap'])
+    assert lds <= 160 * 1024
+    a, b, c = _lib.tile_plan(g, 102, 102, 128, 176)
     assert np.array_equal(a, hdr) and np.array_equal(b, pool)   # deterministic

@@ -1,0 +1,47 @@
+"""Diagnostic: per-phase cycle shares of the fused kernel (needs a library built with UDS_PHASE_TIMING=1).
+Run on the GPU box:  UDS_PHASE_TIMING=1 python -m gnn_uds_amd.build --force && python tools/phase_timing.py"""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gnn_uds_amd as U
+from gnn_uds_amd import _lib
+
+dev = torch.device('cuda', 0)
+g = U.DrainageGraph.from_edges(U.synthetic_drainage_network(10000, 12000, 0))
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+layer = U.SpatialLayer(g, 64, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1)).to(dev)
+x, e = torch.rand(S, 10000, 64, device=dev), torch.rand(S, 12000, 64, device=dev)
+lib = _lib.load()
+net = layer.network()
+info = net.plan_info()
+vn, _ = layer.node_edge_n.support_values(); ve, _ = layer.node_edge_e.support_values()
+p = {k: (v.to(dev) if v is not None else None) for k, v in layer.export_params().items() if not k.startswith('ne_')}
+p.update(ne_n_val=vn, ne_e_val=ve)
+import ctypes
+sp = _lib.SpatialParams()
+for name, _ in _lib.SpatialParams._fields_:
+    setattr(sp, name, _lib._dev(p[name], name, allow_none=name.endswith('_b')))
+ws = torch.zeros(lib.uds_spatial_workspace_floats(net.ptr, S, 32, 64), device=dev)
+ox, oe = torch.empty(S, 10000, 64, device=dev), torch.empty(S, 12000, 64, device=dev)
+for _ in range(3):
+    ws.zero_()
+    rc = lib.uds_spatial_layer_forward(net.ptr, ctypes.byref(sp), x.data_ptr(), 64, e.data_ptr(), 64, S, 32, 64, 1, 0, ws.data_ptr(), ox.data_ptr(), oe.data_ptr(), None)
+    assert rc == 0
+torch.cuda.synchronize()
+n_tiles = info['node_tiles'] + info['link_tiles']
+raw = ws[22528:].view(torch.int64).cpu().numpy()
+n_wg = 0
+rows = raw[:(len(raw) // 12) * 12].reshape(-1, 12)
+valid = (rows[:, 7] & 1) == 1
+rows = rows[valid]
+print('waves with stamps:', len(rows), 'plan', info)
+names = ['setup', 'wait_stage', 'P1', 'bar1', 'P2', 'bar2', 'P3']
+tot = rows[:, :7].sum()
+for side in (0, 1):
+    r = rows[((rows[:, 7] >> 8) & 0xff) == side]
+    print('side', side, 'waves', len(r), ' mean cycles per wave:', {n: int(r[:, k].mean()) for k, n in enumerate(names)}, 'total', int(r[:, :7].sum(1).mean()))
+for wv in range(8):
+    r = rows[rows[:, 10] == wv]
+    print('wave', wv, {n: int(r[:, k].mean()) for k, n in enumerate(names)}, 'P3pre', int(r[:, 8].mean()), 'P3loop', int(r[:, 9].mean()))
+print('shares:', {n: round(float(rows[:, k].sum() / tot), 3) for k, n in enumerate(names)})
