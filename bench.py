@@ -32,6 +32,20 @@ def algorithmic_bytes_per_graph_step(g, f_in, d):
     return 4 * (N + E) * (f_in + d) + 4 * ((N + 1) + g.adj.nnz + (E + 1) + g.edge_adj.nnz + 4 * 2 * E)
 
 
+def recorded_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json),
+    only when this run's configuration is the one they were collected on; None otherwise."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as fh:
+            rec = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    cfg = rec.get('config', {})
+    same = (cfg.get('nodes') == args.nodes and cfg.get('links') == args.links and cfg.get('embed') == args.embed and
+            cfg.get('snapshots') == args.snapshots and cfg.get('precision') == args.precision)
+    return rec.get('traffic_bytes_per_launch') if same else None
+
+
 def cpu_baseline(g, block_params, d, budget_s=12.0, S=2):
     """The oracle (sparse-CSR PyTorch-CPU restatement of the reference forward, kind 'port': the
     reference's TF path cannot run here) timed on this host's cores on a bounded sample."""
@@ -56,7 +70,7 @@ def cpu_baseline(g, block_params, d, budget_s=12.0, S=2):
         one_pass()
         n += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or n >= 50:
+        if el >= budget_s or n >= 400:
             break
     steps = n * len(block_params) * S
     return {'value': steps / el, 'unit': 'graph-steps/s', 'cores': cores, 'kind': 'port',
@@ -146,8 +160,9 @@ def main():
                        'parallelism': 'snapshot-sharded x%d' % world, 'precision': args.precision,
                        'plan': block.layers[0].network().plan_info()},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
-                         'kernel': 'k_fused_side<64,64> (one launch per layer over S snapshots)' if args.precision == 'bf16x3' else
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': recorded_traffic(args),
+                         'algorithmic_bytes_per_launch': S * bytes_gs, 'launch_ms': dev_ms / L,
+                         'kernel': 'k_fused_tile<64,64,relu> (one launch per layer over S snapshots)' if args.precision == 'bf16x3' else
                                    'uds_spatial_layer_forward, unfused (8 launches per layer over S snapshots)',
                          'algorithmic_bytes_per_graph_step': bytes_gs, 'device_ms_per_step': dev_ms},
         }

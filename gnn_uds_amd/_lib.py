@@ -46,6 +46,8 @@ SYMBOLS = {
     'uds_tile_plan_sizes': (_c_int, [_c_ptr, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64), _c_ptr]),
     'uds_tile_plan_copy': (_c_int, [_c_ptr, _c_ptr, _c_ptr]),
     'uds_spatial_workspace_floats': (_c_i64, [_c_ptr, _c_i64, _c_i64, _c_i64]),
+    'uds_spatial_packed_bytes': (_c_i64, []),
+    'uds_spatial_pack_weights': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr]),
     'uds_spatial_layer_forward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
                                            _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
 }
@@ -54,7 +56,7 @@ SYMBOLS = {
 class SpatialParams(ctypes.Structure):
     """uds_spatial_params_t"""
     _fields_ = [(n, _c_ptr) for n in ('xe_k', 'xe_b', 'ex_k', 'ex_b', 'ne_n_val', 'ne_e_val',
-                                      'gx_k', 'gx_as', 'gx_an', 'gx_b', 'ge_k', 'ge_as', 'ge_an', 'ge_b')]
+                                      'gx_k', 'gx_as', 'gx_an', 'gx_b', 'ge_k', 'ge_as', 'ge_an', 'ge_b', 'packed')]
 
 
 class UdsError(RuntimeError):
@@ -265,6 +267,29 @@ def gat_forward(handle, xa, kernel, a_self, a_nbr, bias=None, act='relu', xb=Non
     return out
 
 
+def _spatial_params(p):
+    sp = SpatialParams()
+    for name, _ in SpatialParams._fields_:
+        if name == 'packed':
+            t = p.get('packed')
+            sp.packed = None if t is None else t.data_ptr()
+        else:
+            setattr(sp, name, _dev(p[name], name, allow_none=name.endswith('_b')))
+    return sp
+
+
+def spatial_pack_weights(p, fx, fe, h, d):
+    """Pre-split the four kernels of a spatial layer into the fused kernel's bf16 hi/lo MFMA fragments (done once per
+    parameter update instead of in every forward call).  Returns the device buffer to pass as p['packed']."""
+    lib = load()
+    out = torch.empty(lib.uds_spatial_packed_bytes() // 4, device=p['xe_k'].device, dtype=torch.float32)
+    q = dict(p)
+    q['packed'] = None
+    _check(lib.uds_spatial_pack_weights(ctypes.byref(_spatial_params(q)), fx, fe, h, d, out.data_ptr(), _stream()),
+           'uds_spatial_pack_weights')
+    return out
+
+
 def spatial_layer_forward(net, p, x, e, h, d, act='relu', flags=0):
     """One spatial-block loop body (`emulator.py:225-230`).  p: dict of the 14 tensors of
     uds_spatial_params_t.  x:(S,N,fx), e:(S,E,fe) -> (S,N,d), (S,E,d).  flags: FLAG_* of the C ABI."""
@@ -278,9 +303,7 @@ def spatial_layer_forward(net, p, x, e, h, d, act='relu', flags=0):
         _dev(x, 'x')
         return (torch.empty((0, N, d), device=x.device, dtype=torch.float32),
                 torch.empty((0, E, d), device=x.device, dtype=torch.float32))
-    sp = SpatialParams()
-    for name, _ in SpatialParams._fields_:
-        setattr(sp, name, _dev(p[name], name, allow_none=name.endswith('_b')))
+    sp = _spatial_params(p)
     ws = torch.empty(lib.uds_spatial_workspace_floats(net.ptr, S, h, d), device=x.device, dtype=torch.float32)
     out_x = torch.empty((S, N, d), device=x.device, dtype=torch.float32)
     out_e = torch.empty((S, E, d), device=x.device, dtype=torch.float32)

@@ -389,6 +389,27 @@ int64_t uds_spatial_workspace_floats(const uds_network_t *net, int64_t S, int64_
 }
 
 
+int64_t uds_spatial_packed_bytes(void) { return PACKED_WEIGHT_FLOATS * 4; }
+
+int uds_spatial_pack_weights(const uds_spatial_params_t *p, int64_t fx, int64_t fe, int64_t h, int64_t d, void *packed_out,
+                             uds_stream_t stream) {
+  UDS_REQUIRE(p && packed_out && p->xe_k && p->ex_k && p->gx_k && p->ge_k, "uds_spatial_pack_weights: NULL argument");
+  UDS_REQUIRE(h == uds::FUSED_H && d == uds::FUSED_D && (fx == 64 || fx == 96) && (fe == 64 || fe == 96),
+              "uds_spatial_pack_weights: the fused kernel takes h=32, d=64, fx, fe in {64, 96} (got h=%lld d=%lld fx=%lld fe=%lld)",
+              (long long)h, (long long)d, (long long)fx, (long long)fe);
+  UDS_REQUIRE(aligned16(packed_out), "uds_spatial_pack_weights: output must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  uint4 *wq = reinterpret_cast<uint4 *>(packed_out);
+  hipError_t he;
+  // node side: secondary = links (xe_k on e), big = gx_k; link side: secondary = nodes (ex_k on x), big = ge_k
+  if ((he = pack_weights(p->xe_k, (int)fe, (int)h, wq, st)) != hipSuccess ||
+      (he = pack_weights(p->gx_k, (int)(fx + h), (int)d, wq + 768, st)) != hipSuccess ||
+      (he = pack_weights(p->ex_k, (int)fx, (int)h, wq + 768 + 2048, st)) != hipSuccess ||
+      (he = pack_weights(p->ge_k, (int)(fe + h), (int)d, wq + 2 * 768 + 2048, st)) != hipSuccess)
+    return fail(UDS_EHIP, "uds_spatial_pack_weights: launch -> %s", hipGetErrorString(he));
+  return UDS_OK;
+}
+
 int uds_spatial_layer_forward(const uds_network_t *net, const uds_spatial_params_t *p, const float *x, int64_t fx,
                               const float *e, int64_t fe, int64_t S, int64_t h, int64_t d, int act, int flags, float *ws,
                               float *out_x, float *out_e, uds_stream_t stream) {
@@ -416,15 +437,16 @@ int uds_spatial_layer_forward(const uds_network_t *net, const uds_spatial_params
     UDS_REQUIRE(aligned16(p->xe_b) && aligned16(p->ex_b) && aligned16(p->gx_as) && aligned16(p->gx_an) && aligned16(p->gx_b) &&
                     aligned16(p->ge_as) && aligned16(p->ge_an) && aligned16(p->ge_b),
                 "uds_spatial_layer_forward: bias / attention vectors must be 16-byte aligned");
-    uint4 *wq = reinterpret_cast<uint4 *>(ws);
-    uint4 *w_small_n = wq, *w_big_n = wq + 768, *w_small_e = wq + 768 + 2048, *w_big_e = wq + 2 * 768 + 2048;
     hipError_t he;
-    // node side: secondary = links (xe_k on e), big = gx_k; link side: secondary = nodes (ex_k on x), big = ge_k
-    if ((he = pack_weights(p->xe_k, (int)fe, (int)h, w_small_n, st)) != hipSuccess ||
-        (he = pack_weights(p->gx_k, (int)(fx + h), (int)d, w_big_n, st)) != hipSuccess ||
-        (he = pack_weights(p->ex_k, (int)fx, (int)h, w_small_e, st)) != hipSuccess ||
-        (he = pack_weights(p->ge_k, (int)(fe + h), (int)d, w_big_e, st)) != hipSuccess)
-      return fail(UDS_EHIP, "uds_spatial_layer_forward: weight packing -> %s", hipGetErrorString(he));
+    const uint4 *wq = reinterpret_cast<const uint4 *>(p->packed);
+    if (!wq) {   // no pre-packed weights: split them now into the head of the workspace
+      int rc = uds_spatial_pack_weights(p, fx, fe, h, d, ws, stream);
+      if (rc != UDS_OK) return rc;
+      wq = reinterpret_cast<const uint4 *>(ws);
+    } else {
+      UDS_REQUIRE(aligned16(wq), "uds_spatial_layer_forward: packed weights must be 16-byte aligned");
+    }
+    const uint4 *w_small_n = wq, *w_big_n = wq + 768, *w_small_e = wq + 768 + 2048, *w_big_e = wq + 2 * 768 + 2048;
     uds::FusedArgs a;
     a.side[0] = uds::FusedSide{x, e, out_x, w_small_n, w_big_n, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
     a.side[1] = uds::FusedSide{e, x, out_e, w_small_e, w_big_e, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};

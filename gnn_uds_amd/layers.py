@@ -293,6 +293,14 @@ class SpatialLayer(nn.Module):
         self.gat_x = GATConv(self.d, activation=activation, in_channels=fx + self.h, generator=g)   # :229
         self.gat_e = GATConv(self.d, activation=activation, in_channels=fe + self.h, generator=g)   # :230
         self._net = net
+        self._packed = None       # (parameter versions, packed bf16 hi/lo fragments) of the four GEMM kernels
+
+    def _packed_weights(self, p, fx, fe):
+        ks = (self.dense_xe.kernel, self.dense_ex.kernel, self.gat_x.kernel, self.gat_e.kernel)
+        key = tuple((k._version, k.data_ptr()) for k in ks) + (fx, fe)
+        if self._packed is None or self._packed[0] != key:
+            self._packed = (key, _lib.spatial_pack_weights(p, fx, fe, self.h, self.d))
+        return self._packed[1]
 
     def network(self):
         if self._net is None:
@@ -328,6 +336,9 @@ class SpatialLayer(nn.Module):
                      gx_b=self.gat_x.bias,
                      ge_k=self.gat_e.kernel, ge_as=self.gat_e.attn_kernel_self, ge_an=self.gat_e.attn_kernel_neighs,
                      ge_b=self.gat_e.bias)
+            fx, fe = xs.shape[-1], es.shape[-1]
+            if self.precision == 'bf16x3' and self.h == 32 and self.d == 64 and fx in (64, 96) and fe in (64, 96):
+                p['packed'] = self._packed_weights(p, fx, fe)       # split once per parameter update, not per call
             ox, oe = _lib.spatial_layer_forward(self.network(), p, xs, es, self.h, self.d, self.activation,
                                                 _lib.PRECISION_FLAGS[self.precision])
         else:   # trained dense NodeEdge bias: unfused composition with the dense remainder GEMM

@@ -132,7 +132,16 @@ typedef struct uds_spatial_params {
   const float *ne_e_val;    /* NodeEdge(|inci|^T) on its support: nnz(inc_e)  emulator.py:228 */
   const float *gx_k, *gx_as, *gx_an, *gx_b; /* GAT nodes: (fx+h, d),(d),(d),(d) emulator.py:229 */
   const float *ge_k, *ge_as, *ge_an, *ge_b; /* GAT links: (fe+h, d),(d),(d),(d) emulator.py:230 */
+  const void *packed;       /* optional: output of uds_spatial_pack_weights for THESE kernels (device, 16-B aligned);
+                               NULL = pack inside every forward call (4 tiny launches) */
 } uds_spatial_params_t;
+
+/* Bytes of the packed-weight buffer (fixed, covers fx, fe up to 96). */
+int64_t uds_spatial_packed_bytes(void);
+/* Splits the four kernels xe_k, ex_k, gx_k, ge_k into bf16 hi/lo MFMA fragments for the fused kernel.  Call once per
+ * parameter update; the buffer must outlive the forward calls that reference it. */
+int uds_spatial_pack_weights(const uds_spatial_params_t *params, int64_t fx, int64_t fe, int64_t h, int64_t d,
+                             void *packed_out, uds_stream_t stream);
 
 /* flags of uds_spatial_layer_forward */
 enum {

@@ -19,9 +19,7 @@ vn, _ = layer.node_edge_n.support_values(); ve, _ = layer.node_edge_e.support_va
 p = {k: (v.to(dev) if v is not None else None) for k, v in layer.export_params().items() if not k.startswith('ne_')}
 p.update(ne_n_val=vn, ne_e_val=ve)
 import ctypes
-sp = _lib.SpatialParams()
-for name, _ in _lib.SpatialParams._fields_:
-    setattr(sp, name, _lib._dev(p[name], name, allow_none=name.endswith('_b')))
+sp = _lib._spatial_params(p)
 ws = torch.zeros(lib.uds_spatial_workspace_floats(net.ptr, S, 32, 64), device=dev)
 ox, oe = torch.empty(S, 10000, 64, device=dev), torch.empty(S, 12000, 64, device=dev)
 for _ in range(3):
