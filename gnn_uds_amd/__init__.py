@@ -11,4 +11,6 @@ from .graph import CSR, DrainageGraph, synthetic_drainage_network     # noqa: F4
 from .layers import (Dense, GATConv, GCNConv, MixedGAT, NodeEdge,     # noqa: F401
                      SpatialBlock, SpatialLayer)
 
+from .emulator import Conv1D, Emulator                                # noqa: F401,E402
+
 __version__ = '0.1.0'

@@ -35,6 +35,10 @@ SYMBOLS = {
     'uds_dense_act': (_c_int, [_c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr,
                                _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'uds_csr_spmm': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_int, _c_ptr, _c_ptr]),
+    'uds_conv1d_causal': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr,
+                                   _c_ptr]),
+    'uds_cumsum_act': (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
+    'uds_flow_balance': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'uds_gat_workspace_floats': (_c_i64, [_c_i64, _c_i64, _c_i64]),
     'uds_gat_forward': (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                  _c_int, _c_ptr, _c_ptr, _c_ptr]),
@@ -227,6 +231,53 @@ def dense_act(xa, kernel, bias=None, act='linear', xb=None, attn=None):
                              _dev(out, 'out'), _dev(s_self, 's_self', True), _dev(s_nbr, 's_nbr', True), _stream()),
            'uds_dense_act')
     return (out, s_self, s_nbr) if attn is not None else out
+
+
+def conv1d_causal(x, kernel, bias=None, dilation=1, act='linear'):
+    """keras Conv1D(padding='causal', dilation_rate) along axis 1 of x (B,T,R,F), no transposes; kernel (taps,F,H)."""
+    lib = load()
+    if x.dim() != 4 or kernel.dim() != 3 or kernel.shape[1] != x.shape[-1]:
+        raise UdsError('conv1d_causal: x %r / kernel %r' % (tuple(x.shape), tuple(kernel.shape)))
+    B, T, R, F = x.shape
+    taps, _, H = kernel.shape
+    out = torch.empty((B, T, R, H), device=x.device, dtype=torch.float32)
+    if out.numel() == 0:
+        _dev(x, 'x')
+        return out
+    _check(lib.uds_conv1d_causal(_dev(x, 'x'), B, T, R, F, _dev(kernel, 'kernel'), _dev(bias, 'bias', True), taps, dilation, H,
+                                 ACT[act], _dev(out, 'out'), _stream()), 'uds_conv1d_causal')
+    return out
+
+
+def cumsum_act(x, res=None, act='linear'):
+    """act(cumsum over axis 1 of x (B,T,R,F) + res (B,1,R,F))."""
+    lib = load()
+    B, T, R, F = x.shape
+    if res is not None and tuple(res.shape) != (B, 1, R, F):
+        raise UdsError('cumsum_act: res must be %r, got %r' % ((B, 1, R, F), tuple(res.shape)))
+    out = torch.empty_like(x)
+    if out.numel() == 0:
+        _dev(x, 'x')
+        return out
+    _check(lib.uds_cumsum_act(_dev(x, 'x'), _dev(res, 'res', True), B, T, R, F, ACT[act], _dev(out, 'out'), _stream()),
+           'uds_cumsum_act')
+    return out
+
+
+def flow_balance(handle, sign, flow, scale_in, scale_out):
+    """Link -> node flow balance (emulator.py:717-724): flow (S,E) -> q_in, q_out (S,N)."""
+    lib = load()
+    if flow.dim() != 2 or flow.shape[1] != handle.n_cols:
+        raise UdsError('flow must be (S,%d), got %r' % (handle.n_cols, tuple(flow.shape)))
+    S = flow.shape[0]
+    q_in = torch.empty((S, handle.n_rows), device=flow.device, dtype=torch.float32)
+    q_out = torch.empty_like(q_in)
+    if q_in.numel() == 0:
+        return q_in, q_out
+    _check(lib.uds_flow_balance(handle.ptr, _dev(sign, 'sign'), _dev(flow, 'flow'), S, _dev(scale_in, 'scale_in'),
+                                _dev(scale_out, 'scale_out'), _dev(q_in, 'q_in'), _dev(q_out, 'q_out'), _stream()),
+           'uds_flow_balance')
+    return q_in, q_out
 
 
 def csr_spmm(handle, val, x, bias=None, act='linear'):

@@ -16,6 +16,9 @@ struct DenseArgs {
   float *out, *s_self, *s_nbr;
   int fa, fb, fo, act;
   int64_t rows;
+  // causal dilated Conv1D over time as a GEMM on time-shifted rows (taps = 0: plain dense).  Rows are (b, t, r) with
+  // r fastest: tap j reads the row `(taps-1-j)*dil` time steps earlier (t_rows rows back) or zero before t = 0.
+  int taps = 0, dil = 1, T = 1, t_rows = 1;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(256) void k_dense_act(DenseArgs a) {
   const int cg = tid % CG;
   const int rt = tid / CG;
   const int64_t row0 = (int64_t)blockIdx.x * ROWS;
-  const int F = a.fa + a.fb;
+  const int F = a.taps ? a.taps * a.fa : a.fa + a.fb;
 
   float acc[TM][4];
 #pragma unroll
@@ -57,9 +60,17 @@ __global__ __launch_bounds__(256) void k_dense_act(DenseArgs a) {
       const int64_t grow = row0 + r;
       const int kk = k0 + k;
       float v = 0.0f;
-      if (grow < a.rows) {
-        if (kk < a.fa) v = a.xa[grow * a.fa + kk];
-        else if (kk < F) v = a.xb[grow * a.fb + (kk - a.fa)];
+      if (grow < a.rows && kk < F) {
+        if (a.taps) {
+          const int j = kk / a.fa, f = kk - j * a.fa;
+          const int shift = (a.taps - 1 - j) * a.dil;
+          const int t = (int)((grow / a.t_rows) % a.T);
+          if (t >= shift) v = a.xa[(grow - (int64_t)shift * a.t_rows) * a.fa + f];
+        } else if (kk < a.fa) {
+          v = a.xa[grow * a.fa + kk];
+        } else {
+          v = a.xb[grow * a.fb + (kk - a.fa)];
+        }
       }
       As[r][k] = v;
     }

@@ -108,4 +108,71 @@ inline hipError_t launch_gat_aggregate(const GatArgs &a, hipStream_t st) {
   return hipGetLastError();
 }
 
+// out[b,t,r,:] = act(sum_{t' <= t} x[b,t',r,:] + res[b,0,r,:])   -- `cumsum(x_out, axis=1) + tile(res)` then the
+// activation (emulator.py:313-320).  One lane owns one float4 feature chunk of one (b, r) and walks the T steps.
+struct CumsumArgs {
+  const float *x, *res;
+  float *out;
+  int B, T, R, f4, act;
+};
+
+__global__ __launch_bounds__(256) void k_cumsum_res_act(CumsumArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per_b = (int64_t)a.R * a.f4;
+  if (t >= per_b * a.B) return;
+  const int64_t b = t / per_b, rc = t - b * per_b;
+  const float4 *x4 = reinterpret_cast<const float4 *>(a.x) + b * a.T * per_b + rc;
+  float4 *o4 = reinterpret_cast<float4 *>(a.out) + b * a.T * per_b + rc;
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.res) r = reinterpret_cast<const float4 *>(a.res)[b * per_b + rc];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < a.T; ++s) {
+    const float4 v = x4[(int64_t)s * per_b];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    float4 o;
+    o.x = apply_act(acc.x + r.x, a.act);
+    o.y = apply_act(acc.y + r.y, a.act);
+    o.z = apply_act(acc.z + r.z, a.act);
+    o.w = apply_act(acc.w + r.w, a.act);
+    o4[(int64_t)s * per_b] = o;
+  }
+}
+
+inline hipError_t launch_cumsum(const CumsumArgs &a, hipStream_t st) {
+  const int64_t total = (int64_t)a.B * a.R * a.f4;
+  hipLaunchKernelGGL(k_cumsum_res_act, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// Link -> node flow balance of post_proc_tf (emulator.py:717-724): for node n and every incident link l with
+// sign sg (+1 = n is the from-node, -1 = the to-node) and signed flow f:
+//   q_out[n] += sg > 0 ? max(f,0) : max(-f,0);   q_in[n] += sg > 0 ? max(-f,0) : max(f,0)
+// each scaled per node (the reference divides by norm_y where it exceeds 1e-3, else multiplies by 0).
+struct FlowArgs {
+  const int32_t *rowptr, *col;
+  const float *sign, *flow, *scale_in, *scale_out;
+  float *q_in, *q_out;
+  int n_node, n_edge, S;
+};
+
+__global__ __launch_bounds__(256) void k_flow_balance(FlowArgs a) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= a.n_node) return;
+  const int s = blockIdx.y;
+  const float *f = a.flow + (int64_t)s * a.n_edge;
+  float qi = 0.f, qo = 0.f;
+  for (int p = a.rowptr[n]; p < a.rowptr[n + 1]; ++p) {
+    const float v = f[a.col[p]];
+    const float fp = fmaxf(v, 0.f), fn = fmaxf(-v, 0.f);
+    if (a.sign[p] > 0.f) { qo += fp; qi += fn; } else { qi += fp; qo += fn; }
+  }
+  a.q_in[(int64_t)s * a.n_node + n] = qi * a.scale_in[n];
+  a.q_out[(int64_t)s * a.n_node + n] = qo * a.scale_out[n];
+}
+
+inline hipError_t launch_flow_balance(const FlowArgs &a, hipStream_t st) {
+  hipLaunchKernelGGL(k_flow_balance, dim3((unsigned)((a.n_node + 255) / 256), (unsigned)a.S), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 }  // namespace uds

@@ -230,6 +230,50 @@ int uds_dense_act(const float *xa, int64_t fa, const float *xb, int64_t fb, int6
   return UDS_OK;
 }
 
+int uds_conv1d_causal(const float *x, int64_t B, int64_t T, int64_t R, int64_t F, const float *kernel, const float *bias,
+                      int64_t taps, int64_t dil, int64_t H, int act, float *out, uds_stream_t stream) {
+  UDS_REQUIRE(x && kernel && out, "uds_conv1d_causal: NULL x/kernel/out");
+  UDS_REQUIRE(B >= 0 && T > 0 && R > 0 && F > 0 && taps > 0 && taps <= 16 && dil > 0 && H > 0 && H <= 256 && taps * F <= 4096,
+              "uds_conv1d_causal: bad sizes B=%lld T=%lld R=%lld F=%lld taps=%lld dil=%lld H=%lld", (long long)B, (long long)T,
+              (long long)R, (long long)F, (long long)taps, (long long)dil, (long long)H);
+  UDS_REQUIRE(act >= UDS_ACT_LINEAR && act <= UDS_ACT_HARD_SIGMOID, "uds_conv1d_causal: unknown activation %d", act);
+  UDS_REQUIRE(((H & 3) != 0 || aligned16(out)), "uds_conv1d_causal: out must be 16-byte aligned");
+  if (B == 0) return UDS_OK;
+  uds::DenseArgs a{x, nullptr, kernel, bias, nullptr, nullptr, out, nullptr, nullptr, (int)F, 0, (int)H, act, B * T * R};
+  a.taps = (int)taps;
+  a.dil = (int)dil;
+  a.T = (int)T;
+  a.t_rows = (int)R;
+  hipError_t e = uds::launch_dense_act(a, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_conv1d_causal: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
+int uds_cumsum_act(const float *x, const float *res, int64_t B, int64_t T, int64_t R, int64_t F, int act, float *out,
+                   uds_stream_t stream) {
+  UDS_REQUIRE(x && out, "uds_cumsum_act: NULL x/out");
+  UDS_REQUIRE(B >= 0 && T > 0 && R > 0 && F > 0 && F % 4 == 0, "uds_cumsum_act: bad sizes (F must be a multiple of 4)");
+  UDS_REQUIRE(aligned16(x) && aligned16(out) && aligned16(res), "uds_cumsum_act: x/res/out must be 16-byte aligned");
+  UDS_REQUIRE(act >= UDS_ACT_LINEAR && act <= UDS_ACT_HARD_SIGMOID, "uds_cumsum_act: unknown activation %d", act);
+  if (B == 0) return UDS_OK;
+  uds::CumsumArgs a{x, res, out, (int)B, (int)T, (int)R, (int)(F / 4), act};
+  hipError_t e = uds::launch_cumsum(a, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_cumsum_act: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
+int uds_flow_balance(const uds_csr_t *inc_n, const float *sign, const float *flow, int64_t S, const float *scale_in,
+                     const float *scale_out, float *q_in, float *q_out, uds_stream_t stream) {
+  UDS_REQUIRE(inc_n && sign && flow && scale_in && scale_out && q_in && q_out, "uds_flow_balance: NULL argument");
+  UDS_REQUIRE(S >= 0 && S <= 65535, "uds_flow_balance: S=%lld outside [0,65535]", (long long)S);
+  if (S == 0 || inc_n->n_rows == 0) return UDS_OK;
+  uds::FlowArgs a{inc_n->d_rowptr, inc_n->d_col, sign, flow, scale_in, scale_out, q_in, q_out, (int)inc_n->n_rows,
+                  (int)inc_n->n_cols, (int)S};
+  hipError_t e = uds::launch_flow_balance(a, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_flow_balance: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
 int uds_csr_spmm(const uds_csr_t *csr, const float *val, const float *x, int64_t S, int64_t F, const float *bias,
                  int act, float *out, uds_stream_t stream) {
   UDS_REQUIRE(csr && x && out, "uds_csr_spmm: NULL csr/x/out");

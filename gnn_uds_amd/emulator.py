@@ -1,0 +1,369 @@
+"""`Emulator`: the reference's surrogate model (`surrogate/emulator.py:47-852`) on the HIP engine.
+
+Same constructor (`Emulator(conv, resnet, recurrent, args)`, attributes read from `args` with the reference's
+names and defaults, emulator.py:48-127), same method names, positional order and tensor layouts
+(`(B,T,N,C)` / `(B,T,E,C)`), re-expressed as a `torch.nn.Module`:
+
+    forward / model          build_network                      emulator.py:166-341
+    predict, predict_tf      raw states -> de-normalised (B,T,N,5), (B,T,E,3)        :566-641
+    _model                   single chunk or `roll` autoregressive chunks            :400-438
+    simulate                 sliding-window evaluation of an event                   :521-564
+    post_proc_tf, constrain_tf, normalize, set_norm, get_edge_action, get_action     :364-398,680-810
+    save / load              weights + norm_*.npy                                    :814-852
+
+What runs where: every layer of the network (embedding / fusion / head Dense, NodeEdge, GAT or GCN, causal dilated
+Conv1D, the resnet prefix sum) and the link->node flow balance of post_proc_tf are HIP kernels behind the C ABI.
+The remaining post-processing is elementwise gating / clipping on tensors already in HBM and is written with torch
+tensor ops (device plumbing).  Not built: training (`fit_eval`), `graph_base` > 0, `use_adj`,
+GRU / LSTM, DiffusionConv / GeneralConv -- each raises.
+"""
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .graph import DrainageGraph, csr_from_dense
+from .layers import Dense, SpatialBlock, _glorot_uniform, _param
+
+
+class Conv1D(nn.Module):
+    """keras Conv1D(filters, kernel_size, padding='causal', dilation_rate, activation) along the time axis of
+    x (B, T, R, F) -- the reference transposes to (B*R, T, F) first (emulator.py:244), this layout needs no transpose."""
+
+    def __init__(self, filters, kernel_size, dilation_rate=1, activation=None, in_features=None, generator=None):
+        super().__init__()
+        self.filters, self.kernel_size, self.dilation_rate = int(filters), int(kernel_size), int(dilation_rate)
+        self.activation = activation or 'linear'
+        self.kernel = _param(_glorot_uniform((self.kernel_size, int(in_features), self.filters), 'cpu', generator))
+        self.bias = _param(torch.zeros(self.filters))
+
+    def forward(self, x):
+        return _lib.conv1d_causal(x.contiguous(), self.kernel, self.bias, self.dilation_rate, self.activation)
+
+
+class Emulator(nn.Module):
+    def __init__(self, conv=None, resnet=False, recurrent=None, args=None, precision='bf16x3', generator=None):
+        super().__init__()
+        g = lambda k, d=None: getattr(args, k, d)
+        self.n_node, self.n_in = g('state_shape', (40, 4))
+        self.tide = bool(g('tide', False))
+        self.b_in = 2 if self.tide else 1
+        act = g('act', False)
+        self.act = bool(act and act != 'False')
+        self.n_out = self.n_in - 1
+        self.seq_in, self.seq_out = g('seq_in', 6), g('seq_out', 1)
+        self.embed_size, self.hidden_dim = g('embed_size', 64), g('hidden_dim', 64)
+        self.kernel_size, self.n_sp_layer, self.n_tp_layer = g('kernel_size', 3), g('n_sp_layer', 3), g('n_tp_layer', 2)
+        self.dropout = g('dropout', 0.0)
+        self.activation = g('activation', 'relu')
+        self.if_flood = int(g('if_flood', 0))
+        if self.if_flood:
+            self.n_in += 1
+        self.epsilon = g('epsilon', -1.0)
+        self.graph_base = g('graph_base', 0)
+        self.edge_fusion = bool(g('edge_fusion', False))
+        self.edges = np.asarray(g('edges'))
+        self.n_edge, self.e_in = g('edge_state_shape', (40, 4))
+        self.e_out = self.e_in - 1
+        if self.edge_fusion:
+            self.n_out -= 2
+        self.use_adj = bool(g('use_adj', False)) if self.act else False
+        self.act_edges = np.asarray(g('act_edges', np.zeros((0, 2), dtype=int))) if self.act else None
+        self.roll = int(g('roll', 0))
+        self.model_dir = g('model_dir')
+        self.resnet = bool(resnet)
+        self.conv = False if conv in (None, 'None', 'False', 'NoneType', False) else conv
+        self.recurrent = recurrent
+        if not self.conv:
+            raise NotImplementedError('the HIP engine builds the graph-convolution emulator (conv=GAT/GCN); the dense MLP variant is not built')
+        if 'GAT' in self.conv:
+            self.conv_kind = 'GAT'
+        elif 'GCN' in self.conv:
+            self.conv_kind = 'GCN'
+        else:
+            raise NotImplementedError('conv=%r is not built (GAT and GCN are)' % (conv,))
+        if self.graph_base or self.use_adj:
+            raise NotImplementedError('graph_base > 0 and use_adj are not built')
+        if recurrent not in ('Conv1D', None, 'None', False):
+            raise NotImplementedError('recurrent=%r is not built (Conv1D is what every shipped model uses)' % (recurrent,))
+        if self.dropout:
+            raise NotImplementedError('dropout > 0 (training-time) is not built')
+
+        adj = np.asarray(g('adj', np.eye(self.n_node)))
+        edge_adj = np.asarray(g('edge_adj', np.eye(self.n_edge)))
+        node_edge = np.asarray(g('node_edge'), dtype=np.float64)
+        self.graph = DrainageGraph.from_dense(adj, edge_adj, node_edge, self.edges)
+        if self.conv_kind == 'GCN':
+            from .layers import GCNConv
+            self.filter, self.edge_filter = GCNConv.preprocess(adj), GCNConv.preprocess(edge_adj)     # emulator.py:133-134
+        else:
+            self.filter, self.edge_filter = (adj > 0).astype(int), (edge_adj > 0).astype(int)        # emulator.py:143-145
+
+        # per-node / per-link physical constants (emulator.py:71-98), kept as float32 buffers
+        vec = lambda k, n, d: torch.as_tensor(np.asarray(g(k, np.full(n, d)), dtype=np.float64), dtype=torch.float32)
+        for name, n, d in (('is_outfall', self.n_node, 0.0), ('area', self.n_node, 0.0), ('pump_in', self.n_node, 0.0),
+                           ('pump_out', self.n_node, 0.0), ('hmax', self.n_node, 1.5), ('hmin', self.n_node, 0.0),
+                           ('ehmax', self.n_edge, 0.5), ('pump', self.n_edge, 0.0), ('offset', self.n_edge, 0.0)):
+            self.register_buffer(name, vec(name, n, d), persistent=False)
+        self.register_buffer('node_edge', torch.as_tensor(node_edge, dtype=torch.float32), persistent=False)
+        self.register_buffer('_inc_sign', torch.as_tensor(self.graph.inc_n.val, dtype=torch.float32), persistent=False)
+        self._inc_handle = None
+        self._norms = {}
+
+        d, h, H, L, gen = self.embed_size, self.embed_size // 2, self.hidden_dim, self.n_sp_layer, generator
+        a = self.activation
+        self.embed_x = Dense(d, 'linear', in_features=self.n_in, generator=gen)                 # emulator.py:198
+        self.embed_b = Dense(h, a, in_features=self.b_in, generator=gen)                        # :203
+        self.embed_e = Dense(d, 'linear', in_features=self.e_in, generator=gen)                 # :206
+        self.embed_ae = Dense(h, a, in_features=1, generator=gen) if self.act else None         # :212
+        sp = self.n_node * self.n_edge > (1 << 24)
+        self.block1 = SpatialBlock(self.graph, d, L, a, sparse_params=sp, generator=gen, precision=precision,
+                                   conv=self.conv_kind, filters=(self.filter, self.edge_filter))                      # :219-235
+        tem = lambda f: nn.ModuleList([Conv1D(H, self.kernel_size, 2 ** i, a, in_features=(f if i == 0 else H), generator=gen)
+                                       for i in range(self.n_tp_layer)])
+        self.tem1_x, self.tem1_e = tem(d), tem(d)                                               # :247,254
+        fx2, fe2 = H + h, H + (h if self.act else 0)
+        self.block2 = SpatialBlock(self.graph, d, L, a, fx=fx2, fe=fe2, sparse_params=sp, generator=gen, precision=precision,
+                                   conv=self.conv_kind, filters=(self.filter, self.edge_filter))                      # :272-288
+        self.tem2_x, self.tem2_e = tem(d), tem(d)                                               # :302,308
+        self.res_x = Dense(d, 'linear' if self.resnet else a, in_features=H, generator=gen)     # :313 'dense_resx'
+        self.res_e = Dense(d, 'linear' if self.resnet else a, in_features=H, generator=gen)     # :317
+        self.out = Dense(self.n_out, 'hard_sigmoid', in_features=d, generator=gen)              # :324
+        fl, fi = [], d
+        for _ in range(self.if_flood):
+            fl.append(Dense(h, a, in_features=fi, generator=gen))                               # :329
+            fi = h
+        self.flood = nn.ModuleList(fl)
+        self.flood_out = Dense(1, 'sigmoid', in_features=fi, generator=gen) if self.if_flood else None      # :330
+        self.e_out_layer = Dense(self.e_out, 'tanh', in_features=d, generator=gen)              # :336
+
+    # ------------------------------------------------------------------ network forward (build_network)
+    def forward(self, X, B, E, AE=None):
+        nb = X.shape[0]
+        c = lambda t: t.contiguous()
+        # the embedding is linear, its last step is kept as the residual, then the activation is applied (:198-201):
+        # two launches of the same GEMM (same per-row arithmetic), one with and one without the activation
+        x_lin_last = _lib.dense_act(c(X[:, -1:]), self.embed_x.kernel, self.embed_x.bias, 'linear')
+        x = _lib.dense_act(c(X), self.embed_x.kernel, self.embed_x.bias, self.activation)
+        e_lin_last = _lib.dense_act(c(E[:, -1:]), self.embed_e.kernel, self.embed_e.bias, 'linear')
+        e = _lib.dense_act(c(E), self.embed_e.kernel, self.embed_e.bias, self.activation)
+        b = self.embed_b(c(B))
+        ae = self.embed_ae(c(AE)) if self.act else None
+
+        def spatial(block, x, e):
+            T = x.shape[1]
+            xs, es = block(x.reshape(nb * T, self.n_node, -1), e.reshape(nb * T, self.n_edge, -1))
+            return xs.reshape(nb, T, self.n_node, -1), es.reshape(nb, T, self.n_edge, -1)
+
+        x, e = spatial(self.block1, x, e)
+        for ly in self.tem1_x:
+            x = ly(x)
+        for ly in self.tem1_e:
+            e = ly(e)
+        x, e = x[:, -self.seq_out:], e[:, -self.seq_out:]             # :249,256
+        x = torch.cat([x, b], dim=-1)                                 # :260
+        if self.act:
+            e = torch.cat([e, ae], dim=-1)                            # :262
+        x, e = spatial(self.block2, c(x), c(e))
+        for ly in self.tem2_x:
+            x = ly(x)
+        for ly in self.tem2_e:
+            e = ly(e)
+        x, e = self.res_x(x), self.res_e(e)
+        if self.resnet:                                               # :315-320
+            x = _lib.cumsum_act(x, x_lin_last, self.activation)
+            e = _lib.cumsum_act(e, e_lin_last, self.activation)
+        out = self.out(x)
+        if self.if_flood:
+            f = x
+            for ly in self.flood:
+                f = ly(f)
+            out = torch.cat([out, self.flood_out(f)], dim=-1)         # :330-333
+        return out, self.e_out_layer(e)
+
+    model = forward
+
+    # ------------------------------------------------------------------ normalisation (:794-810)
+    def set_norm(self, norm_x, norm_b, norm_y, norm_r, norm_e):
+        for k, v in (('x', norm_x), ('b', norm_b), ('y', norm_y), ('r', norm_r), ('e', norm_e)):
+            if v is not None:
+                self._norms[k] = torch.as_tensor(np.asarray(v), dtype=torch.float32)
+
+    def _norm(self, item, device):
+        t = self._norms[item]
+        if t.device != device:
+            t = self._norms[item] = t.to(device)
+        return t
+
+    def normalize(self, dat, item, inverse=False):
+        normal = self._norm(item, dat.device)
+        dim = dat.shape[-1]
+        maxi, mini = normal[0, ..., :dim], normal[1, ..., :dim]
+        return dat * (maxi - mini) + mini if inverse else (dat - mini) / (maxi - mini)
+
+    # ------------------------------------------------------------------ actions (:364-398)
+    def _act_edge_index(self):
+        hits = [np.where((self.edges == ae).all(1))[0] for ae in self.act_edges]
+        flat = [int(i) for e in hits for i in e]
+        return sorted(set(flat), key=flat.index)
+
+    def get_edge_action(self, a, g=True):
+        out = np.zeros(self.n_edge, dtype=np.int64)
+        out[self._act_edge_index()] = np.arange(1, a.shape[-1] + 1)
+        table = torch.cat([torch.ones_like(a[..., :1]), a], dim=-1)
+        return table[..., torch.as_tensor(out, device=a.device)].unsqueeze(-1)
+
+    def get_action(self, a, g=True):
+        out_o, out_i = np.zeros(self.n_node, dtype=np.int64), np.zeros(self.n_node, dtype=np.int64)
+        out_o[self.act_edges[:, 0]] = np.arange(1, a.shape[-1] + 1)
+        out_i[self.act_edges[:, 1]] = np.arange(1, a.shape[-1] + 1)
+        table = torch.cat([torch.ones_like(a[..., :1]), a], dim=-1)
+        return table[..., torch.as_tensor(out_o, device=a.device)], table[..., torch.as_tensor(out_i, device=a.device)]
+
+    # ------------------------------------------------------------------ post-processing (:680-770)
+    def _flow_balance(self, flow):
+        """q_in, q_out (B,T,N,1) from de-normalised link flows (B,T,E,1): HIP kernel on the incidence CSR."""
+        if self._inc_handle is None:
+            self._inc_handle = _lib.CsrHandle(self.graph.inc_n)
+        ny = self._norm('y', flow.device)
+        s_out = (ny[0, :, 2] > 1e-3).float() / ny[0, :, 2]
+        s_in = (ny[0, :, 1] > 1e-3).float() / ny[0, :, 1]
+        lead = flow.shape[:-2]
+        q_in, q_out = _lib.flow_balance(self._inc_handle, self._inc_sign, flow.reshape(-1, self.n_edge).contiguous(),
+                                        s_in.contiguous(), s_out.contiguous())
+        return q_in.reshape(lead + (self.n_node, 1)), q_out.reshape(lead + (self.n_node, 1))
+
+    def post_proc_tf(self, preds, a, b):
+        preds, edge_preds = preds
+        pos = self.node_edge.clamp(0, 1)
+        if self.tide:
+            h = preds[..., 0] * (1 - self.is_outfall) + b[..., -1]
+            preds = torch.cat([h.unsqueeze(-1), preds[..., 1:]], dim=-1)
+        if float(self.offset.max()) > 0:
+            inoff = torch.matmul(self.normalize(preds, 'y', True)[..., 0] - self.hmin, pos)
+            flow, off = edge_preds[..., -1], self.offset
+            flow = (flow * (flow > 0).float() * (off > 0).float() * (inoff > off).float() + flow * (flow <= 0).float() * (off > 0).float() +
+                    flow * (off == 0).float()).unsqueeze(-1)
+            edge_preds = torch.cat([edge_preds[..., :-1], flow], dim=-1)
+        if self.act:
+            ne_ = self._norm('e', preds.device)
+            if float(self.pump.min()) > 0:
+                fl = self.pump * torch.matmul((preds[..., 0] > 0.01).float(), pos)
+                fl = fl * (ne_[0, :, 2] > 1e-3).float() / ne_[0, :, 2]
+                flow = (edge_preds[..., -1] * (fl == 0).float() + fl).unsqueeze(-1)
+            else:
+                flow = edge_preds[..., -1:]
+            edge_preds = torch.cat([edge_preds[..., :-1], flow * self.get_edge_action(a, True)], dim=-1)
+            if not self.edge_fusion:
+                ny = self._norm('y', preds.device)
+                a_out, a_in = self.get_action(a[:, :self.seq_out], True)
+                fli = self.pump_in * (preds[..., 0] > 0).float() / ny[0, :, 1]
+                flo = self.pump_out * (preds[..., 0] > 0).float() / ny[0, :, 2]
+                inflow = preds[..., 1] * (fli == 0).float() + fli
+                outflow = preds[..., 2] * (flo == 0).float() + flo
+                preds = torch.cat([torch.stack([preds[..., 0], inflow * a_in, outflow * a_out], dim=-1), preds[..., 3:]], dim=-1)
+        if self.edge_fusion:
+            flow = self.normalize(edge_preds, 'e', True)[..., -1:]
+            q_in, q_out = self._flow_balance(flow)
+            preds = torch.cat([preds[..., :1], q_in, q_out, preds[..., 1:]], dim=-1)
+        return preds, edge_preds
+
+    def constrain_tf(self, y, r, h0=None):
+        h, q_us, q_ds = y[..., 0], y[..., 1], y[..., 2]
+        r = r.squeeze(-1)
+        h = torch.minimum(torch.maximum(h, self.hmin), self.hmax)
+        q_w = (q_us + r - q_ds).clamp(min=0) * (1 - self.is_outfall)
+        if self.if_flood:
+            f = (y[..., -1] > 0.5).float()
+            h = self.hmax * f + h * (1 - f)
+            y = torch.stack([h, q_us, q_ds, y[..., -1]], dim=-1)
+        else:
+            y = torch.stack([h, q_us, q_ds], dim=-1)
+        if self.epsilon > 0:
+            q_w = q_w * ((self.hmax - h) < self.epsilon).float()
+        elif self.epsilon == 0:
+            pass
+        elif self.if_flood:
+            q_w = q_w * f
+        return q_w, y
+
+    # ------------------------------------------------------------------ inference entry points
+    def predict_tf(self, states, b, a=None, edge_state=None):
+        x = states[:, -self.seq_in:]
+        ex = edge_state[:, -self.seq_in:]
+        assert b.shape[1] == self.seq_out
+        ae = self.get_edge_action(a, True) if self.act else None
+        nb_ = self.normalize(b, 'b')
+        y, ey = self.forward(self.normalize(x, 'x'), nb_, self.normalize(ex, 'e'), ae)
+        y, ey = self.post_proc_tf((y, ey), a, nb_)
+        ey = self.normalize(ey, 'e', True)
+        ey = torch.cat([torch.minimum(ey[..., 0].clamp(min=0), self.ehmax).unsqueeze(-1), ey[..., 1:]], dim=-1)
+        y = self.normalize(y, 'y', True)
+        if float(self.pump_in.sum() + self.pump_out.sum() + self.pump.sum()) > 0:       # pumped-storage depth (:630-638)
+            ps = ((self.area * torch.mv(self.node_edge.clamp(0, 1), self.pump)) > 0).float()
+            h, qin, qout = y[..., 0], y[..., 1], y[..., 2]
+            de = []
+            for t in range(self.seq_out):
+                prev = x[:, -1, :, 0] if t == 0 else de[-1] + (qin - qout)[:, t] / (self.area + 1e-6)
+                de.append(torch.minimum(torch.maximum(prev, self.hmin), self.hmax))
+            y = torch.cat([(h * (1 - ps) + torch.stack(de, dim=1) * ps).unsqueeze(-1), y[..., 1:]], dim=-1)
+        q_w, y = self.constrain_tf(y, b[..., :1], x[:, -1:, :, 0])
+        return torch.cat([y, q_w.unsqueeze(-1)], dim=-1), ey
+
+    predict = predict_tf      # the reference's NumPy twin (`predict`, :566-602) differs only in host round trips
+
+    def _model(self, x, a, b, ex, ae=None, adj=None, fit=False):
+        """emulator.py:400-438 on normalised tensors; `roll` > 0 = autoregressive chunks of seq_out steps."""
+        if fit:
+            raise NotImplementedError('training (fit_eval, SURVEY.md a10) is not built')
+        if self.roll:
+            ys, eys = [], []
+            for i in range(self.roll):
+                sl = slice(i * self.seq_out, (i + 1) * self.seq_out)
+                ae_i = self.get_edge_action(a[:, sl], True) if self.act else None
+                y, ey = self.forward(x[:, -self.seq_in:], b[:, sl], ex[:, -self.seq_in:], ae_i)
+                y, ey = self.post_proc_tf((y, ey), a[:, sl] if a is not None else None, b[:, sl])
+                ys.append(y)
+                eys.append(ey)
+                if self.if_flood:                                   # flood bit fed back as a hard 0/1 (:417)
+                    x_new = torch.cat([y[..., :-1], (y[..., -1:] > 0.5).float(), b[:, sl]], dim=-1)
+                else:
+                    x_new = torch.cat([y, b[:, sl]], dim=-1)
+                keep = self.seq_in - self.seq_out
+                x = torch.cat([x[:, -keep:], x_new], dim=1) if keep > 0 else x_new
+                ae_new = ae_i if self.act else torch.ones(ey.shape[:-1] + (1,), device=ey.device)
+                ex_new = torch.cat([ey, ae_new], dim=-1)
+                ex = torch.cat([ex[:, -keep:], ex_new], dim=1) if keep > 0 else ex_new
+            preds, edge_preds = torch.cat(ys, dim=1), torch.cat(eys, dim=1)
+        else:
+            if ae is None and self.act:
+                ae = self.get_edge_action(a, True)
+            preds, edge_preds = self.post_proc_tf(self.forward(x, b, ex, ae), a, b)
+        return preds.clamp(0, 1), edge_preds                          # :437
+
+    def simulate(self, states, runoff, a=None, edge_states=None):
+        """emulator.py:521-564, with every sliding window of the event batched into ONE forward (the reference loops
+        over time steps with a host round trip each).  states (n,T_in,N,C), runoff (n,T_out,N,b_in) -> (n,T_out,N,5), (n,T_out,E,3)."""
+        runoff = runoff[:, :self.seq_out]
+        return self.predict_tf(states, runoff, a, edge_states)
+
+    def fit_eval(self, *args, **kwargs):
+        raise NotImplementedError('training (fit_eval, emulator.py:457-484; SURVEY.md a10) is not built: forward engine only')
+
+    # ------------------------------------------------------------------ checkpoints (:814-852)
+    def save(self, model_dir=None):
+        model_dir = model_dir if model_dir is not None else self.model_dir
+        os.makedirs(model_dir, exist_ok=True)
+        torch.save(self.state_dict(), os.path.join(model_dir, 'model.pt'))
+        for item, t in self._norms.items():
+            np.save(os.path.join(model_dir, 'norm_%s.npy' % item), t.cpu().numpy())
+
+    def load(self, model_dir=None, retrain=False):
+        model_dir = model_dir if model_dir is not None else self.model_dir
+        self.load_state_dict(torch.load(os.path.join(model_dir, 'model.pt'), weights_only=True))
+        for item in 'xbyre':
+            path = os.path.join(model_dir, 'norm_%s.npy' % item)
+            if os.path.exists(path):
+                self._norms[item] = torch.as_tensor(np.load(path), dtype=torch.float32)

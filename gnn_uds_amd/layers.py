@@ -268,8 +268,13 @@ class SpatialLayer(nn.Module):
     entry uds_spatial_layer_forward (concats are never materialised)."""
 
     def __init__(self, graph, embed_size, activation='relu', fx=None, fe=None, sparse_params=None, net=None,
-                 generator=None, precision='bf16x3'):
+                 generator=None, precision='bf16x3', conv='GAT', filters=None):
         super().__init__()
+        if conv not in ('GAT', 'GCN'):
+            raise NotImplementedError('conv=%r: GAT and GCN are built' % (conv,))
+        if conv == 'GCN' and filters is None:
+            raise ValueError("conv='GCN' needs filters=(GCNConv.preprocess(adj), GCNConv.preprocess(edge_adj))")
+        self.conv, self.filters = conv, filters
         if precision not in _lib.PRECISION_FLAGS:
             raise ValueError("precision must be 'bf16x3' (fused kernel, split-bf16 MFMA, fp32 accumulate) or 'fp32' "
                              "(exact-fp32 unfused kernels), got %r" % (precision,))
@@ -290,8 +295,12 @@ class SpatialLayer(nn.Module):
         abs_e = CSR(graph.inc_e.rowptr, graph.inc_e.col, graph.n_edge, graph.n_node, np.abs(graph.inc_e.val))
         self.node_edge_n = NodeEdge(abs_n, sparse=sparse_params, generator=g)           # emulator.py:227
         self.node_edge_e = NodeEdge(abs_e, sparse=sparse_params, generator=g)           # emulator.py:228
-        self.gat_x = GATConv(self.d, activation=activation, in_channels=fx + self.h, generator=g)   # :229
-        self.gat_e = GATConv(self.d, activation=activation, in_channels=fe + self.h, generator=g)   # :230
+        if conv == 'GAT':
+            self.gat_x = GATConv(self.d, activation=activation, in_channels=fx + self.h, generator=g)   # :229
+            self.gat_e = GATConv(self.d, activation=activation, in_channels=fe + self.h, generator=g)   # :230
+        else:
+            self.gcn_x = GCNConv(self.d, activation=activation, in_channels=fx + self.h, generator=g)
+            self.gcn_e = GCNConv(self.d, activation=activation, in_channels=fe + self.h, generator=g)
         self._net = net
         self._packed = None       # (parameter versions, packed bf16 hi/lo fragments) of the four GEMM kernels
 
@@ -311,6 +320,8 @@ class SpatialLayer(nn.Module):
         """Parameters as CPU tensors under the key names of uds_spatial_params_t (NodeEdge as
         'ne_*_w'/'ne_*_b' when dense, 'ne_*_v' support values when sparse)."""
         c = lambda t: None if t is None else t.detach().cpu().clone()
+        if self.conv != 'GAT':
+            raise NotImplementedError('export_params covers the GAT layer')
         p = dict(xe_k=c(self.dense_xe.kernel), xe_b=c(self.dense_xe.bias), ex_k=c(self.dense_ex.kernel),
                  ex_b=c(self.dense_ex.bias),
                  gx_k=c(self.gat_x.kernel), gx_as=c(self.gat_x.attn_kernel_self), gx_an=c(self.gat_x.attn_kernel_neighs),
@@ -327,6 +338,11 @@ class SpatialLayer(nn.Module):
     def forward(self, x, e):
         xs, lead_x = _flatten_snapshots(x)
         es, lead_e = _flatten_snapshots(e)
+        if self.conv == 'GCN':     # a_hat @ ([x | agg] W) + b: unfused composition of the Dense / NodeEdge / spmm kernels
+            x_e, e_x = self.dense_xe(es), self.dense_ex(xs)
+            ox = self.gcn_x([torch.cat([xs, self.node_edge_n(x_e)], dim=-1), self.filters[0]])
+            oe = self.gcn_e([torch.cat([es, self.node_edge_e(e_x)], dim=-1), self.filters[1]])
+            return ox.reshape(lead_x + ox.shape[-2:]), oe.reshape(lead_e + oe.shape[-2:])
         vn, rest_n = self.node_edge_n.support_values()
         ve, rest_e = self.node_edge_e.support_values()
         if rest_n is None and rest_e is None:
@@ -353,17 +369,17 @@ class SpatialBlock(nn.Module):
     """`for _ in range(n_sp_layer)` (`emulator.py:219-235`): first layer takes (fx, fe) features."""
 
     def __init__(self, graph, embed_size, n_sp_layer, activation='relu', fx=None, fe=None, sparse_params=None,
-                 generator=None, precision='bf16x3'):
+                 generator=None, precision='bf16x3', conv='GAT', filters=None):
         super().__init__()
         layers = []
         for i in range(n_sp_layer):
             layers.append(SpatialLayer(graph, embed_size, activation, fx if i == 0 else None, fe if i == 0 else None,
-                                       sparse_params, generator=generator, precision=precision))
+                                       sparse_params, generator=generator, precision=precision, conv=conv, filters=filters))
         self.layers = nn.ModuleList(layers)
         self.graph = graph
 
     def forward(self, x, e):
-        net = self.layers[0].network()
+        net = self.layers[0].network() if self.layers[0].conv == 'GAT' else None
         for layer in self.layers:
             layer._net = net
             x, e = layer(x, e)

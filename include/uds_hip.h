@@ -85,6 +85,25 @@ int uds_dense_act(const float *xa, int64_t fa, const float *xb, int64_t fb, int6
 int uds_csr_spmm(const uds_csr_t *csr, const float *val, const float *x, int64_t S, int64_t F,
                  const float *bias, int act, float *out, uds_stream_t stream);
 
+/* keras Conv1D(H, taps, padding='causal', dilation_rate=dil, activation) along T on x laid out (B, T, R, F) with no
+ * transposes: out[b,t,r,:] = act(sum_j x[b, t-(taps-1-j)*dil, r, :] @ kernel[j] + bias), zero before t = 0.
+ * kernel is (taps, F, H) row-major (the Keras layout); out is (B, T, R, H).   emulator.py:155-157,244-257,299-310 */
+int uds_conv1d_causal(const float *x, int64_t B, int64_t T, int64_t R, int64_t F, const float *kernel,
+                      const float *bias, int64_t taps, int64_t dil, int64_t H, int act, float *out,
+                      uds_stream_t stream);
+
+/* out[b,t,r,:] = act(cumsum_t(x)[b,t,r,:] + res[b,0,r,:]); x, out (B,T,R,F), res (B,1,R,F) or NULL; F % 4 == 0.
+ * The resnet head of the emulator.                                          emulator.py:313-320 */
+int uds_cumsum_act(const float *x, const float *res, int64_t B, int64_t T, int64_t R, int64_t F, int act,
+                   float *out, uds_stream_t stream);
+
+/* Link -> node flow balance of post_proc_tf: inc_n is the (N x E) incidence support, sign (nnz) its +1 / -1 values,
+ * flow (S,E) the signed link flows; q_in, q_out (S,N) are scaled per node by scale_in / scale_out (N).
+ * q_out = inc+ @ max(f,0) + inc- @ max(-f,0),  q_in = inc- @ max(f,0) + inc+ @ max(-f,0).   emulator.py:717-724 */
+int uds_flow_balance(const uds_csr_t *inc_n, const float *sign, const float *flow, int64_t S,
+                     const float *scale_in, const float *scale_out, float *q_in, float *q_out,
+                     uds_stream_t stream);
+
 /* Floats of workspace uds_gat_forward needs: S * n * (d + 2). */
 int64_t uds_gat_workspace_floats(int64_t n, int64_t S, int64_t d);
 

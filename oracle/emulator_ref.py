@@ -1,0 +1,370 @@
+"""CPU oracle of the whole surrogate forward, post-processing and rollout (TEST INFRASTRUCTURE ONLY;
+PARITY UNPINNED, see oracle/__init__.py).
+
+Restates, on torch CPU tensors (fp64 or fp32), `surrogate/emulator.py` of the reference:
+  forward            build_network, conv = GAT / GCN, recurrent = Conv1D      emulator.py:166-341
+  normalize          min-max (de)normalisation                                 emulator.py:803-810
+  get_edge_action / get_action   action -> per-link / per-node gates           emulator.py:364-398
+  post_proc          post_proc_tf                                              emulator.py:680-725
+  constrain          constrain_tf                                              emulator.py:750-770
+  predict            predict_tf                                                emulator.py:604-641
+  model_rollout      _model with roll > 0 (curriculum / autoregressive chunks) emulator.py:400-438
+
+`args` is any object with the reference's attribute names (`state_shape`, `edge_state_shape`, `seq_in`,
+`embed_size`, `adj`, `edge_adj`, `node_edge`, ... -- `Emulator.__init__`, emulator.py:48-127); `params`
+is the dict made by `init_params` (Keras creation order and initialisers).
+Not restated (the reference's shipped models never use them): graph_base > 0, use_adj, GRU/LSTM,
+DiffusionConv / GeneralConv, the non-conv MLP variant.
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import spektral_dense as OD
+
+
+def config(args):
+    """Derived sizes, exactly as `Emulator.__init__` computes them (emulator.py:49-108)."""
+    g = lambda k, d=None: getattr(args, k, d)
+    c = SimpleNamespace()
+    c.n_node, n_in0 = g('state_shape', (40, 4))
+    c.tide = bool(g('tide', False))
+    c.b_in = 2 if c.tide else 1
+    act = g('act', False)
+    c.act = bool(act and act != 'False')
+    c.n_out = n_in0 - 1
+    c.seq_in, c.seq_out = g('seq_in', 6), g('seq_out', 1)
+    c.d, c.H = g('embed_size', 64), g('hidden_dim', 64)
+    c.k, c.L, c.n_tp = g('kernel_size', 3), g('n_sp_layer', 3), g('n_tp_layer', 2)
+    c.activation = g('activation', 'relu')
+    c.if_flood = int(g('if_flood', 0))
+    c.n_in = n_in0 + (1 if c.if_flood else 0)
+    c.is_outfall = np.asarray(g('is_outfall', np.zeros(c.n_node)), dtype=np.float64)
+    c.epsilon = g('epsilon', -1.0)
+    c.edge_fusion = bool(g('edge_fusion', False))
+    c.edges = np.asarray(g('edges'))
+    c.n_edge, c.e_in = g('edge_state_shape', (40, 4))
+    c.e_out = c.e_in - 1
+    c.ehmax = np.asarray(g('ehmax', np.full(c.n_edge, 0.5)), dtype=np.float64)
+    c.pump = np.asarray(g('pump', np.zeros(c.n_edge)), dtype=np.float64)
+    c.node_edge = np.asarray(g('node_edge'), dtype=np.float64)
+    if c.edge_fusion:
+        c.n_out -= 2
+    c.adj = np.asarray(g('adj', np.eye(c.n_node)))
+    c.edge_adj = np.asarray(g('edge_adj', np.eye(c.n_edge)))
+    c.act_edges = np.asarray(g('act_edges', np.zeros((0, 2), dtype=int))) if c.act else None
+    c.area = np.asarray(g('area', np.zeros(c.n_node)), dtype=np.float64)
+    c.pump_in = np.asarray(g('pump_in', np.zeros(c.n_node)), dtype=np.float64)
+    c.pump_out = np.asarray(g('pump_out', np.zeros(c.n_node)), dtype=np.float64)
+    c.offset = np.asarray(g('offset', np.zeros(c.n_edge)), dtype=np.float64)
+    c.hmax = np.asarray(g('hmax', np.full(c.n_node, 1.5)), dtype=np.float64)
+    c.hmin = np.asarray(g('hmin', np.zeros(c.n_node)), dtype=np.float64)
+    conv = g('conv', 'GAT')
+    c.conv = 'GCN' if 'GCN' in conv else 'GAT'
+    c.resnet = bool(g('resnet', False))
+    c.roll = int(g('roll', 0))
+    if c.conv == 'GAT':                                   # emulator.py:143-145
+        c.filter = (c.adj > 0).astype(np.float64)
+        c.edge_filter = (c.edge_adj > 0).astype(np.float64)
+    else:                                                 # emulator.py:133-134
+        c.filter = OD.gcn_preprocess(torch.from_numpy(c.adj.astype(np.float64))).numpy()
+        c.edge_filter = OD.gcn_preprocess(torch.from_numpy(c.edge_adj.astype(np.float64))).numpy()
+    return c
+
+
+def _glorot(gen, shape):
+    if len(shape) == 1:
+        fan_in = fan_out = shape[0]
+    elif len(shape) == 2:
+        fan_in, fan_out = shape
+    else:
+        rf = int(np.prod(shape[:-2]))
+        fan_in, fan_out = shape[-2] * rf, shape[-1] * rf
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return (torch.rand(shape, generator=gen, dtype=torch.float64) * 2 - 1) * lim
+
+
+def init_params(args, seed=1, bias_scale=0.05):
+    """Parameters in Keras creation order.  Kernels glorot_uniform, NodeEdge weights
+    N(0, 0.05^2); biases get small random values instead of Keras' zeros so the tests exercise them."""
+    c = config(args)
+    g = torch.Generator().manual_seed(seed)
+    d, h, H = c.d, c.d // 2, c.H
+    bias = lambda n: torch.randn(n, generator=g, dtype=torch.float64) * bias_scale
+    dense = lambda fi, fo: {'kernel': _glorot(g, (fi, fo)), 'bias': bias(fo)}
+
+    def spatial(fx, fe):
+        conv = lambda f: {'kernel': _glorot(g, (f, 1, d)), 'attn_kernel_self': _glorot(g, (d, 1, 1)),
+                          'attn_kernel_neighs': _glorot(g, (d, 1, 1)), 'bias': bias(d)}
+        return {'dense_xe': dense(fe, h), 'dense_ex': dense(fx, h),
+                'node_edge_n': {'weight': torch.randn(c.n_node, c.n_edge, generator=g, dtype=torch.float64) * 0.05,
+                                'bias': torch.zeros(c.n_node, c.n_edge, dtype=torch.float64)},
+                'node_edge_e': {'weight': torch.randn(c.n_edge, c.n_node, generator=g, dtype=torch.float64) * 0.05,
+                                'bias': torch.zeros(c.n_edge, c.n_node, dtype=torch.float64)},
+                'gat_x': conv(fx + h), 'gat_e': conv(fe + h)}
+
+    def temporal(f):
+        out, fi = [], f
+        for _ in range(c.n_tp):
+            out.append({'kernel': _glorot(g, (c.k, fi, H)), 'bias': bias(H)})
+            fi = H
+        return out
+
+    p = {'embed_x': dense(c.n_in, d), 'embed_b': dense(c.b_in, h), 'embed_e': dense(c.e_in, d)}
+    if c.act:
+        p['embed_ae'] = dense(1, h)
+    p['block1'] = [spatial(d, d) for _ in range(c.L)]
+    p['tem1_x'], p['tem1_e'] = temporal(d), temporal(d)
+    fx2, fe2 = H + h, H + (h if c.act else 0)
+    p['block2'] = [spatial(fx2 if i == 0 else d, fe2 if i == 0 else d) for i in range(c.L)]
+    p['tem2_x'], p['tem2_e'] = temporal(d), temporal(d)
+    p['res_x'], p['res_e'] = dense(H, d), dense(H, d)
+    p['out'] = dense(d, c.n_out)
+    p['flood'] = []
+    fi = d
+    for _ in range(c.if_flood):
+        p['flood'].append(dense(fi, h))
+        fi = h
+    if c.if_flood:
+        p['flood_out'] = dense(fi, 1)
+    p['e_out'] = dense(d, c.e_out)
+    return p
+
+
+def cast_params(p, dtype):
+    if isinstance(p, dict):
+        return {k: cast_params(v, dtype) for k, v in p.items()}
+    if isinstance(p, list):
+        return [cast_params(v, dtype) for v in p]
+    return p.to(dtype)
+
+
+def conv1d_causal(x, kernel, bias, dilation, act):
+    """keras Conv1D(padding='causal', dilation_rate): x (M,T,F), kernel (k,F,H) -- emulator.py:155-157."""
+    k = kernel.shape[0]
+    T = x.shape[1]
+    out = torch.zeros(x.shape[0], T, kernel.shape[2], dtype=x.dtype)
+    for j in range(k):
+        shift = (k - 1 - j) * dilation
+        if shift < T:
+            out[:, shift:] += x[:, :T - shift] @ kernel[j]
+    return OD.activation(act)(out + bias)
+
+
+def _spatial_layer(x, e, p, c, dtype):
+    q = {'xe_k': p['dense_xe']['kernel'], 'xe_b': p['dense_xe']['bias'], 'ex_k': p['dense_ex']['kernel'],
+         'ex_b': p['dense_ex']['bias'], 'ne_n_w': p['node_edge_n']['weight'], 'ne_n_b': p['node_edge_n']['bias'],
+         'ne_e_w': p['node_edge_e']['weight'], 'ne_e_b': p['node_edge_e']['bias'],
+         'gx_k': p['gat_x']['kernel'], 'gx_as': p['gat_x']['attn_kernel_self'], 'gx_an': p['gat_x']['attn_kernel_neighs'],
+         'gx_b': p['gat_x']['bias'], 'ge_k': p['gat_e']['kernel'], 'ge_as': p['gat_e']['attn_kernel_self'],
+         'ge_an': p['gat_e']['attn_kernel_neighs'], 'ge_b': p['gat_e']['bias']}
+    return OD.spatial_layer_dense(x, e, q, torch.from_numpy(c.filter).to(dtype), torch.from_numpy(c.edge_filter).to(dtype),
+                                  torch.from_numpy(c.node_edge).to(dtype), c.activation, c.conv)
+
+
+def forward(args, params, X, B, E, AE=None):
+    """`Emulator.build_network` as a function: X (B,T_in,N,n_in), B (B,T_out,N,b_in), E (B,T_in,E,e_in),
+    AE (B,T_out,E,1) when act -> out (B,T_out,N,n_out[+1]), e_out (B,T_out,E,e_out).  emulator.py:195-338."""
+    c = config(args)
+    dt = X.dtype
+    act = OD.activation(c.activation)
+    D = lambda t, p, a='linear': OD.dense(t, p['kernel'], p['bias'], a)
+    x = D(X, params['embed_x'])                                   # :198
+    res = x[:, -1:]                                               # :200
+    x = act(x)
+    b = D(B, params['embed_b'], c.activation)                     # :203
+    e = D(E, params['embed_e'])                                   # :206
+    res_e = e[:, -1:]
+    e = act(e)
+    ae = D(AE, params['embed_ae'], c.activation) if c.act else None      # :212
+    nb = X.shape[0]
+
+    def spatial(x, e, layers):                                    # :217-235 / :265-288
+        T = x.shape[1]
+        xs, es = x.reshape((-1,) + tuple(x.shape[2:])), e.reshape((-1,) + tuple(e.shape[2:]))
+        for p in layers:
+            xs, es = _spatial_layer(xs, es, p, c, dt)
+        return xs.reshape(nb, T, c.n_node, -1), es.reshape(nb, T, c.n_edge, -1)
+
+    def temporal(x, layers, n):                                   # :244-257 / :299-310
+        T = x.shape[1]
+        y = x.permute(0, 2, 1, 3).reshape(-1, T, x.shape[-1])
+        for i, p in enumerate(layers):
+            y = conv1d_causal(y, p['kernel'], p['bias'], 2 ** i, c.activation)
+        return y.reshape(nb, n, T, -1).permute(0, 2, 1, 3)
+
+    x, e = spatial(x, e, params['block1'])
+    x = temporal(x, params['tem1_x'], c.n_node)[:, -c.seq_out:]   # :249
+    e = temporal(e, params['tem1_e'], c.n_edge)[:, -c.seq_out:]
+    x = torch.cat([x, b], dim=-1)                                 # :260
+    if c.act:
+        e = torch.cat([e, ae], dim=-1)                            # :262
+    x, e = spatial(x, e, params['block2'])
+    x = temporal(x, params['tem2_x'], c.n_node)
+    e = temporal(e, params['tem2_e'], c.n_edge)
+    x_out = D(x, params['res_x'])                                 # :313
+    x = act(torch.cumsum(x_out, dim=1) + res) if c.resnet else act(x_out)   # :315-316
+    e_o = D(e, params['res_e'])
+    e = act(torch.cumsum(e_o, dim=1) + res_e) if c.resnet else act(e_o)     # :319-320
+    out = D(x, params['out'], 'hard_sigmoid')                     # :324
+    if c.if_flood:
+        f = x
+        for p in params['flood']:
+            f = D(f, p, c.activation)                             # :329
+        out = torch.cat([out, D(f, params['flood_out'], 'sigmoid')], dim=-1)    # :330-333
+    return out, D(e, params['e_out'], 'tanh')                     # :336
+
+
+def normalize(norms, dat, item, inverse=False):
+    """emulator.py:803-810; norms[item] is (2, n, C) = [max, min]."""
+    normal = norms[item]
+    dim = dat.shape[-1]
+    maxi, mini = normal[0, ..., :dim], normal[1, ..., :dim]
+    return dat * (maxi - mini) + mini if inverse else (dat - mini) / (maxi - mini)
+
+
+def _act_edge_index(c):
+    hits = [np.where((c.edges == ae).all(1))[0] for ae in c.act_edges]     # emulator.py:386-388
+    flat = [int(i) for e in hits for i in e]
+    return sorted(set(flat), key=flat.index)
+
+
+def get_edge_action(c, a):
+    """emulator.py:385-392 (tensor branch): 1 on free links, the setting on actuated ones -> (B,T,E,1)."""
+    out = np.zeros(c.n_edge, dtype=np.int64)
+    idx = _act_edge_index(c)
+    out[idx] = np.arange(1, a.shape[-1] + 1)
+    table = torch.cat([torch.ones_like(a[..., :1]), a], dim=-1)
+    return table[..., torch.from_numpy(out)].unsqueeze(-1)
+
+
+def get_action(c, a):
+    """emulator.py:364-371 (tensor branch): per-node outflow / inflow gates."""
+    out_o, out_i = np.zeros(c.n_node, dtype=np.int64), np.zeros(c.n_node, dtype=np.int64)
+    out_o[c.act_edges[:, 0]] = np.arange(1, a.shape[-1] + 1)
+    out_i[c.act_edges[:, 1]] = np.arange(1, a.shape[-1] + 1)
+    table = torch.cat([torch.ones_like(a[..., :1]), a], dim=-1)
+    return table[..., torch.from_numpy(out_o)], table[..., torch.from_numpy(out_i)]
+
+
+def post_proc(args, norms, preds, edge_preds, a, b):
+    """`post_proc_tf` (emulator.py:680-725): tide, offset gate, pump rating, action gates, link->node flow balance."""
+    c = config(args)
+    dt = preds.dtype
+    T = lambda v: torch.as_tensor(v, dtype=dt)
+    ne = T(c.node_edge)
+    pos = ne.clamp(0, 1)
+    if c.tide:                                                    # :684-686
+        h = preds[..., 0] * (1 - T(c.is_outfall)) + b[..., -1]
+        preds = torch.cat([h.unsqueeze(-1), preds[..., 1:]], dim=-1)
+    if c.offset.max() > 0:                                        # :688-694
+        inoff = (normalize(norms, preds, 'y', True)[..., 0] - T(c.hmin)) @ pos
+        flow = edge_preds[..., -1]
+        off = T(c.offset)
+        flow = (flow * (flow > 0).to(dt) * (off > 0).to(dt) * (inoff > off).to(dt) + flow * (flow <= 0).to(dt) * (off > 0).to(dt) +
+                flow * (off == 0).to(dt)).unsqueeze(-1)
+        edge_preds = torch.cat([edge_preds[..., :-1], flow], dim=-1)
+    if c.act:                                                     # :696-715
+        if c.pump.min() > 0:
+            fl = T(c.pump) * ((preds[..., 0] > 0.01).to(dt) @ pos)
+            fl = fl * (norms['e'][0, :, 2] > 1e-3).to(dt) / norms['e'][0, :, 2]
+            flow = (edge_preds[..., -1] * (fl == 0).to(dt) + fl).unsqueeze(-1)
+        else:
+            flow = edge_preds[..., -1:]
+        ae = get_edge_action(c, a)
+        edge_preds = torch.cat([edge_preds[..., :-1], flow * ae], dim=-1)
+        if not c.edge_fusion:
+            a_out, a_in = get_action(c, a[:, :c.seq_out])
+            fli = T(c.pump_in) * (preds[..., 0] > 0).to(dt) / norms['y'][0, :, 1]
+            flo = T(c.pump_out) * (preds[..., 0] > 0).to(dt) / norms['y'][0, :, 2]
+            inflow = preds[..., 1] * (fli == 0).to(dt) + fli
+            outflow = preds[..., 2] * (flo == 0).to(dt) + flo
+            preds = torch.cat([torch.stack([preds[..., 0], inflow * a_in, outflow * a_out], dim=-1), preds[..., 3:]], dim=-1)
+    if c.edge_fusion:                                             # :718-724
+        flow = normalize(norms, edge_preds, 'e', True)[..., -1:]
+        neg = ne.clamp(-1, 0).abs()
+        fp, fn = flow.clamp(min=0), -flow.clamp(max=0)
+        node_out = pos @ fp + neg @ fn
+        node_in = neg @ fp + pos @ fn
+        ny = norms['y']
+        node_out = node_out * (ny[0, :, 2:3] > 1e-3).to(dt) / ny[0, :, 2:3]
+        node_in = node_in * (ny[0, :, 1:2] > 1e-3).to(dt) / ny[0, :, 1:2]
+        preds = torch.cat([preds[..., :1], node_in, node_out, preds[..., 1:]], dim=-1)
+    return preds, edge_preds
+
+
+def constrain(args, y, r):
+    """`constrain_tf` (emulator.py:750-770): depth clip, flooding volume, flood gating."""
+    c = config(args)
+    dt = y.dtype
+    T = lambda v: torch.as_tensor(v, dtype=dt)
+    h, q_us, q_ds = y[..., 0], y[..., 1], y[..., 2]
+    r = r.squeeze(-1)
+    h = torch.minimum(torch.maximum(h, T(c.hmin)), T(c.hmax))
+    q_w = (q_us + r - q_ds).clamp(min=0) * (1 - T(c.is_outfall))
+    if c.if_flood:
+        f = (y[..., -1] > 0.5).to(dt)
+        h = T(c.hmax) * f + h * (1 - f)
+        y = torch.stack([h, q_us, q_ds, y[..., -1]], dim=-1)
+    else:
+        y = torch.stack([h, q_us, q_ds], dim=-1)
+    if c.epsilon > 0:
+        q_w = q_w * ((T(c.hmax) - h) < c.epsilon).to(dt)
+    elif c.epsilon == 0:
+        pass
+    elif c.if_flood:
+        q_w = q_w * f
+    return q_w, y
+
+
+def predict(args, params, norms, states, b, a=None, edge_state=None):
+    """`predict_tf` (emulator.py:604-641): raw states in, de-normalised (B,T,N,5) / (B,T,E,3) out."""
+    c = config(args)
+    dt = states.dtype
+    T = lambda v: torch.as_tensor(v, dtype=dt)
+    x = states[:, -c.seq_in:]
+    ex = edge_state[:, -c.seq_in:]
+    assert b.shape[1] == c.seq_out
+    ae = get_edge_action(c, a) if c.act else None
+    y, ey = forward(args, params, normalize(norms, x, 'x'), normalize(norms, b, 'b'), normalize(norms, ex, 'e'), ae)
+    y, ey = post_proc(args, norms, y, ey, a, normalize(norms, b, 'b'))
+    ey = normalize(norms, ey, 'e', True)
+    ey = torch.cat([torch.minimum(ey[..., 0].clamp(min=0), T(c.ehmax)).unsqueeze(-1), ey[..., 1:]], dim=-1)   # :626
+    y = normalize(norms, y, 'y', True)
+    if c.pump_in.sum() + c.pump_out.sum() + c.pump.sum() > 0:     # :630-638
+        ps = ((T(c.area) * (T(c.node_edge).clamp(0, 1) @ T(c.pump))) > 0).to(dt)
+        h, qin, qout = y[..., 0], y[..., 1], y[..., 2]
+        de = []
+        for t in range(c.seq_out):
+            prev = x[:, -1, :, 0] if t == 0 else de[-1] + (qin - qout)[:, t] / (T(c.area) + 1e-6)
+            de.append(torch.minimum(torch.maximum(prev, T(c.hmin)), T(c.hmax)))
+        de = torch.stack(de, dim=1)
+        y = torch.cat([(h * (1 - ps) + de * ps).unsqueeze(-1), y[..., 1:]], dim=-1)
+    q_w, y = constrain(args, y, b[..., :1])
+    return torch.cat([y, q_w.unsqueeze(-1)], dim=-1), ey
+
+
+def model_rollout(args, params, norms, x, a, b, ex):
+    """`_model` with roll > 0 (emulator.py:401-425) on NORMALISED tensors: `roll` chunks of seq_out steps, each fed
+    with the previous chunk's (post-processed) prediction; the flood bit is thresholded at 0.5."""
+    c = config(args)
+    dt = x.dtype
+    ys, eys = [], []
+    for i in range(c.roll):
+        sl = slice(i * c.seq_out, (i + 1) * c.seq_out)
+        ae = get_edge_action(c, a[:, sl]) if c.act else None
+        y, ey = forward(args, params, x[:, -c.seq_in:], b[:, sl], ex[:, -c.seq_in:], ae)
+        y, ey = post_proc(args, norms, y, ey, a[:, sl] if a is not None else None, b[:, sl])
+        ys.append(y)
+        eys.append(ey)
+        if c.if_flood:
+            x_new = torch.cat([y[..., :-1], (y[..., -1:] > 0.5).to(dt), b[:, sl]], dim=-1)      # :417
+        else:
+            x_new = torch.cat([y, b[:, sl]], dim=-1)
+        x = torch.cat([x[:, -(c.seq_in - c.seq_out):], x_new], dim=1) if c.seq_in > c.seq_out else x_new
+        ae_new = get_edge_action(c, a[:, sl]) if c.act else torch.ones(ey.shape[:-1] + (1,), dtype=dt)
+        ex_new = torch.cat([ey, ae_new], dim=-1)                                                  # :422
+        ex = torch.cat([ex[:, -(c.seq_in - c.seq_out):], ex_new], dim=1) if c.seq_in > c.seq_out else ex_new
+    return torch.cat(ys, dim=1).clamp(0, 1), torch.cat(eys, dim=1)                               # :437

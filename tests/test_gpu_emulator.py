@@ -1,0 +1,163 @@
+"""GPU parity of the whole surrogate (`Emulator`) against the fp64 CPU oracle: network forward, predict_tf with its
+post-processing, autoregressive rollout, plus the three non-graph kernels it adds (causal Conv1D, resnet prefix sum,
+link->node flow balance).  Tolerances are stated per test; the oracle itself is "parity unpinned" (oracle/__init__.py)."""
+import numpy as np
+import pytest
+import torch
+
+import gnn_uds_amd as U
+from gnn_uds_amd import _lib
+from oracle import emulator_ref as OE
+from oracle import spektral_dense as OD
+from tests.util import emulator_args, emulator_norms, load_emulator
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda', 0)
+
+
+def close(out, ref, tol):
+    out = out.detach().double().cpu()
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    err = float((out - ref).abs().max())
+    lim = tol * max(1.0, float(ref.abs().max()))
+    assert err <= lim, 'max abs err %.3e > %.3e' % (err, lim)
+
+
+def rnd(g, *shape):
+    return torch.rand(*shape, generator=g, dtype=torch.float64)
+
+
+@pytest.mark.parametrize('B,T,R,F,H,dil,act', [(2, 5, 7, 64, 64, 1, 'relu'), (1, 60, 3, 96, 64, 4, 'relu'), (3, 4, 5, 10, 6, 2, 'tanh')])
+def test_conv1d_causal(dev, B, T, R, F, H, dil, act):
+    g = torch.Generator().manual_seed(T)
+    x, k, b = rnd(g, B, T, R, F) - 0.5, rnd(g, 3, F, H) - 0.5, rnd(g, H) - 0.5
+    ref = OE.conv1d_causal(x.permute(0, 2, 1, 3).reshape(B * R, T, F), k, b, dil, act).reshape(B, R, T, H).permute(0, 2, 1, 3)
+    f = lambda t: t.float().to(dev)
+    close(_lib.conv1d_causal(f(x), f(k), f(b), dil, act), ref, 2e-5)
+
+
+def test_cumsum_act_and_flow_balance(dev, networks):
+    g = torch.Generator().manual_seed(1)
+    x, res = rnd(g, 2, 6, 9, 8) - 0.5, rnd(g, 2, 1, 9, 8) - 0.5
+    close(_lib.cumsum_act(x.float().to(dev), res.float().to(dev), 'relu'), torch.relu(torch.cumsum(x, 1) + res), 1e-6)
+    close(_lib.cumsum_act(x.float().to(dev), None, 'linear'), torch.cumsum(x, 1), 1e-6)
+    net = networks['chaohu']
+    gph = U.DrainageGraph.from_edges(np.array(net['edges']), net['n_node'])
+    ne = torch.from_numpy(gph.inc_n.to_dense())
+    flow = rnd(g, 4, gph.n_edge, 1) - 0.5
+    s_in, s_out = rnd(g, gph.n_node), rnd(g, gph.n_node)
+    pos, neg = ne.clamp(0, 1), ne.clamp(-1, 0).abs()
+    fp, fn = flow.clamp(min=0), -flow.clamp(max=0)
+    q_out, q_in = (pos @ fp + neg @ fn)[..., 0] * s_out, (neg @ fp + pos @ fn)[..., 0] * s_in
+    h = _lib.CsrHandle(gph.inc_n)
+    sign = torch.as_tensor(gph.inc_n.val, dtype=torch.float32, device=dev)
+    gi, go = _lib.flow_balance(h, sign, flow[..., 0].float().to(dev).contiguous(), s_in.float().to(dev), s_out.float().to(dev))
+    close(gi, q_in, 1e-6); close(go, q_out, 1e-6)
+
+
+def _setup(networks, name, dev, precision='bf16x3', **over):
+    net = networks[name]
+    args = emulator_args(net['edges'], net['n_node'], **over)
+    params = OE.init_params(args, seed=3)
+    emul = load_emulator(U.Emulator(args.conv, args.resnet, args.recurrent, args, precision=precision), params, dev)
+    norms = emulator_norms(args)
+    emul.set_norm(*(norms[k].numpy() for k in 'xbyre'))
+    return args, params, emul, norms
+
+
+def _inputs(args, B, seed=5, n_act=2):
+    g = torch.Generator().manual_seed(seed)
+    N, E = args.state_shape[0], args.edge_state_shape[0]
+    n_in = args.state_shape[1] + (1 if args.if_flood else 0)
+    X = rnd(g, B, args.seq_in, N, n_in)
+    Bd = rnd(g, B, args.seq_out * max(1, args.roll), N, 2 if args.tide else 1) * 0.1
+    Ex = rnd(g, B, args.seq_in, E, 4)
+    a = rnd(g, B, args.seq_out * max(1, args.roll), n_act)
+    return X, Bd, Ex, a
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 5e-5), ('bf16x3', 5e-4)])
+def test_network_forward(dev, networks, precision, tol):
+    """build_network (emulator.py:166-341): GAT, edge fusion, actions, flood head, resnet; B*T = 10 snapshots."""
+    args, params, emul, _ = _setup(networks, 'shunqing', dev, precision)
+    X, Bd, Ex, a = _inputs(args, 2)
+    c = OE.config(args)
+    AE = OE.get_edge_action(c, a)
+    ry, rey = OE.forward(args, params, X, Bd, Ex, AE)
+    f = lambda t: t.float().to(dev)
+    y, ey = emul(f(X), f(Bd), f(Ex), emul.get_edge_action(f(a)))
+    assert ry.shape == (2, 5, args.state_shape[0], 2) and rey.shape == (2, 5, args.edge_state_shape[0], 3)
+    close(y, ry, tol); close(ey, rey, tol)
+
+
+def test_network_forward_gcn_and_plain_variants(dev, networks):
+    """conv = GCN (emulator.py:131-134), no actions / flood / resnet / edge fusion, seq_in > seq_out."""
+    args, params, emul, _ = _setup(networks, 'astlingen', dev, conv='GCN', act=False, if_flood=0, resnet=False, edge_fusion=False,
+                                   seq_in=6, seq_out=2, embed_size=32, hidden_dim=16, n_sp_layer=1, n_tp_layer=3)
+    X, Bd, Ex, _ = _inputs(args, 3)
+    ry, rey = OE.forward(args, params, X, Bd, Ex)
+    f = lambda t: t.float().to(dev)
+    y, ey = emul(f(X), f(Bd), f(Ex))
+    assert ry.shape == (3, 2, 30, 3)
+    close(y, ry, 5e-5); close(ey, rey, 5e-5)
+
+
+@pytest.mark.parametrize('variant', ['edge_fusion_act', 'pumps_offset_tide', 'plain'])
+def test_predict_tf(dev, networks, variant):
+    """predict_tf (emulator.py:604-641) incl. post_proc_tf / constrain_tf branches; raw states in, physical units out."""
+    rng = np.random.default_rng(0)
+    net = networks['astlingen']
+    n, e = net['n_node'], len(net['edges'])
+    over = dict(edge_fusion=True, act=True)
+    if variant == 'pumps_offset_tide':
+        over = dict(edge_fusion=False, act=True, tide=True, pump=0.1 + rng.random(e), pump_in=rng.random(n) * (rng.random(n) > 0.7),
+                    pump_out=rng.random(n) * (rng.random(n) > 0.7), offset=rng.random(e) * (rng.random(e) > 0.5), area=rng.random(n),
+                    epsilon=0.1)
+    elif variant == 'plain':
+        over = dict(edge_fusion=False, act=False, if_flood=0, epsilon=0.0)
+    args, params, emul, norms = _setup(networks, 'astlingen', dev, 'fp32', **over)
+    X, Bd, Ex, a = _inputs(args, 2)
+    ry, rey = OE.predict(args, params, norms, X, Bd, a if args.act else None, Ex)
+    f = lambda t: t.float().to(dev)
+    y, ey = emul.predict_tf(f(X), f(Bd), f(a) if args.act else None, f(Ex))
+    assert ry.shape == (2, 5, n, 5 if args.if_flood else 4) and rey.shape == (2, 5, e, 3)
+    # hard thresholds (flood bit > 0.5, depth > 0.01, ...) can flip on values within rounding of the threshold:
+    # compare the bulk tightly and allow a handful of flipped entries
+    for out, ref in ((y, ry), (ey, rey)):
+        d = (out.double().cpu() - ref).abs()
+        bad = int((d > 1e-4 * max(1.0, float(ref.abs().max()))).sum())
+        assert bad <= max(2, ref.numel() // 500), (variant, bad, ref.numel(), float(d.max()))
+
+
+def test_model_rollout(dev, networks):
+    """_model with roll = 3 (emulator.py:401-425): autoregressive chunks, flood bit thresholded, window shifted."""
+    args, params, emul, norms = _setup(networks, 'astlingen', dev, 'fp32', roll=3, seq_in=4, seq_out=2, n_sp_layer=1)
+    X, Bd, Ex, a = _inputs(args, 2)
+    ry, rey = OE.model_rollout(args, params, norms, X, a, Bd, Ex)
+    f = lambda t: t.float().to(dev)
+    y, ey = emul._model(f(X), f(a), f(Bd), f(Ex))
+    assert ry.shape == (2, 6, 30, 4)
+    d = (y.double().cpu() - ry).abs()
+    assert int((d > 2e-4).sum()) <= max(2, ry.numel() // 500), float(d.max())
+    assert float((ey.double().cpu() - rey).abs().max()) < 5e-3
+
+
+def test_save_load_and_not_built(dev, networks, tmp_path):
+    args, params, emul, norms = _setup(networks, 'astlingen', dev, n_sp_layer=1)
+    X, Bd, Ex, a = _inputs(args, 1)
+    f = lambda t: t.float().to(dev)
+    y0, e0 = emul.predict_tf(f(X), f(Bd), f(a), f(Ex))
+    emul.save(str(tmp_path))
+    other = U.Emulator(args.conv, args.resnet, args.recurrent, args).to(dev)
+    other.load(str(tmp_path))
+    y1, e1 = other.predict_tf(f(X), f(Bd), f(a), f(Ex))
+    assert torch.equal(y0, y1) and torch.equal(e0, e1)
+    with pytest.raises(NotImplementedError):
+        emul.fit_eval()
+    with pytest.raises(NotImplementedError):
+        U.Emulator('GAT', False, 'GRU', args)

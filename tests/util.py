@@ -57,3 +57,72 @@ def load_spatial_layer(layer, p, device):
     layer.gat_e.kernel.data = f32(p['ge_k']); layer.gat_e.attn_kernel_self.data = f32(p['ge_as'])
     layer.gat_e.attn_kernel_neighs.data = f32(p['ge_an']); layer.gat_e.bias.data = f32(p['ge_b'])
     return layer
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# whole-emulator helpers
+# ---------------------------------------------------------------------------------------------------------------
+def emulator_args(edges, n_node, seed=0, **over):
+    """A reference-style `args` namespace (attribute names of Emulator.__init__, emulator.py:48-127) for a link list."""
+    from types import SimpleNamespace
+    from oracle import graphs as OG
+    edges = np.asarray(edges)
+    rng = np.random.default_rng(seed)
+    n_edge = len(edges)
+    a = dict(state_shape=(n_node, 4), edge_state_shape=(n_edge, 4), seq_in=5, seq_out=5, embed_size=64, hidden_dim=64,
+             kernel_size=3, n_sp_layer=2, n_tp_layer=2, activation='relu', if_flood=3, epsilon=-1.0, edge_fusion=True,
+             edges=edges, adj=OG.adjacency(edges), edge_adj=OG.edge_adjacency(edges), node_edge=OG.node_edge_incidence(n_node, edges),
+             act=True, act_edges=edges[[1, 4]], conv='GAT', resnet=True, recurrent='Conv1D', roll=0, model_dir='/tmp/uds_model',
+             is_outfall=(np.arange(n_node) == 0).astype(float), hmax=1.0 + rng.random(n_node), hmin=np.zeros(n_node),
+             area=np.zeros(n_node), pump=np.zeros(n_edge), pump_in=np.zeros(n_node), pump_out=np.zeros(n_node),
+             offset=np.zeros(n_edge), ehmax=0.3 + rng.random(n_edge), tide=False)
+    a.update(over)
+    return SimpleNamespace(**a)
+
+
+def emulator_norms(args, seed=0, dtype=torch.float64):
+    """[max, min] per node / link and channel (dataloader.py:224-266 layout): min = 0, max random positive."""
+    g = torch.Generator().manual_seed(seed)
+    n, e = args.state_shape[0], args.edge_state_shape[0]
+    n_in = args.state_shape[1] + (1 if args.if_flood else 0)
+    mk = lambda rows, c: torch.stack([0.5 + torch.rand(rows, c, generator=g, dtype=torch.float64),
+                                      torch.zeros(rows, c, dtype=torch.float64)]).to(dtype)
+    return {'x': mk(n, n_in), 'b': mk(n, 2 if args.tide else 1), 'y': mk(n, 5), 'r': mk(n, 1), 'e': mk(e, 4)}
+
+
+def load_emulator(emul, p, device):
+    """Copy oracle.emulator_ref.init_params parameters into a gnn_uds_amd.Emulator."""
+    f32 = lambda t: t.to(torch.float32).to(device).contiguous()
+    emul.to(device)
+
+    def dense(m, q):
+        m.kernel.data, m.bias.data = f32(q['kernel']), f32(q['bias'])
+
+    def spatial(block, layers):
+        for layer, q in zip(block.layers, layers):
+            dense(layer.dense_xe, q['dense_xe']); dense(layer.dense_ex, q['dense_ex'])
+            for ne, key in ((layer.node_edge_n, 'node_edge_n'), (layer.node_edge_e, 'node_edge_e')):
+                ne.weight.data, ne.bias.data = f32(q[key]['weight']), f32(q[key]['bias'])
+            convs = (layer.gat_x, layer.gat_e) if layer.conv == 'GAT' else (layer.gcn_x, layer.gcn_e)
+            for m, key in zip(convs, ('gat_x', 'gat_e')):
+                if layer.conv == 'GAT':
+                    m.kernel.data = f32(q[key]['kernel'])
+                    m.attn_kernel_self.data, m.attn_kernel_neighs.data = f32(q[key]['attn_kernel_self']), f32(q[key]['attn_kernel_neighs'])
+                else:
+                    m.kernel.data = f32(q[key]['kernel'][:, 0, :])
+                m.bias.data = f32(q[key]['bias'])
+
+    dense(emul.embed_x, p['embed_x']); dense(emul.embed_b, p['embed_b']); dense(emul.embed_e, p['embed_e'])
+    if emul.act:
+        dense(emul.embed_ae, p['embed_ae'])
+    spatial(emul.block1, p['block1']); spatial(emul.block2, p['block2'])
+    for mods, key in ((emul.tem1_x, 'tem1_x'), (emul.tem1_e, 'tem1_e'), (emul.tem2_x, 'tem2_x'), (emul.tem2_e, 'tem2_e')):
+        for m, q in zip(mods, p[key]):
+            dense(m, q)
+    dense(emul.res_x, p['res_x']); dense(emul.res_e, p['res_e']); dense(emul.out, p['out'])
+    for m, q in zip(emul.flood, p['flood']):
+        dense(m, q)
+    if emul.if_flood:
+        dense(emul.flood_out, p['flood_out'])
+    dense(emul.e_out_layer, p['e_out'])
+    return emul
