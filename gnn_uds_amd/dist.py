@@ -1,0 +1,235 @@
+"""Graph-sharded spatial block: node-cut partition of one big drainage network over the GPUs of a node, with the
+boundary rows exchanged once per message-passing layer (one process per GPU, `torch.distributed` over RCCL / xGMI).
+
+The reference has nothing like this (whole graph = one dense matrix on one device); it exists for the
+200k-node case of BASELINE.json (`configs[3]`).  Snapshots of the headline-size network do NOT use it -- they shard
+by snapshot with no collective (bench.py).
+
+Dependency radius of one spatial layer (`emulator.py:225-230`): the outputs of a rank's own nodes / links need
+  hx of   A1 = adj-neighbours of own nodes        -> x of A1 and e of L1 = links incident to A1
+  he of   B1 = edge_adj-neighbours of own links   -> e of B1 and x of M1 = end nodes of B1
+so every rank computes the layer on the sub-network induced by (A1 u M1, L1 u B1): rows it owns come out exact, the
+halo rows are recomputed redundantly where needed (halo hx / he) and otherwise ignored; after the layer every rank
+sends the exact outputs of the own rows its peers hold as halo.  Near-tree networks cut into P connected parts have
+O(P) cut links, so a message is a few dozen rows: latency-bound, hence ONE message per peer per layer (node rows and
+link rows packed together), posted as grouped isend/irecv (ncclSend/ncclRecv on RCCL, each peer pair on its own
+xGMI link).
+
+All index bookkeeping here is host-side numpy and deterministic: every rank derives the same plan from the same
+network, nothing is negotiated at run time.  Tested with world_size-2 gloo processes on CPU (tests/test_dist.py).
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .graph import CSR, DrainageGraph
+
+I32 = np.int32
+
+
+def partition_nodes(graph, n_parts):
+    """Node -> part (int32): equal contiguous ranges of a DFS pre-order of a spanning forest.  A range of a tree's
+    pre-order is a union of a few whole subtrees plus a path, so the cut stays small on near-tree networks."""
+    n = graph.n_node
+    rowptr, col = graph.adj.rowptr, graph.adj.col
+    seen = np.zeros(n, dtype=bool)
+    order = np.empty(n, dtype=np.int64)
+    k = 0
+    for root in range(n):
+        if seen[root]:
+            continue
+        stack = [root]
+        seen[root] = True
+        while stack:
+            v = stack.pop()
+            order[k] = v
+            k += 1
+            nb = col[rowptr[v]:rowptr[v + 1]]
+            for u in nb[::-1]:
+                if not seen[u]:
+                    seen[u] = True
+                    stack.append(int(u))
+    part = np.empty(n, dtype=I32)
+    part[order] = (np.arange(n, dtype=np.int64) * n_parts // n).astype(I32)
+    return part
+
+
+def _rows_union(csr, rows):
+    if len(rows) == 0:
+        return np.zeros(0, dtype=np.int64)
+    rp = csr.rowptr.astype(np.int64)
+    cnt = rp[rows + 1] - rp[rows]
+    idx = np.repeat(rp[rows], cnt) + (np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+    return np.unique(csr.col[idx].astype(np.int64))
+
+
+def _induced(csr, rows, col_map, n_cols_local):
+    """Sub-CSR on `rows` with columns restricted to the local set (col_map: global -> local or -1); also returns the
+    global position of every kept entry (to gather per-entry parameters such as the NodeEdge support values)."""
+    rp = csr.rowptr.astype(np.int64)
+    cnt = rp[rows + 1] - rp[rows]
+    pos = np.repeat(rp[rows], cnt) + (np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+    lcol = col_map[csr.col[pos].astype(np.int64)]
+    keep = lcol >= 0
+    row_of = np.repeat(np.arange(len(rows)), cnt)[keep]
+    lcol, pos = lcol[keep], pos[keep]
+    o = np.lexsort((lcol, row_of))
+    row_of, lcol, pos = row_of[o], lcol[o], pos[o]
+    rowptr = np.zeros(len(rows) + 1, dtype=np.int64)
+    np.add.at(rowptr, row_of + 1, 1)
+    val = None if csr.val is None else csr.val[pos]
+    return CSR(np.cumsum(rowptr).astype(I32), lcol.astype(I32), len(rows), n_cols_local, val), pos
+
+
+@dataclass
+class LocalProblem:
+    """What one rank computes and exchanges.  Local row order: own rows first (ascending id), then halo rows."""
+    rank: int
+    own_nodes: np.ndarray
+    own_links: np.ndarray
+    nodes: np.ndarray                 # local node list (global ids)
+    links: np.ndarray
+    graph: DrainageGraph              # induced sub-network on (nodes, links)
+    inc_n_pos: np.ndarray             # global inc_n / inc_e entry of every local entry
+    inc_e_pos: np.ndarray
+    send_nodes: Dict[int, np.ndarray] = field(default_factory=dict)   # peer -> LOCAL indices of own rows it needs
+    send_links: Dict[int, np.ndarray] = field(default_factory=dict)
+    recv_nodes: Dict[int, np.ndarray] = field(default_factory=dict)   # peer -> LOCAL indices of halo rows it owns
+    recv_links: Dict[int, np.ndarray] = field(default_factory=dict)
+
+
+def build_partition_plan(graph, n_parts, part=None):
+    """Deterministic plan for all ranks: List[LocalProblem]."""
+    if part is None:
+        part = partition_nodes(graph, n_parts)
+    part = np.asarray(part, dtype=np.int64)
+    link_part = part[graph.edges[:, 0].astype(np.int64)]            # a link belongs to the part of its from-node
+    probs: List[LocalProblem] = []
+    for r in range(n_parts):
+        own_n = np.nonzero(part == r)[0]
+        own_e = np.nonzero(link_part == r)[0]
+        a1 = _rows_union(graph.adj, own_n)
+        l1 = _rows_union(graph.inc_n, a1)
+        b1 = _rows_union(graph.edge_adj, own_e)
+        m1 = _rows_union(graph.inc_e, b1)
+        nodes = np.concatenate([own_n, np.setdiff1d(np.union1d(a1, m1), own_n)])
+        links = np.concatenate([own_e, np.setdiff1d(np.union1d(l1, b1), own_e)])
+        nmap = np.full(graph.n_node, -1, dtype=np.int64)
+        nmap[nodes] = np.arange(len(nodes))
+        lmap = np.full(graph.n_edge, -1, dtype=np.int64)
+        lmap[links] = np.arange(len(links))
+        adj, _ = _induced(graph.adj, nodes, nmap, len(nodes))
+        eadj, _ = _induced(graph.edge_adj, links, lmap, len(links))
+        inc_n, pos_n = _induced(graph.inc_n, nodes, lmap, len(links))
+        inc_e, pos_e = _induced(graph.inc_e, links, nmap, len(nodes))
+        edges = np.stack([nmap[graph.edges[links, 0].astype(np.int64)], nmap[graph.edges[links, 1].astype(np.int64)]], axis=1)
+        sub = DrainageGraph(len(nodes), len(links), edges.astype(I32), adj, eadj, inc_n, inc_e, dict(part=r, n_parts=n_parts))
+        probs.append(LocalProblem(r, own_n, own_e, nodes, links, sub, pos_n, pos_e))
+    for p in probs:                                                   # who needs what from whom
+        halo_n, halo_e = p.nodes[len(p.own_nodes):], p.links[len(p.own_links):]
+        for q in range(n_parts):
+            if q == p.rank:
+                continue
+            hn = np.nonzero(part[halo_n] == q)[0]
+            he = np.nonzero(link_part[halo_e] == q)[0]
+            if len(hn) == 0 and len(he) == 0:
+                continue
+            p.recv_nodes[q] = (len(p.own_nodes) + hn).astype(np.int64)
+            p.recv_links[q] = (len(p.own_links) + he).astype(np.int64)
+            peer = probs[q]
+            p_n = np.searchsorted(peer.own_nodes, halo_n[hn])        # own rows are sorted and come first locally
+            p_e = np.searchsorted(peer.own_links, halo_e[he])
+            peer.send_nodes[p.rank] = p_n.astype(np.int64)
+            peer.send_links[p.rank] = p_e.astype(np.int64)
+    return probs
+
+
+class HaloExchange:
+    """One message per peer: [node rows | link rows] of width F, posted as grouped isend / irecv."""
+
+    def __init__(self, prob, device, group=None):
+        self.prob, self.group = prob, group
+        t = lambda a: torch.as_tensor(a, dtype=torch.int64, device=device)
+        self.peers = sorted(set(prob.send_nodes) | set(prob.recv_nodes))
+        self.send_n = {q: t(prob.send_nodes.get(q, np.zeros(0, np.int64))) for q in self.peers}
+        self.send_e = {q: t(prob.send_links.get(q, np.zeros(0, np.int64))) for q in self.peers}
+        self.recv_n = {q: t(prob.recv_nodes.get(q, np.zeros(0, np.int64))) for q in self.peers}
+        self.recv_e = {q: t(prob.recv_links.get(q, np.zeros(0, np.int64))) for q in self.peers}
+
+    def bytes_per_layer(self, S, F):
+        return sum((len(self.send_n[q]) + len(self.send_e[q])) * S * F * 4 for q in self.peers)
+
+    def __call__(self, x, e):
+        """x (S, n_local_nodes, F), e (S, n_local_links, F): overwrite the halo rows with the owners' exact rows."""
+        if not self.peers:
+            return x, e
+        ops, recvs, keep = [], [], []
+        for q in self.peers:
+            nn_, ne_ = len(self.recv_n[q]), len(self.recv_e[q])
+            if nn_ + ne_:
+                buf = torch.empty((x.shape[0], nn_ + ne_, x.shape[-1]), device=x.device, dtype=x.dtype)
+                recvs.append((q, buf, nn_))
+                ops.append(dist.P2POp(dist.irecv, buf, q, self.group))
+            sn, se = self.send_n[q], self.send_e[q]
+            if len(sn) + len(se):
+                out = torch.cat([x.index_select(1, sn), e.index_select(1, se)], dim=1).contiguous()
+                keep.append(out)
+                ops.append(dist.P2POp(dist.isend, out, q, self.group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for q, buf, nn_ in recvs:
+            x.index_copy_(1, self.recv_n[q], buf[:, :nn_])
+            e.index_copy_(1, self.recv_e[q], buf[:, nn_:])
+        return x, e
+
+
+class ShardedSpatialBlock:
+    """The L-layer spatial block of one rank of a graph-sharded run.
+
+    layer_fn(prob, layer_index, x_local, e_local) -> (x', e') computes one spatial layer on the rank's sub-network
+    (exact on own rows).  The product passes HIP `SpatialLayer`s built on `prob.graph` (see `hip_layers`); the CPU
+    tests pass the oracle."""
+
+    def __init__(self, prob, n_layers, layer_fn, device, group=None):
+        self.prob, self.n_layers, self.layer_fn = prob, n_layers, layer_fn
+        self.exchange = HaloExchange(prob, device, group)
+
+    def scatter_inputs(self, x_global, e_global):
+        """Local buffers from replicated global inputs (own + halo rows are simply read)."""
+        dev = x_global.device
+        ni = torch.as_tensor(self.prob.nodes, dtype=torch.int64, device=dev)
+        li = torch.as_tensor(self.prob.links, dtype=torch.int64, device=dev)
+        return x_global.index_select(1, ni).contiguous(), e_global.index_select(1, li).contiguous()
+
+    def forward(self, x_local, e_local):
+        """x_local (S, n_local_nodes, F), e_local likewise, halo rows valid.  Returns the own rows of the block output."""
+        for i in range(self.n_layers):
+            x_local, e_local = self.layer_fn(self.prob, i, x_local, e_local)
+            if i + 1 < self.n_layers:
+                x_local, e_local = self.exchange(x_local, e_local)
+        return x_local[:, :len(self.prob.own_nodes)], e_local[:, :len(self.prob.own_links)]
+
+
+def hip_layers(prob, global_params, embed_size, activation='relu', precision='bf16x3', device='cuda'):
+    """HIP `SpatialLayer`s for a rank's sub-network from GLOBAL per-layer parameters (dicts with the keys of
+    `SpatialLayer.export_params()` in sparse form: 'ne_n_v' / 'ne_e_v' are indexed by global support entry)."""
+    from .layers import SpatialLayer
+    layers = []
+    for p in global_params:
+        fx, fe = p['ex_k'].shape[0], p['xe_k'].shape[0]
+        ly = SpatialLayer(prob.graph, embed_size, activation, fx=fx, fe=fe, sparse_params=True, precision=precision).to(device)
+        f = lambda t: None if t is None else t.to(torch.float32).to(device).contiguous()
+        ly.dense_xe.kernel.data, ly.dense_xe.bias.data = f(p['xe_k']), f(p['xe_b'])
+        ly.dense_ex.kernel.data, ly.dense_ex.bias.data = f(p['ex_k']), f(p['ex_b'])
+        ly.node_edge_n.weight.data = f(p['ne_n_v'][torch.as_tensor(prob.inc_n_pos)])
+        ly.node_edge_e.weight.data = f(p['ne_e_v'][torch.as_tensor(prob.inc_e_pos)])
+        ly.node_edge_n.bias.data = torch.zeros_like(ly.node_edge_n.weight.data)
+        ly.node_edge_e.bias.data = torch.zeros_like(ly.node_edge_e.weight.data)
+        for m, k in ((ly.gat_x, 'gx'), (ly.gat_e, 'ge')):
+            m.kernel.data, m.bias.data = f(p[k + '_k']), f(p[k + '_b'])
+            m.attn_kernel_self.data, m.attn_kernel_neighs.data = f(p[k + '_as']), f(p[k + '_an'])
+        layers.append(ly)
+    return layers
