@@ -9,6 +9,9 @@ A "step" = one pass of the hot path over one batch: the L-layer spatial block
 (graph-step = one spatial layer on one snapshot).  With N > 1 every rank
 runs its own S snapshots of the same network (snapshots are independent inside a forward,
 `emulator.py:217-218`): weak scaling, no data-path collective.  Rank 0 prints ONE JSON line.
+
+`--workload c4` switches to BASELINE.json's 200k-node mega-catchment: ONE network node-cut partitioned
+over the N ranks, boundary rows exchanged once per layer over RCCL (gnn_uds_amd/dist.py): strong scaling.
 """
 import argparse
 import json
@@ -78,6 +81,57 @@ def cpu_baseline(g, block_params, d, budget_s=12.0, S=2):
                       % (n, len(block_params), S, el)}
 
 
+def bench_c4(args, U, dist, world, rank, dev):
+    """200k-node network, node-cut over `world` ranks, halo exchange after every layer but the last (strong scaling)."""
+    from gnn_uds_amd import dist as D
+    nodes = 200000 if args.nodes == 10000 else args.nodes
+    links = 240000 if args.links == 12000 else args.links
+    S = 8 if args.snapshots == 60 else args.snapshots
+    d, L = args.embed, args.layers
+    g = U.DrainageGraph.from_edges(U.synthetic_drainage_network(nodes, links, seed=0))
+    prob = D.build_partition_plan(g, world)[rank]
+    ref = U.SpatialBlock(g, d, L, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1))   # CPU parameters only
+    params = [ly.export_params() for ly in ref.layers]
+    layers = D.hip_layers(prob, params, d, 'relu', args.precision, dev)
+    block = D.ShardedSpatialBlock(prob, L, lambda p, i, x, e: layers[i](x, e), dev)
+    gen = torch.Generator().manual_seed(2)
+    x, e = block.scatter_inputs(torch.rand(S, nodes, d, generator=gen), torch.rand(S, links, d, generator=gen))
+    x, e = x.to(dev), e.to(dev)
+    for _ in range(args.warmup):
+        block.forward(x, e)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        block.forward(x, e)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    if rank == 0:
+        bytes_gs = algorithmic_bytes_per_graph_step(g, d, d)
+        achieved = args.steps * L * S * bytes_gs / world / wall / 1e9        # per GPU: each rank streams 1/world of the network
+        print(json.dumps({
+            'metric': 'graph-steps/sec (forward rollout), 200k-node network partitioned over the GPUs', 'value': args.steps * L * S / wall,
+            'unit': 'graph-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else
+            'f32 storage/accumulate, GEMM operands as bf16 hi+lo split (3 MFMA products)', 'data': 'synthetic',
+            'config': {'workload': 'C4 synthetic mega-catchment N=%d E=%d d=%d, %d-layer GAT spatial block, S=%d snapshots, '
+                                   '%d-way node cut with per-layer halo exchange' % (nodes, links, d, L, S, world),
+                       'own_nodes': int(len(prob.own_nodes)), 'halo_nodes': int(len(prob.nodes) - len(prob.own_nodes)),
+                       'halo_links': int(len(prob.links) - len(prob.own_links)), 'peers': len(block.exchange.peers),
+                       'halo_bytes_per_layer': block.exchange.bytes_per_layer(S, d), 'precision': args.precision},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
+                         'traffic': None, 'kernel': 'k_fused_tile (per rank, its part of the network)'}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -91,6 +145,8 @@ def main():
     ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'fp32'],
                     help="bf16x3: fused kernel, GEMM operands split into bf16 hi+lo (3 MFMA products, fp32 accumulate); "
                          "fp32: exact-fp32 unfused kernels")
+    ap.add_argument('--workload', default='headline', choices=['headline', 'c4'],
+                    help='c4: 200k-node / 240k-link network partitioned over the ranks with per-layer halo exchange')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -109,6 +165,8 @@ def main():
 
     import gnn_uds_amd as U
 
+    if args.workload == 'c4':
+        return bench_c4(args, U, dist, world, rank, dev)
     g = U.DrainageGraph.from_edges(U.synthetic_drainage_network(args.nodes, args.links, seed=0))
     d, L, S = args.embed, args.layers, args.snapshots
     # random-init weights of the reference architecture (Keras initialisers: glorot_uniform kernels, zero
