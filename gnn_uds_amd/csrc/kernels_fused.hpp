@@ -119,6 +119,17 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// sum over the four lanes l, l^16, l^32, l^48 with v_permlane16_swap / v_permlane32_swap (VALU, no LDS round trip):
+// swap16(A=B=v) gives A' = [r0,r0,r2,r2], B' = [r1,r1,r3,r3] (16-lane rows r0..r3), swap32 gives [lo,lo] and [hi,hi].
+__device__ __forceinline__ float quarters_sum(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const unsigned w = __float_as_uint(s);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // ACT: UDS_ACT_* known at compile time (relu / linear fast paths), or -1 = decide at run time from a.act.
 template <int ACT>
 __device__ __forceinline__ float fused_act(float v, int act_rt) {
@@ -155,6 +166,31 @@ __device__ __forceinline__ void glds16(const float *src, unsigned lds_byte) {
                : "=&s"(keep)
                : "v"(src), "s"(lds_byte)
                : "memory");
+}
+// NP consecutive 1-KiB pieces in ONE statement (one M0 save / restore): piece i goes to lds_byte + i * 1024.
+template <int NP>
+__device__ __forceinline__ void glds16_run(const float *const (&src)[NP], unsigned lds_byte) {
+  static_assert(NP == 4 || NP == 6, "pieces per 16-row block: 4 (64 floats) or 6 (96 floats)");
+  unsigned keep;
+  if constexpr (NP == 4) {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "s"(lds_byte)
+                 : "memory", "scc");
+  } else {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), "s"(lds_byte)
+                 : "memory", "scc");
+  }
 }
 __device__ __forceinline__ unsigned lds_addr(const void *p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
@@ -258,19 +294,19 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
     const int off = blk == wave ? soff0 : (blk == wave + NW ? soff1 : sec_off(blk));
     const float *src = S_.sec_in + (int64_t)s * S_.n_sec_glob * FS + off;
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(stage_s) + (unsigned)blk * (KT_S * 2 * 1024));
+    const float *pc[2 * KT_S];
 #pragma unroll
-    for (int t = 0; t < KT_S; ++t)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) glds16(src + 32 * t + 16 * i, dst + (t * 2 + i) * 1024);
+    for (int i = 0; i < 2 * KT_S; ++i) pc[i] = src + 16 * i;      // piece (t, i) = floats 32t + 16i = 16 * (2t + i)
+    glds16_run<2 * KT_S>(pc, dst);
   };
   auto dma_prim = [&](int blk, int s) {
     const int off = blk == wave ? poff0 : prim_off(blk);
     const float *src = S_.prim_in + (int64_t)s * S_.n_prim_glob * FP + off;
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(stage_p) + (unsigned)blk * (KT_X * 2 * 1024));
+    const float *pc[2 * KT_X];
 #pragma unroll
-    for (int t = 0; t < KT_X; ++t)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) glds16(src + 32 * t + 16 * i, dst + (t * 2 + i) * 1024);
+    for (int i = 0; i < 2 * KT_X; ++i) pc[i] = src + 16 * i;
+    glds16_run<2 * KT_X>(pc, dst);
   };
 
   // P3 (the planner keeps n_own <= 4*NW*U, so one trip covers the tile: row = wave*4 + 4*NW*u + rs): the (wave-
@@ -338,18 +374,30 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
     const int ag_l0 = ag_beg < ag_end ? ag_l0r : 0, ag_l1 = ag_beg + 1 < ag_end ? ag_l1r : 0;
     const float ag_w0 = ag_beg < ag_end ? ag_w0r : 0.f, ag_w1 = ag_beg + 1 < ag_end ? ag_w1r : 0.f;
     // ---------------- P2: [prim | agg] @ Wbig -> hx, attention scalars -> LDS ----------------
+    int p3_deg[U], p3_jn[U], p3_row[U];   // P3 index lists (they do not depend on the data): fetched inside P2
     for (int blk = wave; blk * 16 < n_prim; blk += NW) {
       const float4 *st = reinterpret_cast<const float4 *>(stage_p + blk * (KT_X * 2 * 256)) + lane;
       bf16x8 dh[KT_B], dl[KT_B];
 #pragma unroll
       for (int t = 0; t < KT_X; ++t) split8(st[(2 * t) * 64], st[(2 * t + 1) * 64], dh[t], dl[t]);
+      UDS_STAMP(8);    // P2a: stage read + split
       if (s + 1 < s_end) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         dma_prim(blk, s + 1);
       }
+      UDS_STAMP(9);    // P2b: DMA issue
       const int lrow = blk * 16 + r16;
       const bool valid = lrow < n_prim;
       const int lr = min(lrow, n_prim - 1);
+      // the k-steps over the row's own features do not need the aggregate: issue their MFMAs first, the matrix pipe
+      // works on them while this wave gathers the incident secondary rows below
+      f32x4 acc[MB_B];
+#pragma unroll
+      for (int m = 0; m < MB_B; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < KT_X; ++t)
+#pragma unroll
+        for (int m = 0; m < MB_B; ++m) acc[m] = mfma3(wbh[t][m], wbl[t][m], dh[t], dl[t], acc[m]);
       float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;   // this lane's 8 aggregate features (fragment shape)
       auto add_row = [&](int loc, float wv) {
         const float *row = sec + loc * SEC_STRIDE + 4 * qd;
@@ -366,13 +414,22 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
         for (int p = inc_ptr[lr]; p < inc_ptr[lr + 1]; ++p) add_row(inc_loc[p], inc_val[p]);
       }
       split8(g0, g1, dh[KT_X], dl[KT_X]);
-      f32x4 acc[MB_B];
+      UDS_STAMP(10);   // P2c: x-part MFMA issue + aggregation
+      // the index reads P3 needs are issued now, ahead of the last MFMAs, so they land in their shadow
+      if (blk == wave) {
 #pragma unroll
-      for (int m = 0; m < MB_B; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < U; ++u) {
+          const int i = wave * 4 + 4 * NW * u + rs;
+          const int ic = min(i, n_own - 1);
+          const int b0 = adj_ptr[ic];
+          p3_deg[u] = i < n_own ? adj_ptr[ic + 1] - b0 : 0;
+          p3_jn[u] = adj_loc[b0 + min(c16, max(p3_deg[u] - 1, 0))];
+          p3_row[u] = prim_ids[ic];
+        }
+      }
 #pragma unroll
-      for (int t = 0; t < KT_B; ++t)
-#pragma unroll
-        for (int m = 0; m < MB_B; ++m) acc[m] = mfma3(wbh[t][m], wbl[t][m], dh[t], dl[t], acc[m]);
+      for (int m = 0; m < MB_B; ++m) acc[m] = mfma3(wbh[KT_X][m], wbl[KT_X][m], dh[KT_X], dl[KT_X], acc[m]);
+      UDS_STAMP(11);   // P2d: index prefetch + MFMA chain
       float ps = 0.f, pn = 0.f;
 #pragma unroll
       for (int m = 0; m < MB_B; ++m) {
@@ -384,8 +441,8 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
           pn = fmaf(acc[m][j], an4[j], pn);
         }
       }
-      ps += __shfl_xor(ps, 16); pn += __shfl_xor(pn, 16);
-      ps += __shfl_xor(ps, 32); pn += __shfl_xor(pn, 32);
+      ps = quarters_sum(ps);
+      pn = quarters_sum(pn);
       if (valid) {
         if (qd == 0) {
           s_self[lrow] = ps;
@@ -396,15 +453,16 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
           *reinterpret_cast<f32x4 *>(hx + lrow * FUSED_D + (((4 * m + qd) ^ (lrow & 7)) << 2)) = acc[m];
       }
     }
-    int p3_deg[U], p3_jn[U], p3_row[U];   // P3 index lists, fetched ahead of the barrier like the P2 ones
+    if (!(wave * 16 < n_prim)) {   // waves without a P2 block fetch their P3 index lists here
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = wave * 4 + 4 * NW * u + rs;
-      const int ic = min(i, n_own - 1);
-      const int b0 = adj_ptr[ic];
-      p3_deg[u] = i < n_own ? adj_ptr[ic + 1] - b0 : 0;
-      p3_jn[u] = adj_loc[b0 + min(c16, max(p3_deg[u] - 1, 0))];
-      p3_row[u] = prim_ids[ic];
+      for (int u = 0; u < U; ++u) {
+        const int i = wave * 4 + 4 * NW * u + rs;
+        const int ic = min(i, n_own - 1);
+        const int b0 = adj_ptr[ic];
+        p3_deg[u] = i < n_own ? adj_ptr[ic + 1] - b0 : 0;
+        p3_jn[u] = adj_loc[b0 + min(c16, max(p3_deg[u] - 1, 0))];
+        p3_row[u] = prim_ids[ic];
+      }
     }
     UDS_STAMP(4);
     lds_barrier();
@@ -442,7 +500,6 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
           const float sc = leaky02(ss[u] + s_nbr[jn[u]]);
           lg[u] = c16 < deg[u] ? sc : -INFINITY;
         }
-        UDS_STAMP(8);
         float2 *scr = reinterpret_cast<float2 *>(scratch) + wave * (U * 64);   // (weight, neighbour) per (u, lane)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -495,7 +552,6 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
         for (; k < e2; k += 2) trip(std::integral_constant<int, 3>{}, k);
         for (; k < e1; k += 2) trip(std::integral_constant<int, 2>{}, k);
         for (; k < e0; k += 2) trip(std::integral_constant<int, 1>{}, k);
-        UDS_STAMP(9);
       } else {   // some row has more than 16 neighbours: every lane walks its row's whole list
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -532,9 +588,10 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
   }
 #ifdef UDS_PHASE_TIMING
   if (a.dbg && lane == 0) {
-    unsigned long long *o = a.dbg + ((size_t)blockIdx.x * NW + wave) * 12;
+    unsigned long long *o = a.dbg + ((size_t)blockIdx.x * NW + wave) * 16;
+    o[12] = wave;
     for (int k = 0; k < 7; ++k) o[k] = tm_[k];
-    o[8] = tm_[8]; o[9] = tm_[9]; o[10] = wave;
+    o[8] = tm_[8]; o[9] = tm_[9]; o[10] = tm_[10]; o[11] = tm_[11];
     o[7] = 1ull | ((unsigned long long)sd << 8) | ((unsigned long long)n_own << 16) | ((unsigned long long)n_prim << 32) |
            ((unsigned long long)n_sec << 48);
   }

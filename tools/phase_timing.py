@@ -30,7 +30,7 @@ torch.cuda.synchronize()
 n_tiles = info['node_tiles'] + info['link_tiles']
 raw = ws[22528:].view(torch.int64).cpu().numpy()
 n_wg = 0
-rows = raw[:(len(raw) // 12) * 12].reshape(-1, 12)
+rows = raw[:(len(raw) // 16) * 16].reshape(-1, 16)
 valid = (rows[:, 7] & 1) == 1
 rows = rows[valid]
 print('waves with stamps:', len(rows), 'plan', info)
@@ -40,6 +40,6 @@ for side in (0, 1):
     r = rows[((rows[:, 7] >> 8) & 0xff) == side]
     print('side', side, 'waves', len(r), ' mean cycles per wave:', {n: int(r[:, k].mean()) for k, n in enumerate(names)}, 'total', int(r[:, :7].sum(1).mean()))
 for wv in range(8):
-    r = rows[rows[:, 10] == wv]
-    print('wave', wv, {n: int(r[:, k].mean()) for k, n in enumerate(names)}, 'P3pre', int(r[:, 8].mean()), 'P3loop', int(r[:, 9].mean()))
+    r = rows[rows[:, 12] == wv]
+    print('wave', wv, {n: int(r[:, k].mean()) for k, n in enumerate(names)}, 'P2a..d', [int(r[:, k].mean()) for k in (8, 9, 10, 11)])
 print('shares:', {n: round(float(rows[:, k].sum() / tot), 3) for k, n in enumerate(names)})
