@@ -245,10 +245,65 @@ def edge_adjacency_csr(edges, directed=False, order=1, length=0, lengths=None):
     return _csr_from_pairs(rows, cols, n_edge, n_edge)
 
 
+def _dijkstra_ball(nbrs, src, cutoff):
+    """{vertex: distance} for every vertex within `cutoff` of src (inclusive), as
+    nx.single_source_dijkstra_path_length(G, src, weight='length', cutoff=cutoff)."""
+    import heapq
+    dist = {}
+    seen = {src: 0.0}
+    heap = [(0.0, 0, src)]
+    tick = 1
+    while heap:
+        d, _, v = heapq.heappop(heap)
+        if v in dist:
+            continue
+        dist[v] = d
+        for u, w in nbrs.get(v, ()):
+            nd = d + w
+            if nd > cutoff:
+                continue
+            if u in dist:
+                continue
+            if u not in seen or nd < seen[u]:
+                seen[u] = nd
+                heapq.heappush(heap, (nd, tick, u))
+                tick += 1
+    return dist
+
+
 def _gaussian_ball_csr(n_vertices, edges, lengths, cutoff, directed, line):
-    raise NotImplementedError(
-        'length>0 (Gaussian-kernel Dijkstra neighbourhoods, base.py:372-380,421-425) is not built '
-        'yet; pass a dense filter to csr_from_dense instead')
+    """`length > 0` branches of get_adj / get_edge_adj (`base.py:370-380,396-425`): every vertex within
+    weighted distance `length` (Dijkstra, cutoff inclusive) gets exp(-(dist / (std(lengths) + 1e-5))^2).
+    Node graph: link lengths (a later link between the same two nodes overrides an earlier one, as in
+    nx.Graph.add_edge).  Line graph: two links sharing a node are (len_p + len_q) / 2 apart.
+    Entries whose kernel value underflows to 0 are dropped (the GAT filter is `adj > 0`)."""
+    if lengths is None:
+        raise ValueError('length > 0 needs the link lengths')
+    lengths = np.asarray(lengths, dtype=np.float64)
+    sigma = float(np.std(lengths))
+    nbrs = {}
+    if not line:
+        w = {}
+        for (a, b), ln in zip(edges.tolist(), lengths.tolist()):
+            w[(a, b)] = ln
+            if not directed:
+                w[(b, a)] = ln
+        for (a, b), ln in w.items():
+            nbrs.setdefault(a, []).append((b, ln))
+    else:
+        pr, pc = _link_pairs_sharing_a_node(edges, directed)
+        keep = pr != pc
+        for p, q in zip(pr[keep].tolist(), pc[keep].tolist()):
+            nbrs.setdefault(p, []).append((q, (lengths[p] + lengths[q]) / 2))
+    rows, cols, vals = [], [], []
+    for n in range(n_vertices):
+        for a, dist in _dijkstra_ball(nbrs, n, float(cutoff)).items():
+            v = float(np.exp(-(dist / (sigma + 1e-5)) ** 2))
+            if v > 0.0:
+                rows.append(n)
+                cols.append(a)
+                vals.append(v)
+    return _csr_from_pairs(rows, cols, n_vertices, n_vertices, vals)
 
 
 def incidence_csr(n_node, edges):
@@ -297,15 +352,21 @@ class DrainageGraph:
     meta: dict = field(default_factory=dict)
 
     @classmethod
-    def from_edges(cls, edges, n_node=None, directed=False, order=1):
+    def from_edges(cls, edges, n_node=None, directed=False, order=1, length=0, lengths=None):
+        """Patterns of the GAT filters `(adj > 0)` with forced self loops (`emulator.py:143-145`) for the reference's
+        `get_args(directed, length, order)` options (`base.py:277,321-328`)."""
         edges = _check_edges(edges)
         if n_node is None:
             n_node = int(edges.max()) + 1
-        adj = adjacency_csr(edges, n_node, directed, order)
-        eadj = edge_adjacency_csr(edges, directed, order)
+        adj = adjacency_csr(edges, n_node, directed, order, length, lengths)
+        eadj = edge_adjacency_csr(edges, directed, order, length, lengths)
+        me_n, me_e = np.arange(n_node, dtype=np.int64), np.arange(edges.shape[0], dtype=np.int64)
+        adj = _csr_from_pairs(np.concatenate([adj.rows(), me_n]), np.concatenate([adj.col.astype(np.int64), me_n]), n_node, n_node)
+        eadj = _csr_from_pairs(np.concatenate([eadj.rows(), me_e]), np.concatenate([eadj.col.astype(np.int64), me_e]),
+                               edges.shape[0], edges.shape[0])
         inc_n, inc_e = incidence_csr(n_node, edges)
         return cls(n_node, edges.shape[0], edges.astype(I32), adj, eadj, inc_n, inc_e,
-                   dict(directed=directed, order=order))
+                   dict(directed=directed, order=order, length=length))
 
     @classmethod
     def from_dense(cls, adj, edge_adj, node_edge, edges=None):

@@ -117,6 +117,19 @@ def test_synthetic_network_is_seeded_and_drainage_like():
     assert (h.adj.nnz, h.edge_adj.nnz, h.inc_n.nnz) == (34000, 63000, 24000)
 
 
-def test_length_kernel_not_built_is_loud():
-    with pytest.raises(NotImplementedError):
-        G.adjacency_csr(np.array([[0, 1]]), length=10.0, lengths=[5.0])
+@pytest.mark.parametrize('name', ['astlingen', 'shunqing', 'hague'])
+@pytest.mark.parametrize('cutoff', [50.0, 200.0])
+def test_gaussian_length_kernel_matches_networkx(networks, name, cutoff):
+    """`length > 0` (base.py:370-380,396-425): Dijkstra balls with the Gaussian kernel exp(-(l/std)^2)."""
+    net = networks[name]
+    e, ln = np.array(net['edges']), np.array(net['lengths'])
+    for directed in (False, True):
+        ref = OG.adjacency(e, directed, cutoff, 1, ln)
+        csr = G.adjacency_csr(e, None, directed, 1, cutoff, ln)
+        assert np.array_equal(ref > 0, csr.to_dense() > 0) and np.allclose(ref, csr.to_dense(), rtol=1e-12, atol=0)
+        if directed in DEFINED[name]:
+            ref = OG.edge_adjacency(e, directed, cutoff, 1, ln)
+            csr = G.edge_adjacency_csr(e, directed, 1, cutoff, ln)
+            assert np.array_equal(ref > 0, csr.to_dense() > 0) and np.allclose(ref, csr.to_dense(), rtol=1e-12, atol=0)
+    with pytest.raises(ValueError):
+        G.adjacency_csr(e, length=cutoff)
