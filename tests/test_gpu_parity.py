@@ -248,6 +248,46 @@ def test_headline_size_properties(dev):
     assert float((fe_ - oe).abs().max()) <= TOL_BF16X3 * max(1.0, float(fe_.abs().max()))
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_hub_network_rows_with_more_than_16_neighbours(dev, precision):
+    """A hub junction with 30 conduits plus a chain: node rows with 31 neighbours and link rows with 30+ line-graph
+    neighbours take the fused kernel's long-list path (every lane walks the whole list) -- real drainage networks
+    never do (max degree 11 in the shipped ones), so it needs its own case."""
+    hub = [[0, i] for i in range(1, 31)]
+    chain = [[i, i + 1] for i in range(30, 90)]
+    edges = np.array(hub + chain)
+    gph = U.DrainageGraph.from_edges(edges)
+    assert gph.adj.degrees().max() == 31 and gph.edge_adj.degrees().max() >= 30
+    d, S = 64, 3
+    p = spatial_params(gph.n_node, gph.n_edge, d, d, d, seed=21)
+    g = torch.Generator().manual_seed(22)
+    x, e = rnd(g, S, gph.n_node, d), rnd(g, S, gph.n_edge, d)
+    rx, re = OD.spatial_layer_dense(x, e, p, torch.from_numpy(gph.adj.to_dense()), torch.from_numpy(gph.edge_adj.to_dense()),
+                                    torch.from_numpy(gph.inc_n.to_dense()))
+    layer = load_spatial_layer(U.SpatialLayer(gph, d, 'relu', sparse_params=False, precision=precision), p, dev)
+    ox, oe = layer(x.float().to(dev), e.float().to(dev))
+    close(ox, rx, PREC_TOL[precision]); close(oe, re, PREC_TOL[precision])
+
+
+def test_c3_size_properties(dev):
+    """C3 scale (50k junctions / 65k conduits, d=64): same size-independent properties as the headline test."""
+    gph = U.DrainageGraph.from_edges(U.synthetic_drainage_network(50000, 65000, 0))
+    d, S = 64, 4
+    layer = U.SpatialLayer(gph, d, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1)).to(dev)
+    g = torch.Generator().manual_seed(2)
+    x, e = torch.rand(S, 50000, d, generator=g).to(dev), torch.rand(S, 65000, d, generator=g).to(dev)
+    ox, oe = layer(x, e)
+    ox2, oe2 = layer(x, e)
+    assert torch.equal(ox, ox2) and torch.equal(oe, oe2)                     # bitwise reproducible
+    o1x, o1e = layer(x[1:2].contiguous(), e[1:2].contiguous())
+    assert torch.equal(o1x[0], ox[1]) and torch.equal(o1e[0], oe[1])          # snapshots independent
+    p = cast(layer.export_params(), torch.float64)
+    rx, re = OS.spatial_layer_csr(x[1:2].double().cpu(), e[1:2].double().cpu(), p, (gph.adj.rowptr, gph.adj.col),
+                                  (gph.edge_adj.rowptr, gph.edge_adj.col), (gph.inc_n.rowptr, gph.inc_n.col),
+                                  (gph.inc_e.rowptr, gph.inc_e.col))
+    close(ox[1:2], rx, TOL_BF16X3); close(oe[1:2], re, TOL_BF16X3)
+
+
 def test_cpu_tensors_are_refused(dev):
     layer = U.Dense(4, 'relu', in_features=4)
     with pytest.raises(_lib.UdsError):
