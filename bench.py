@@ -49,6 +49,32 @@ def recorded_traffic(args):
     return rec.get('traffic_bytes_per_launch') if same else None
 
 
+def rollout_forward(U, g, args, dev, reps=5):
+    """End-to-end forward of the whole surrogate (`build_network`, emulator.py:166-341: embeddings, 2 x L spatial layers,
+    2 x 2 temporal Conv1D stacks, resnet head, flood / flow heads) on the same network with T_in = T_out = S, B = 1:
+    simulated time steps per second and graph-steps/s including the non-graph tail."""
+    from types import SimpleNamespace
+    T = args.snapshots
+    a = SimpleNamespace(state_shape=(g.n_node, 4), edge_state_shape=(g.n_edge, 4), seq_in=T, seq_out=T, embed_size=args.embed,
+                        hidden_dim=64, kernel_size=3, n_sp_layer=args.layers, n_tp_layer=3, activation='relu', if_flood=3,
+                        edge_fusion=True, edges=g.edges, act=False, graph=g, model_dir=None)
+    emul = U.Emulator('GAT', True, 'Conv1D', a, precision=args.precision, generator=torch.Generator().manual_seed(1)).to(dev)
+    X = torch.rand(1, T, g.n_node, 5, device=dev)
+    B = torch.rand(1, T, g.n_node, 1, device=dev)
+    E = torch.rand(1, T, g.n_edge, 4, device=dev)
+    for _ in range(2):
+        emul(X, B, E)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        emul(X, B, E)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return {'ms_per_forward': dt * 1e3, 'time_steps_per_s': T / dt, 'graph_steps_per_s_end_to_end': 2 * args.layers * T / dt,
+            'config': 'Emulator(GAT, resnet, Conv1D) B=1 T_in=T_out=%d, %d+%d spatial layers, 3+3 temporal layers x2 sides, '
+                      'flood head' % (T, args.layers, args.layers)}
+
+
 def cpu_baseline(g, block_params, d, budget_s=12.0, S=2):
     """The oracle (sparse-CSR PyTorch-CPU restatement of the reference forward, kind 'port': the
     reference's TF path cannot run here) timed on this host's cores on a bounded sample."""
@@ -224,6 +250,8 @@ def main():
                                    'uds_spatial_layer_forward, unfused (8 launches per layer over S snapshots)',
                          'algorithmic_bytes_per_graph_step': bytes_gs, 'device_ms_per_step': dev_ms},
         }
+        if world == 1 and args.embed == 64:
+            out['rollout'] = rollout_forward(U, g, args, dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(g, params, d)
         print(json.dumps(out))

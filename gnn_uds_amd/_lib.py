@@ -37,6 +37,9 @@ SYMBOLS = {
     'uds_csr_spmm': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_int, _c_ptr, _c_ptr]),
     'uds_conv1d_causal': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr,
                                    _c_ptr]),
+    'uds_rowgemm_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
+    'uds_rowgemm_pack': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
+    'uds_rowgemm_forward': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_cumsum_act': (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_flow_balance': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'uds_gat_workspace_floats': (_c_i64, [_c_i64, _c_i64, _c_i64]),
@@ -246,6 +249,44 @@ def conv1d_causal(x, kernel, bias=None, dilation=1, act='linear'):
         return out
     _check(lib.uds_conv1d_causal(_dev(x, 'x'), B, T, R, F, _dev(kernel, 'kernel'), _dev(bias, 'bias', True), taps, dilation, H,
                                  ACT[act], _dev(out, 'out'), _stream()), 'uds_conv1d_causal')
+    return out
+
+
+def rowgemm_supported(k_total, f_in, f_out):
+    """Shapes the matrix-core row GEMM takes: input width a multiple of 32, at most 64 outputs."""
+    return f_in % 32 == 0 and k_total % 32 == 0 and 0 < f_out <= 64
+
+
+def rowgemm_pack(kernel2d):
+    """Pre-split a (K, f_out) kernel into bf16 hi/lo MFMA fragments (once per parameter update)."""
+    lib = load()
+    K, fo = kernel2d.shape
+    nbytes = lib.uds_rowgemm_packed_bytes(K, fo)
+    if nbytes <= 0:
+        raise UdsError('rowgemm_pack: unsupported shape %r' % ((K, fo),))
+    out = torch.empty(nbytes // 4, device=kernel2d.device, dtype=torch.float32)
+    _check(lib.uds_rowgemm_pack(_dev(kernel2d, 'kernel'), K, fo, out.data_ptr(), _stream()), 'uds_rowgemm_pack')
+    return out
+
+
+def rowgemm_forward(x, packed, bias, f_out, act='linear', taps=1, dilation=1):
+    """Matrix-core Dense (taps=1, any leading dims) or causal Conv1D (x (B,T,R,F), taps = kernel size)."""
+    lib = load()
+    F = x.shape[-1]
+    if taps == 1:
+        B, T, R = 1, 1, x.numel() // F
+        out_shape = tuple(x.shape[:-1]) + (f_out,)
+    else:
+        if x.dim() != 4:
+            raise UdsError('conv needs x (B,T,R,F), got %r' % (tuple(x.shape),))
+        B, T, R = x.shape[:3]
+        out_shape = (B, T, R, f_out)
+    out = torch.empty(out_shape, device=x.device, dtype=torch.float32)
+    if out.numel() == 0:
+        _dev(x, 'x')
+        return out
+    _check(lib.uds_rowgemm_forward(_dev(x, 'x'), B, T, R, F, packed.data_ptr(), _dev(bias, 'bias', True), taps, dilation, f_out,
+                                   ACT[act], _dev(out, 'out'), _stream()), 'uds_rowgemm_forward')
     return out
 
 

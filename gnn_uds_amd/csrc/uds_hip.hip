@@ -15,6 +15,7 @@
 #include "kernels_dense.hpp"
 #include "kernels_sparse.hpp"
 #include "kernels_fused.hpp"
+#include "kernels_rowgemm.hpp"
 #include "tile_plan.hpp"
 
 namespace {
@@ -246,6 +247,41 @@ int uds_conv1d_causal(const float *x, int64_t B, int64_t T, int64_t R, int64_t F
   a.t_rows = (int)R;
   hipError_t e = uds::launch_dense_act(a, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(UDS_EHIP, "uds_conv1d_causal: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
+int64_t uds_rowgemm_packed_bytes(int64_t k_total, int64_t f_out) {
+  if (k_total <= 0 || k_total % 32 || f_out <= 0 || f_out > 64) return 0;
+  return (k_total / 32) * uds::rowgemm_mb((int)f_out) * 2 * 64 * 16;
+}
+
+int uds_rowgemm_pack(const float *W, int64_t k_total, int64_t f_out, void *packed, uds_stream_t stream) {
+  UDS_REQUIRE(W && packed && aligned16(packed), "uds_rowgemm_pack: NULL / misaligned argument");
+  UDS_REQUIRE(uds_rowgemm_packed_bytes(k_total, f_out) > 0, "uds_rowgemm_pack: needs K %% 32 == 0 and f_out <= 64 (K=%lld f_out=%lld)",
+              (long long)k_total, (long long)f_out);
+  const int mb = uds::rowgemm_mb((int)f_out);
+  const int total = (int)(k_total / 32) * mb * 64;
+  hipLaunchKernelGGL(uds::k_pack_weight_frags_padded, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), W,
+                     (int)k_total, (int)f_out, mb, reinterpret_cast<uint4 *>(packed));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_rowgemm_pack: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
+int uds_rowgemm_forward(const float *x, int64_t B, int64_t T, int64_t R, int64_t F, const void *packed, const float *bias,
+                        int64_t taps, int64_t dil, int64_t f_out, int act, float *out, uds_stream_t stream) {
+  UDS_REQUIRE(x && packed && out, "uds_rowgemm_forward: NULL x/packed/out");
+  UDS_REQUIRE(B >= 0 && T > 0 && R > 0 && F > 0 && F % 32 == 0 && taps > 0 && taps <= 16 && dil > 0 && f_out > 0 && f_out <= 64,
+              "uds_rowgemm_forward: needs F %% 32 == 0, f_out <= 64 (B=%lld T=%lld R=%lld F=%lld taps=%lld f_out=%lld)", (long long)B,
+              (long long)T, (long long)R, (long long)F, (long long)taps, (long long)f_out);
+  UDS_REQUIRE(act >= UDS_ACT_LINEAR && act <= UDS_ACT_HARD_SIGMOID, "uds_rowgemm_forward: unknown activation %d", act);
+  UDS_REQUIRE(aligned16(x) && aligned16(packed) && aligned16(out) && aligned16(bias), "uds_rowgemm_forward: pointers must be 16-byte aligned");
+  UDS_REQUIRE(B * T * R < INT32_MAX, "uds_rowgemm_forward: %lld rows exceed the int32 row index", (long long)(B * T * R));
+  if (B == 0) return UDS_OK;
+  uds::RowGemmArgs a{x, bias, reinterpret_cast<const uint4 *>(packed), out, B * T * R, (int)F, (int)taps, (int)dil, (int)T, (int)R,
+                     (int)f_out, act};
+  hipError_t e = uds::launch_rowgemm(a, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_rowgemm_forward: launch -> %s", hipGetErrorString(e));
   return UDS_OK;
 }
 

@@ -25,22 +25,29 @@ from torch import nn
 
 from . import _lib
 from .graph import DrainageGraph, csr_from_dense
-from .layers import Dense, SpatialBlock, _glorot_uniform, _param
+from .layers import Dense, SpatialBlock, _glorot_uniform, _packed_kernel, _param
 
 
 class Conv1D(nn.Module):
     """keras Conv1D(filters, kernel_size, padding='causal', dilation_rate, activation) along the time axis of
     x (B, T, R, F) -- the reference transposes to (B*R, T, F) first (emulator.py:244), this layout needs no transpose."""
 
-    def __init__(self, filters, kernel_size, dilation_rate=1, activation=None, in_features=None, generator=None):
+    def __init__(self, filters, kernel_size, dilation_rate=1, activation=None, in_features=None, generator=None,
+                 precision='fp32'):
         super().__init__()
         self.filters, self.kernel_size, self.dilation_rate = int(filters), int(kernel_size), int(dilation_rate)
+        self.precision = precision
         self.activation = activation or 'linear'
         self.kernel = _param(_glorot_uniform((self.kernel_size, int(in_features), self.filters), 'cpu', generator))
         self.bias = _param(torch.zeros(self.filters))
 
     def forward(self, x):
-        return _lib.conv1d_causal(x.contiguous(), self.kernel, self.bias, self.dilation_rate, self.activation)
+        x = x.contiguous()
+        k, f, h = self.kernel.shape
+        if self.precision == 'bf16x3' and _lib.rowgemm_supported(k * f, f, h):     # matrix-core path (split-bf16, 3 products)
+            return _lib.rowgemm_forward(x, _packed_kernel(self, self.kernel.reshape(k * f, h)), self.bias, h, self.activation,
+                                        taps=k, dilation=self.dilation_rate)
+        return _lib.conv1d_causal(x, self.kernel, self.bias, self.dilation_rate, self.activation)
 
 
 class Emulator(nn.Module):
@@ -91,15 +98,23 @@ class Emulator(nn.Module):
         if self.dropout:
             raise NotImplementedError('dropout > 0 (training-time) is not built')
 
-        adj = np.asarray(g('adj', np.eye(self.n_node)))
-        edge_adj = np.asarray(g('edge_adj', np.eye(self.n_edge)))
-        node_edge = np.asarray(g('node_edge'), dtype=np.float64)
-        self.graph = DrainageGraph.from_dense(adj, edge_adj, node_edge, self.edges)
-        if self.conv_kind == 'GCN':
-            from .layers import GCNConv
-            self.filter, self.edge_filter = GCNConv.preprocess(adj), GCNConv.preprocess(edge_adj)     # emulator.py:133-134
+        graph = g('graph')
+        if isinstance(graph, DrainageGraph):
+            # large networks: `args.graph` (CSR, e.g. DrainageGraph.from_edges) instead of the dense (N,N) / (E,E) / (N,E)
+            # matrices of `args.adj`, `args.edge_adj`, `args.node_edge`, which cannot exist at N >= 50k
+            if self.conv_kind != 'GAT':
+                raise NotImplementedError('args.graph (CSR input) is built for conv=GAT')
+            self.graph, self.filter, self.edge_filter, node_edge = graph, None, None, None
         else:
-            self.filter, self.edge_filter = (adj > 0).astype(int), (edge_adj > 0).astype(int)        # emulator.py:143-145
+            adj = np.asarray(g('adj', np.eye(self.n_node)))
+            edge_adj = np.asarray(g('edge_adj', np.eye(self.n_edge)))
+            node_edge = np.asarray(g('node_edge'), dtype=np.float64)
+            self.graph = DrainageGraph.from_dense(adj, edge_adj, node_edge, self.edges)
+            if self.conv_kind == 'GCN':
+                from .layers import GCNConv
+                self.filter, self.edge_filter = GCNConv.preprocess(adj), GCNConv.preprocess(edge_adj)     # emulator.py:133-134
+            else:
+                self.filter, self.edge_filter = (adj > 0).astype(int), (edge_adj > 0).astype(int)        # emulator.py:143-145
 
         # per-node / per-link physical constants (emulator.py:71-98), kept as float32 buffers
         vec = lambda k, n, d: torch.as_tensor(np.asarray(g(k, np.full(n, d)), dtype=np.float64), dtype=torch.float32)
@@ -107,13 +122,15 @@ class Emulator(nn.Module):
                            ('pump_out', self.n_node, 0.0), ('hmax', self.n_node, 1.5), ('hmin', self.n_node, 0.0),
                            ('ehmax', self.n_edge, 0.5), ('pump', self.n_edge, 0.0), ('offset', self.n_edge, 0.0)):
             self.register_buffer(name, vec(name, n, d), persistent=False)
-        self.register_buffer('node_edge', torch.as_tensor(node_edge, dtype=torch.float32), persistent=False)
+        # dense signed incidence: only the offset / pump branches of post_proc_tf use it (small networks)
+        self.register_buffer('node_edge', None if node_edge is None else torch.as_tensor(node_edge, dtype=torch.float32), persistent=False)
         self.register_buffer('_inc_sign', torch.as_tensor(self.graph.inc_n.val, dtype=torch.float32), persistent=False)
         self._inc_handle = None
         self._norms = {}
 
         d, h, H, L, gen = self.embed_size, self.embed_size // 2, self.hidden_dim, self.n_sp_layer, generator
         a = self.activation
+        pr = precision
         self.embed_x = Dense(d, 'linear', in_features=self.n_in, generator=gen)                 # emulator.py:198
         self.embed_b = Dense(h, a, in_features=self.b_in, generator=gen)                        # :203
         self.embed_e = Dense(d, 'linear', in_features=self.e_in, generator=gen)                 # :206
@@ -121,23 +138,23 @@ class Emulator(nn.Module):
         sp = self.n_node * self.n_edge > (1 << 24)
         self.block1 = SpatialBlock(self.graph, d, L, a, sparse_params=sp, generator=gen, precision=precision,
                                    conv=self.conv_kind, filters=(self.filter, self.edge_filter))                      # :219-235
-        tem = lambda f: nn.ModuleList([Conv1D(H, self.kernel_size, 2 ** i, a, in_features=(f if i == 0 else H), generator=gen)
+        tem = lambda f: nn.ModuleList([Conv1D(H, self.kernel_size, 2 ** i, a, in_features=(f if i == 0 else H), generator=gen, precision=pr)
                                        for i in range(self.n_tp_layer)])
         self.tem1_x, self.tem1_e = tem(d), tem(d)                                               # :247,254
         fx2, fe2 = H + h, H + (h if self.act else 0)
         self.block2 = SpatialBlock(self.graph, d, L, a, fx=fx2, fe=fe2, sparse_params=sp, generator=gen, precision=precision,
                                    conv=self.conv_kind, filters=(self.filter, self.edge_filter))                      # :272-288
         self.tem2_x, self.tem2_e = tem(d), tem(d)                                               # :302,308
-        self.res_x = Dense(d, 'linear' if self.resnet else a, in_features=H, generator=gen)     # :313 'dense_resx'
-        self.res_e = Dense(d, 'linear' if self.resnet else a, in_features=H, generator=gen)     # :317
-        self.out = Dense(self.n_out, 'hard_sigmoid', in_features=d, generator=gen)              # :324
+        self.res_x = Dense(d, 'linear' if self.resnet else a, in_features=H, generator=gen, precision=pr)     # :313 'dense_resx'
+        self.res_e = Dense(d, 'linear' if self.resnet else a, in_features=H, generator=gen, precision=pr)     # :317
+        self.out = Dense(self.n_out, 'hard_sigmoid', in_features=d, generator=gen, precision=pr)              # :324
         fl, fi = [], d
         for _ in range(self.if_flood):
-            fl.append(Dense(h, a, in_features=fi, generator=gen))                               # :329
+            fl.append(Dense(h, a, in_features=fi, generator=gen, precision=pr))                               # :329
             fi = h
         self.flood = nn.ModuleList(fl)
-        self.flood_out = Dense(1, 'sigmoid', in_features=fi, generator=gen) if self.if_flood else None      # :330
-        self.e_out_layer = Dense(self.e_out, 'tanh', in_features=d, generator=gen)              # :336
+        self.flood_out = Dense(1, 'sigmoid', in_features=fi, generator=gen, precision=pr) if self.if_flood else None      # :330
+        self.e_out_layer = Dense(self.e_out, 'tanh', in_features=d, generator=gen, precision=pr)              # :336
 
     # ------------------------------------------------------------------ network forward (build_network)
     def forward(self, X, B, E, AE=None):
@@ -237,7 +254,9 @@ class Emulator(nn.Module):
 
     def post_proc_tf(self, preds, a, b):
         preds, edge_preds = preds
-        pos = self.node_edge.clamp(0, 1)
+        if self.node_edge is None and (float(self.offset.max()) > 0 or (self.act and float(self.pump.min()) > 0)):
+            raise NotImplementedError('offset / pump gating needs the dense incidence (`args.node_edge`), not built for CSR-only networks')
+        pos = None if self.node_edge is None else self.node_edge.clamp(0, 1)
         if self.tide:
             h = preds[..., 0] * (1 - self.is_outfall) + b[..., -1]
             preds = torch.cat([h.unsqueeze(-1), preds[..., 1:]], dim=-1)
@@ -302,6 +321,8 @@ class Emulator(nn.Module):
         ey = torch.cat([torch.minimum(ey[..., 0].clamp(min=0), self.ehmax).unsqueeze(-1), ey[..., 1:]], dim=-1)
         y = self.normalize(y, 'y', True)
         if float(self.pump_in.sum() + self.pump_out.sum() + self.pump.sum()) > 0:       # pumped-storage depth (:630-638)
+            if self.node_edge is None:
+                raise NotImplementedError('pumped-storage depth needs the dense incidence (`args.node_edge`)')
             ps = ((self.area * torch.mv(self.node_edge.clamp(0, 1), self.pump)) > 0).float()
             h, qin, qout = y[..., 0], y[..., 1], y[..., 2]
             de = []

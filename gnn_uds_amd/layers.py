@@ -50,12 +50,26 @@ def _flatten_snapshots(x):
     return x.reshape((-1,) + tuple(x.shape[-2:])).contiguous(), lead
 
 
-class Dense(nn.Module):
-    """keras.layers.Dense(units, activation): act(x @ kernel + bias) on the last axis."""
+def _packed_kernel(module, kernel2d):
+    """bf16 hi/lo MFMA fragments of a (K, f_out) kernel, re-split only when the parameter changes."""
+    key = (module.kernel._version, module.kernel.data_ptr())
+    hit = getattr(module, '_packed', None)
+    if hit is None or hit[0] != key:
+        module._packed = (key, _lib.rowgemm_pack(kernel2d.contiguous()))
+    return module._packed[1]
 
-    def __init__(self, units, activation=None, use_bias=True, in_features=None, generator=None):
+
+class Dense(nn.Module):
+    """keras.layers.Dense(units, activation): act(x @ kernel + bias) on the last axis.
+
+    precision='fp32': exact-fp32 FMA kernel (any shape).  precision='bf16x3': matrix-core kernel (operands split into
+    bf16 hi + lo, 3 MFMA products, fp32 accumulate) when the input width is a multiple of 32 and units <= 64, the
+    exact kernel otherwise."""
+
+    def __init__(self, units, activation=None, use_bias=True, in_features=None, generator=None, precision='fp32'):
         super().__init__()
         self.units, self.activation, self.use_bias = int(units), activation or 'linear', use_bias
+        self.precision = precision
         self._gen = generator
         self.kernel = self.bias = None
         if self.activation not in _lib.ACT:
@@ -71,6 +85,9 @@ class Dense(nn.Module):
         if self.kernel is None:
             self.build(x.shape[-1], x.device)
         xc = x.contiguous()
+        fi = xc.shape[-1]
+        if self.precision == 'bf16x3' and _lib.rowgemm_supported(fi, fi, self.units):
+            return _lib.rowgemm_forward(xc, _packed_kernel(self, self.kernel), self.bias, self.units, self.activation)
         return _lib.dense_act(xc, self.kernel, self.bias, self.activation)
 
 

@@ -92,6 +92,16 @@ int uds_conv1d_causal(const float *x, int64_t B, int64_t T, int64_t R, int64_t F
                       const float *bias, int64_t taps, int64_t dil, int64_t H, int act, float *out,
                       uds_stream_t stream);
 
+/* Matrix-core version of uds_dense_act (taps = 1, T = 1: rows = B*R) and uds_conv1d_causal for F % 32 == 0 and
+ * f_out <= 64: operands split into bf16 hi + lo, three MFMA products, fp32 accumulation (the fused spatial kernel's
+ * numerics).  `packed` = uds_rowgemm_pack(W (taps*F, f_out)) -- uds_rowgemm_packed_bytes() bytes, once per
+ * parameter update.                                              emulator.py:155-157,313,317,324,329-330,336 */
+int64_t uds_rowgemm_packed_bytes(int64_t k_total, int64_t f_out);
+int uds_rowgemm_pack(const float *W, int64_t k_total, int64_t f_out, void *packed, uds_stream_t stream);
+int uds_rowgemm_forward(const float *x, int64_t B, int64_t T, int64_t R, int64_t F, const void *packed,
+                        const float *bias, int64_t taps, int64_t dil, int64_t f_out, int act, float *out,
+                        uds_stream_t stream);
+
 /* out[b,t,r,:] = act(cumsum_t(x)[b,t,r,:] + res[b,0,r,:]); x, out (B,T,R,F), res (B,1,R,F) or NULL; F % 4 == 0.
  * The resnet head of the emulator.                                          emulator.py:313-320 */
 int uds_cumsum_act(const float *x, const float *res, int64_t B, int64_t T, int64_t R, int64_t F, int act,

@@ -41,6 +41,27 @@ def test_conv1d_causal(dev, B, T, R, F, H, dil, act):
     close(_lib.conv1d_causal(f(x), f(k), f(b), dil, act), ref, 2e-5)
 
 
+@pytest.mark.parametrize('B,T,R,F,H,taps,dil,act', [(2, 5, 7, 64, 64, 3, 1, 'relu'), (1, 60, 3, 96, 64, 3, 4, 'relu'), (3, 4, 50, 64, 32, 3, 2, 'tanh'),
+                                                    (1, 1, 1000, 64, 64, 1, 1, 'linear'), (1, 1, 333, 32, 1, 1, 1, 'sigmoid'), (2, 3, 40, 64, 3, 1, 1, 'tanh'),
+                                                    (1, 1, 97, 64, 32, 1, 1, 'relu')])
+def test_rowgemm_mfma_dense_and_conv(dev, B, T, R, F, H, taps, dil, act):
+    """Matrix-core Dense / causal Conv1D (split-bf16, 3 products): tolerance 2e-4 * max(1, max|ref|)."""
+    g = torch.Generator().manual_seed(T + R)
+    x, k, b = rnd(g, B, T, R, F) - 0.5, rnd(g, taps, F, H) - 0.5, rnd(g, H) - 0.5
+    if taps == 1:
+        ref = OD.dense(x, k[0], b, act)
+    else:
+        ref = OE.conv1d_causal(x.permute(0, 2, 1, 3).reshape(B * R, T, F), k, b, dil, act).reshape(B, R, T, H).permute(0, 2, 1, 3)
+    f = lambda t: t.float().to(dev)
+    packed = _lib.rowgemm_pack(f(k).reshape(taps * F, H))
+    close(_lib.rowgemm_forward(f(x), packed, f(b), H, act, taps=taps, dilation=dil), ref, 2e-4)
+    close(_lib.rowgemm_forward(f(x), packed, None, H, 'linear', taps=taps, dilation=dil) if taps == 1 else
+          _lib.rowgemm_forward(f(x), packed, None, H, 'linear', taps=taps, dilation=dil),
+          OD.dense(x, k[0], None) if taps == 1 else
+          OE.conv1d_causal(x.permute(0, 2, 1, 3).reshape(B * R, T, F), k, torch.zeros(H, dtype=torch.float64), dil, 'linear').reshape(B, R, T, H).permute(0, 2, 1, 3),
+          2e-4)
+
+
 def test_cumsum_act_and_flow_balance(dev, networks):
     g = torch.Generator().manual_seed(1)
     x, res = rnd(g, 2, 6, 9, 8) - 0.5, rnd(g, 2, 1, 9, 8) - 0.5
