@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "kernels_fused.hpp"
 
 namespace uds {
@@ -21,6 +23,7 @@ struct RowGemmArgs {
   float *out;
   int64_t rows;
   int F, taps, dil, T, t_rows, fo, act;   // A row = taps x F floats, K = taps * F (multiple of 32)
+  int seg;                  // seg > 0: XCD-aware mapping (see k_rowgemm_mfma), else consecutive wave-tiles
 };
 
 // Pack with zero padding of the output features up to mb*16 (heads have 1..3 outputs).
@@ -42,115 +45,250 @@ __global__ void k_pack_weight_frags_padded(const float *__restrict__ W, int K, i
   out[((t * MB + m) * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
 }
 
-template <int MB, int NB>
-__global__ __launch_bounds__(256, 2) void k_rowgemm_mfma(RowGemmArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// Two 1-KiB LDS-DMA pieces in one statement (one k-step of one 16-row block): src0 -> lds_byte, src1 -> +1 KiB.
+__device__ __forceinline__ void glds16_pair(const float *src0, const float *src1, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+               "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(src0), "v"(src1), "s"(lds_byte)
+               : "memory", "scc");
+}
+
+// Persistent 8-wave workgroups, one per CU.  LDS: the packed weights of every k-step and the bias (staged once per
+// workgroup) | per wave a ring of RING 2-KiB slots filled by LDS-DMA in fragment order (the lane that issues a 16-B
+// piece reads it back, so the wave's own counted vmcnt is the only synchronisation) | per wave a 16 x 32 tile that
+// turns accumulators into whole output rows.  A wave owns a stream of 64-row wave-tiles; a "piece" is one k-step (32
+// of the K values) of one 16-row block, and the wave keeps RING-1 future pieces in flight -- across k-steps, blocks
+// AND wave-tiles -- while it splits and multiplies the current one, so the prologue / epilogue of a tile overlaps
+// the fetch of the next.  No VGPRs are spent on prefetch and the loop has no compiler-visible vector-memory loads
+// (weights and bias come from LDS), so nothing but the counted waits below touches the DMA queue.
+//
+// vmcnt bookkeeping: every trip issues exactly one piece (2 DMA instructions; past the end of the stream it re-fetches
+// the last tile, so the count never changes) and then waits for vmcnt <= 2 (RING-1).  The output stores of a finished
+// tile are younger than the pieces already in flight, so this wait is at worst conservative (it may also wait for some
+// stores), never too weak.
+template <int MB, int NB, int RING>
+__global__ __launch_bounds__(512, 2) void k_rowgemm_mfma(RowGemmArgs a) {
+  static_assert(RING - 1 <= NB && RING >= 2, "the ring may reach at most one k-step ahead");
+  constexpr int CG = MB >= 2 ? 2 : 1;            // accumulator fragments per transposed store group (32 columns)
+  constexpr int LD = 16 * CG + 4;                // padded tile row (floats)
+  extern __shared__ __attribute__((aligned(16))) float smem_rg[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, qd = lane >> 4;
-  const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * (NB * 16);
-  if (base >= a.rows) return;
   const int KT = a.taps * a.F / 32;
+  const int n_w = KT * MB * 2 * 64;             // uint4 entries of the packed weights
+  uint4 *wlds = reinterpret_cast<uint4 *>(smem_rg);
+  float *bias_s = smem_rg + n_w * 4;
+  float *ring = bias_s + 64 + wave * (RING * 512);
+  float *tile = bias_s + 64 + 8 * (RING * 512) + wave * (16 * LD);
+  for (int i = tid; i < n_w; i += 512) wlds[i] = a.packed[i];
+  if (tid < 64) bias_s[tid] = (a.bias && tid < a.fo) ? a.bias[tid] : 0.f;
+  __syncthreads();
 
-  f32x4 acc[NB][MB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int m = 0; m < MB; ++m) acc[b][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // per block: this lane's row and its time index (for the causal zero padding)
-  int row[NB], tix[NB];        // rows < 2^31 (checked by the launcher)
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    row[b] = (int)min(base + b * 16 + r16, a.rows - 1);
-    tix[b] = (row[b] / a.t_rows) % a.T;
+  // The wave's stream of 64-row wave-tiles.  Linear: tile w = rows [64 w, 64 (w+1)).  XCD-aware (causal conv, seg > 0):
+  // workgroups go round-robin to the 8 XCDs, so XCD x = blockIdx % 8 takes the row range [x seg, (x+1) seg) of EVERY
+  // time slab and walks the slabs in time order -- the shifted rows of the earlier taps were fetched by the same XCD a
+  // few slabs before and are still in its L2, instead of crossing the fabric once per tap.
+  int w, w_stride, w_total, wt_x = 1, n_lo = 0, n_hi = 0;
+  if (a.seg > 0) {
+    const int xcd = blockIdx.x & 7;
+    n_lo = xcd * a.seg;
+    n_hi = min(a.t_rows, n_lo + a.seg);
+    wt_x = max(0, (n_hi - n_lo + NB * 16 - 1) / (NB * 16));
+    w_total = (int)(a.rows / a.t_rows) * wt_x;
+    w = (blockIdx.x >> 3) * 8 + wave;
+    w_stride = (gridDim.x >> 3) * 8;
+  } else {
+    w_total = (int)((a.rows + NB * 16 - 1) / (NB * 16));
+    w = blockIdx.x * 8 + wave;
+    w_stride = gridDim.x * 8;
   }
-  auto load = [&](int b, int t, float4 &v0, float4 &v1) {
+  if (w >= w_total) return;
+  auto locate = [&](int wt, int &base, int &nv) {       // first row and number of existing rows of wave-tile wt
+    if (a.seg > 0) {
+      const int slab = wt / wt_x, k = wt - slab * wt_x;
+      const int n0 = n_lo + k * (NB * 16);
+      base = slab * a.t_rows + n0;
+      nv = min(NB * 16, n_hi - n0);
+    } else {
+      base = wt * (NB * 16);
+      nv = (int)min<int64_t>(NB * 16, a.rows - base);
+    }
+  };
+  auto lane_rows = [&](int base, int nv, int (&row)[NB], int (&tix)[NB]) {   // rows < 2^31 (checked by the launcher)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      row[b] = base + min(b * 16 + r16, nv - 1);
+      tix[b] = (row[b] / a.t_rows) % a.T;
+    }
+  };
+  const unsigned my_lds = __builtin_amdgcn_readfirstlane(lds_addr(ring));
+  // piece (k-step t, row rw at time index tx): two 1-KiB halves.  A row before t = 0 of the causal window is fetched
+  // from the row itself (always in bounds) and zeroed at use.
+  auto live_of = [&](int t, int tx) { return tx >= (a.taps - 1 - (32 * t) / a.F) * a.dil; };
+  auto issue = [&](int t, int rw, int tx, int slot) {
     const int k0 = 32 * t;
     const int j = k0 / a.F, f0 = k0 - j * a.F;
     const int shift = (a.taps - 1 - j) * a.dil;
-    const bool live = tix[b] >= shift;
-    const float *src = a.x + (int64_t)(row[b] - (live ? shift * a.t_rows : 0)) * a.F + f0 + 4 * qd;
-    v0 = *reinterpret_cast<const float4 *>(src);
-    v1 = *reinterpret_cast<const float4 *>(src + 16);
-    if (!live) v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *src = a.x + (int64_t)(rw - (tx >= shift ? shift * a.t_rows : 0)) * a.F + f0 + 4 * qd;
+    glds16_pair(src, src + 16, my_lds + (unsigned)slot * 2048);
   };
 
-  for (int t0 = 0; t0 < KT; t0 += 2) {           // 64-wide K chunk (the last one may be 32 wide)
-    const int nt = min(2, KT - t0);
-    bf16x8 wh[2][MB], wl[2][MB];
+  int base, nv, row[NB], tix[NB];
+  locate(w, base, nv);
+  lane_rows(base, nv, row, tix);
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+  for (int q = 0; q < RING - 1; ++q) issue(0, row[q], tix[q], q);
+  int cs = 0;                                     // ring slot of the piece consumed next
+
+  for (; w < w_total; w += w_stride) {
+    const int wn = w + w_stride < w_total ? w + w_stride : w;     // past the end: dummy re-fetch of this tile
+    int base_n, nv_n, row_n[NB], tix_n[NB];
+    locate(wn, base_n, nv_n);
+    lane_rows(base_n, nv_n, row_n, tix_n);
+    f32x4 acc[NB][MB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int m = 0; m < MB; ++m) acc[b][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int t = 0; t < KT; ++t) {
+      bf16x8 wh[MB], wl[MB];
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
-        const int t = min(t0 + tt, KT - 1);
-        wh[tt][m] = __builtin_bit_cast(bf16x8, a.packed[((t * MB + m) * 2 + 0) * 64 + lane]);
-        wl[tt][m] = __builtin_bit_cast(bf16x8, a.packed[((t * MB + m) * 2 + 1) * 64 + lane]);
+        wh[m] = __builtin_bit_cast(bf16x8, wlds[((t * MB + m) * 2 + 0) * 64 + lane]);
+        wl[m] = __builtin_bit_cast(bf16x8, wlds[((t * MB + m) * 2 + 1) * 64 + lane]);
       }
-    float4 cur[4], nxt[4];
-    load(0, t0, cur[0], cur[1]);
-    if (nt == 2) load(0, t0 + 1, cur[2], cur[3]);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        // refill the slot the previous trip left: piece RING-1 ahead (this tile's next k-step, or the next tile's first)
+        constexpr int dummy_fb = 0;
+        (void)dummy_fb;
+        const int fb = (b + RING - 1) % NB, ft = t + (b + RING - 1) / NB;
+        int rs = cs + (RING - 1);
+        rs = rs >= RING ? rs - RING : rs;
+        if (ft < KT) issue(ft, row[fb], tix[fb], rs);
+        else issue(ft - KT, row_n[fb], tix_n[fb], rs);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (RING - 1)) : "memory");
+        const float4 *st = reinterpret_cast<const float4 *>(ring + cs * 512) + lane;
+        float4 v0 = st[0], v1 = st[64];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // slot consumed before the next trip refills it
+        cs = cs + 1 == RING ? 0 : cs + 1;
+        if (!live_of(t, tix[b])) v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        bf16x8 dh, dl;
+        split8(v0, v1, dh, dl);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc[b][m] = mfma3(wh[m], wl[m], dh, dl, acc[b][m]);
+      }
+    }
+
+    // ---- epilogue: bias + activation, whole-row stores ----
+    if (a.fo == 16 * MB && MB >= 2) {
+      // turn each 16 x 32 accumulator pair through the wave's tile so that one store instruction writes 8 rows x 128 B
+      // (whole cache lines; 1 KiB contiguous when fo = 32) instead of sixteen 64-byte pieces
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int g = 0; g < MB / CG; ++g) {
+#pragma unroll
+          for (int mm = 0; mm < CG; ++mm) {
+            const int m = g * CG + mm;
+            const f32x4 bb = *reinterpret_cast<const f32x4 *>(bias_s + 16 * m + 4 * qd);
+            f32x4 o = acc[b][m];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = apply_act(o[j] + bb[j], a.act);
+            *reinterpret_cast<f32x4 *>(tile + r16 * LD + 16 * mm + 4 * qd) = o;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int rr = i * 8 + (lane >> 3), cc = 4 * (lane & 7);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(tile + rr * LD + cc);
+            if (b * 16 + rr < nv) *reinterpret_cast<f32x4 *>(a.out + (int64_t)(base + b * 16 + rr) * a.fo + 32 * g + cc) = v;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    } else {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int64_t r = (int64_t)base + b * 16 + r16;
+        if (b * 16 + r16 >= nv) continue;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          const int c0 = 16 * m + 4 * qd;
+          f32x4 o = acc[b][m];
+          if ((a.fo & 3) == 0) {
+            if (c0 < a.fo) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) o[j] = apply_act(o[j] + bias_s[c0 + j], a.act);
+              *reinterpret_cast<f32x4 *>(a.out + r * a.fo + c0) = o;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (c0 + j < a.fo) a.out[r * a.fo + c0 + j] = apply_act(o[j] + bias_s[c0 + j], a.act);
+          }
+        }
+      }
+    }
+    base = base_n;
+    nv = nv_n;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      if (b + 1 < NB) {                          // next block's rows are in flight while this one is multiplied
-        load(b + 1, t0, nxt[0], nxt[1]);
-        if (nt == 2) load(b + 1, t0 + 1, nxt[2], nxt[3]);
-      }
-      bf16x8 dh, dl;
-      split8(cur[0], cur[1], dh, dl);
-#pragma unroll
-      for (int m = 0; m < MB; ++m) acc[b][m] = mfma3(wh[0][m], wl[0][m], dh, dl, acc[b][m]);
-      if (nt == 2) {
-        split8(cur[2], cur[3], dh, dl);
-#pragma unroll
-        for (int m = 0; m < MB; ++m) acc[b][m] = mfma3(wh[1][m], wl[1][m], dh, dl, acc[b][m]);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+      row[b] = row_n[b];
+      tix[b] = tix_n[b];
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the dummy pieces land before the LDS is released
+}
 
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int64_t r = base + b * 16 + r16;
-    if (r >= a.rows) continue;
-#pragma unroll
-    for (int m = 0; m < MB; ++m) {
-      const int c0 = 16 * m + 4 * qd;
-      f32x4 o = acc[b][m];
-      if ((a.fo & 3) == 0) {
-        if (c0 < a.fo) {
-          if (a.bias) {
-            const f32x4 bb = *reinterpret_cast<const f32x4 *>(a.bias + c0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] += bb[j];
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = apply_act(o[j], a.act);
-          *reinterpret_cast<f32x4 *>(a.out + r * a.fo + c0) = o;
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (c0 + j < a.fo) a.out[r * a.fo + c0 + j] = apply_act(o[j] + (a.bias ? a.bias[c0 + j] : 0.f), a.act);
-      }
-    }
+inline int64_t rowgemm_lds_bytes(int K, int MB, int ring) {
+  const int cg = MB >= 2 ? 2 : 1;
+  return (int64_t)(K / 32) * MB * 2 * 1024 + 256 + 8 * ring * 2048 + 8 * 16 * (16 * cg + 4) * 4;
+}
+// deepest ring (5, else 3) that fits the LDS next to the weights; 0 = the weights alone are too large
+inline int rowgemm_ring(int K, int MB) {
+  if (rowgemm_lds_bytes(K, MB, 5) <= 160 * 1024) return 5;
+  if (rowgemm_lds_bytes(K, MB, 3) <= 160 * 1024) return 3;
+  return 0;
+}
+
+template <int MB, int NB, int RING>
+inline hipError_t launch_rowgemm_r(const RowGemmArgs &a, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowgemm_mfma<MB, NB, RING>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
   }
+  constexpr int64_t WT = NB * 16;                          // rows of a wave-tile
+  const int64_t lds = rowgemm_lds_bytes(a.taps * a.F, MB, RING);
+  RowGemmArgs b = a;
+  b.seg = 0;
+  int64_t grid = std::min<int64_t>(256, ((a.rows + WT - 1) / WT + 7) / 8);      // one persistent workgroup per CU
+  if (a.taps > 1 && a.t_rows >= 64 * WT) {                 // a slab wide enough to give every XCD several wave-tiles
+    b.seg = (int)(((a.t_rows + 7) / 8 + 15) / 16 * 16);
+    grid = 256;
+  }
+  hipLaunchKernelGGL((k_rowgemm_mfma<MB, NB, RING>), dim3((unsigned)grid), dim3(512), (size_t)lds, st, b);
+  return hipGetLastError();
 }
 
 template <int MB, int NB>
 inline hipError_t launch_rowgemm_t(const RowGemmArgs &a, hipStream_t st) {
-  const int64_t rows_per_wg = 4 * NB * 16;
-  hipLaunchKernelGGL((k_rowgemm_mfma<MB, NB>), dim3((unsigned)((a.rows + rows_per_wg - 1) / rows_per_wg)), dim3(256), 0, st, a);
-  return hipGetLastError();
+  return rowgemm_ring(a.taps * a.F, MB) == 5 ? launch_rowgemm_r<MB, NB, 5>(a, st) : launch_rowgemm_r<MB, NB, 3>(a, st);
 }
 
 inline int rowgemm_mb(int fo) { return fo <= 16 ? 1 : (fo <= 32 ? 2 : 4); }
 
 inline hipError_t launch_rowgemm(const RowGemmArgs &a, hipStream_t st) {
   switch (rowgemm_mb(a.fo)) {
-    case 1: return launch_rowgemm_t<1, 8>(a, st);
-    case 2: return launch_rowgemm_t<2, 8>(a, st);
-    default: return launch_rowgemm_t<4, 6>(a, st);
+    case 1: return launch_rowgemm_t<1, 4>(a, st);
+    case 2: return launch_rowgemm_t<2, 4>(a, st);
+    default: return launch_rowgemm_t<4, 4>(a, st);
   }
 }
 

@@ -43,7 +43,9 @@ def test_conv1d_causal(dev, B, T, R, F, H, dil, act):
 
 @pytest.mark.parametrize('B,T,R,F,H,taps,dil,act', [(2, 5, 7, 64, 64, 3, 1, 'relu'), (1, 60, 3, 96, 64, 3, 4, 'relu'), (3, 4, 50, 64, 32, 3, 2, 'tanh'),
                                                     (1, 1, 1000, 64, 64, 1, 1, 'linear'), (1, 1, 333, 32, 1, 1, 1, 'sigmoid'), (2, 3, 40, 64, 3, 1, 1, 'tanh'),
-                                                    (1, 1, 97, 64, 32, 1, 1, 'relu')])
+                                                    (1, 1, 97, 64, 32, 1, 1, 'relu'),
+                                                    # slabs wide enough for the XCD-aware row mapping (R >= 4096), ragged XCD ranges
+                                                    (1, 6, 4133, 64, 64, 3, 2, 'relu'), (2, 3, 4096, 32, 32, 3, 1, 'linear')])
 def test_rowgemm_mfma_dense_and_conv(dev, B, T, R, F, H, taps, dil, act):
     """Matrix-core Dense / causal Conv1D (split-bf16, 3 products): tolerance 2e-4 * max(1, max|ref|)."""
     g = torch.Generator().manual_seed(T + R)
