@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libuds_hip.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
 PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
 
@@ -45,6 +45,9 @@ SYMBOLS = {
     'uds_gat_workspace_floats': (_c_i64, [_c_i64, _c_i64, _c_i64]),
     'uds_gat_forward': (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                  _c_int, _c_ptr, _c_ptr, _c_ptr]),
+    'uds_gat_backward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr,
+                                  _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
+    'uds_csr_sddmm': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
     'uds_network_create': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, ctypes.POINTER(_c_ptr)]),
     'uds_network_destroy': (_c_int, [_c_ptr]),
     'uds_network_plan_info': (_c_int, [_c_ptr, _c_ptr]),
@@ -115,6 +118,13 @@ def _dev(t, name, allow_none=False):
     return t.data_ptr()
 
 
+def _dev_i32(t, name):
+    """Device pointer of a contiguous int32 HIP tensor (index lists of the backward kernels)."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.int32 or not t.is_contiguous():
+        raise UdsError('%s must be a contiguous int32 HIP tensor' % name)
+    return t.data_ptr()
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -131,6 +141,32 @@ class CsrHandle:
         _check(lib.uds_csr_create(rowptr.ctypes.data, col.ctypes.data, self.n_rows, self.n_cols, self.nnz,
                                   ctypes.byref(h)), 'uds_csr_create')
         self._h = h
+        self._rowptr, self._col = rowptr, col
+        self._t = None
+
+    def transposed(self, device):
+        """(handle of the transposed pattern, perm_t): perm_t[p] (int32 device tensor) = position in THIS pattern's
+        row-major order of entry p of the transposed pattern.  Integer bookkeeping for the backward kernels, built once."""
+        if self._t is None:
+            rows = np.repeat(np.arange(self.n_rows, dtype=np.int64), np.diff(self._rowptr.astype(np.int64)))
+            cols = self._col.astype(np.int64)
+            order = np.lexsort((rows, cols))                  # by column, then row: the transpose in row-major order
+            t_rowptr = np.zeros(self.n_cols + 1, dtype=np.int64)
+            np.add.at(t_rowptr, cols + 1, 1)
+            t_rowptr = np.cumsum(t_rowptr)
+
+            class _T:      # what CsrHandle.__init__ reads
+                pass
+            t = _T()
+            t.n_rows, t.n_cols, t.nnz = self.n_cols, self.n_rows, self.nnz
+            t.rowptr, t.col = t_rowptr.astype(np.int32), rows[order].astype(np.int32)
+            self._t = (CsrHandle(t), order.astype(np.int32))
+        h, perm = self._t
+        if not isinstance(perm, torch.Tensor) or perm.device != torch.device(device):
+            perm = torch.as_tensor(np.asarray(perm.cpu() if isinstance(perm, torch.Tensor) else perm), dtype=torch.int32,
+                                   device=device)
+            self._t = (h, perm)
+        return h, perm
 
     @property
     def ptr(self):
@@ -341,8 +377,10 @@ def csr_spmm(handle, val, x, bias=None, act='linear'):
     return out
 
 
-def gat_forward(handle, xa, kernel, a_self, a_nbr, bias=None, act='relu', xb=None):
-    """Single-head GATConv over a CSR pattern with self loops; xa:(S,n,fa) [| xb:(S,n,fb)] -> (S,n,d)."""
+def gat_forward(handle, xa, kernel, a_self, a_nbr, bias=None, act='relu', xb=None, return_workspace=False):
+    """Single-head GATConv over a CSR pattern with self loops; xa:(S,n,fa) [| xb:(S,n,fb)] -> (S,n,d).
+    return_workspace=True also returns (hx (S,n,d), s_self (S,n), s_nbr (S,n)) -- views of the workspace, for the
+    backward pass."""
     lib = load()
     if xa.dim() != 3 or xa.shape[1] != handle.n_rows:
         raise UdsError('x must be (S,%d,F), got %r' % (handle.n_rows, tuple(xa.shape)))
@@ -359,6 +397,44 @@ def gat_forward(handle, xa, kernel, a_self, a_nbr, bias=None, act='relu', xb=Non
     _check(lib.uds_gat_forward(handle.ptr, _dev(xa, 'xa'), fa, _dev(xb, 'xb', True), fb, S, _dev(kernel, 'kernel'),
                                _dev(a_self, 'a_self'), _dev(a_nbr, 'a_nbr'), _dev(bias, 'bias', True), d, ACT[act],
                                _dev(ws, 'workspace'), _dev(out, 'out'), _stream()), 'uds_gat_forward')
+    if return_workspace:
+        m = S * n
+        return out, (ws[:m * d].view(S, n, d), ws[m * d:m * d + m].view(S, n), ws[m * d + m:m * d + 2 * m].view(S, n))
+    return out
+
+
+def gat_backward(handle, handle_t, perm_t, grad, hx, s_self, s_nbr, a_self, a_nbr):
+    """Reverse mode of the attention / aggregation part of gat_forward (uds_gat_backward): grad = dL/d(pre-activation)
+    (S,n,d) -> d_hx (S,n,d), ds_self (S,n), ds_nbr (S,n)."""
+    lib = load()
+    S, n, d = grad.shape
+    d_hx = torch.empty_like(grad)
+    ds_self = torch.empty((S, n), device=grad.device, dtype=torch.float32)
+    ds_nbr = torch.empty_like(ds_self)
+    if grad.numel() == 0:
+        _dev(grad, 'grad')
+        return d_hx, ds_self, ds_nbr
+    ws = torch.empty((2, S, max(handle.nnz, 1)), device=grad.device, dtype=torch.float32)
+    _check(lib.uds_gat_backward(handle.ptr, handle_t.ptr, _dev_i32(perm_t, 'perm_t'), _dev(grad, 'grad'), _dev(hx, 'hx'),
+                                _dev(s_self, 's_self'), _dev(s_nbr, 's_nbr'), _dev(a_self, 'a_self'), _dev(a_nbr, 'a_nbr'),
+                                S, d, _dev(ws[0], 'alpha_ws'), _dev(ws[1], 'de_ws'), _dev(d_hx, 'd_hx'),
+                                _dev(ds_self, 'ds_self'), _dev(ds_nbr, 'ds_nbr'), _stream()), 'uds_gat_backward')
+    return d_hx, ds_self, ds_nbr
+
+
+def csr_sddmm(handle, a, b):
+    """out[k] = sum_s <a[s,row(k),:], b[s,col(k),:]> per pattern entry; a:(S,n_rows,F), b:(S,n_cols,F) -> (nnz,)."""
+    lib = load()
+    if a.dim() != 3 or b.dim() != 3 or a.shape[1] != handle.n_rows or b.shape[1] != handle.n_cols or a.shape[0] != b.shape[0] \
+            or a.shape[2] != b.shape[2]:
+        raise UdsError('sddmm: a must be (S,%d,F) and b (S,%d,F), got %r, %r' % (handle.n_rows, handle.n_cols, tuple(a.shape),
+                                                                               tuple(b.shape)))
+    out = torch.zeros(handle.nnz, device=a.device, dtype=torch.float32)
+    if handle.nnz == 0 or a.numel() == 0:
+        _dev(a, 'a')
+        return out
+    _check(lib.uds_csr_sddmm(handle.ptr, _dev(a, 'a'), _dev(b, 'b'), a.shape[0], a.shape[2], _dev(out, 'out'), _stream()),
+           'uds_csr_sddmm')
     return out
 
 

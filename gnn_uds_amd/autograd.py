@@ -1,0 +1,223 @@
+"""Reverse mode for the HIP operators: `torch.autograd.Function` wrappers around the C ABI.
+
+The reference trains through `tf.GradientTape` over the whole Keras model (`emulator.py:457-484`); here every HIP
+operator of the forward carries its own backward, so `loss.backward()` on an `Emulator` output reaches all parameters:
+
+    DenseFn        keras Dense                     dX = row GEMM with the transposed kernel (HIP), dW = X^T dZ (plain GEMM)
+    Conv1DFn       causal dilated Conv1D           dX = the same kernels looking AHEAD (dilation < 0) with transposed taps
+    SpmmFn         NodeEdge on its support / GCN   dX = spmm on the transposed pattern, dval = uds_csr_sddmm
+    GatFn          MixedGAT(GATConv)               uds_gat_backward (softmax / leaky-relu / aggregation), then Dense rules
+    CumsumActFn    relu(cumsum_T(x) + res)         reverse cumulative sum
+    FlowBalanceFn  post_proc_tf incidence sums     gather along the link end nodes
+    SpatialLayerFn the fused spatial layer forward, backward through the unfused chain above (intermediates recomputed)
+
+Weight gradients are plain GEMMs with a huge reduction dimension (rows) and tiny outputs: they go to rocBLAS through
+`torch.mm` (a library GEMM, not a hot-path kernel).  Activations are differentiated from their outputs.
+"""
+import torch
+
+from . import _lib
+
+
+def act_grad(y, gy, act):
+    """dL/dz from dL/dy for y = act(z), using only y (every activation here is invertible enough for that)."""
+    act = act or 'linear'
+    if act == 'linear':
+        return gy
+    if act == 'relu':
+        return gy * (y > 0).to(gy.dtype)
+    if act == 'tanh':
+        return gy * (1.0 - y * y)
+    if act == 'sigmoid':
+        return gy * y * (1.0 - y)
+    if act == 'hard_sigmoid':
+        return gy * 0.2 * ((y > 0) & (y < 1)).to(gy.dtype)
+    raise ValueError('unknown activation %r' % (act,))
+
+
+def rows_matmul(x, w, precision='bf16x3'):
+    """x (..., K) @ w (K, M) on the HIP row-GEMM kernels (matrix cores where the shape allows, in <= 64-column pieces)."""
+    x = x.contiguous()
+    K, M = w.shape
+    lead = x.shape[:-1]
+    x3 = x.reshape(1, -1, K)
+    if precision == 'bf16x3' and K % 32 == 0:
+        outs = []
+        for c0 in range(0, M, 64):
+            wc = w[:, c0:c0 + 64].contiguous()
+            if not _lib.rowgemm_supported(K, K, wc.shape[1]):
+                outs = None
+                break
+            outs.append(_lib.rowgemm_forward(x3, _lib.rowgemm_pack(wc), None, wc.shape[1], 'linear'))
+        if outs is not None:
+            out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=-1)
+            return out.reshape(lead + (M,))
+    return _lib.dense_act(x3, w.contiguous(), None, 'linear').reshape(lead + (M,))
+
+
+class DenseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, bias, module, act):
+        xc = x.contiguous()
+        fi = xc.shape[-1]
+        if module.precision == 'bf16x3' and _lib.rowgemm_supported(fi, fi, module.units):
+            from .layers import _packed_kernel
+            y = _lib.rowgemm_forward(xc, _packed_kernel(module, kernel), bias, module.units, act)
+        else:
+            y = _lib.dense_act(xc, kernel, bias, act)
+        ctx.save_for_backward(xc, kernel, y)
+        ctx.act, ctx.precision, ctx.has_bias = act, module.precision, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, kernel, y = ctx.saved_tensors
+        gz = act_grad(y, gy.contiguous(), ctx.act)
+        g2 = gz.reshape(-1, gz.shape[-1])
+        dx = rows_matmul(gz, kernel.t(), ctx.precision) if ctx.needs_input_grad[0] else None
+        dw = x.reshape(-1, x.shape[-1]).t().mm(g2) if ctx.needs_input_grad[1] else None
+        db = g2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None
+
+
+class Conv1DFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, bias, module):
+        xc = x.contiguous()
+        k, f, h = kernel.shape
+        if module.precision == 'bf16x3' and _lib.rowgemm_supported(k * f, f, h):
+            from .layers import _packed_kernel
+            y = _lib.rowgemm_forward(xc, _packed_kernel(module, kernel.reshape(k * f, h)), bias, h, module.activation, taps=k,
+                                     dilation=module.dilation_rate)
+        else:
+            y = _lib.conv1d_causal(xc, kernel, bias, module.dilation_rate, module.activation)
+        ctx.save_for_backward(xc, kernel, y)
+        ctx.act, ctx.precision, ctx.dil = module.activation, module.precision, module.dilation_rate
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, kernel, y = ctx.saved_tensors
+        k, f, h = kernel.shape
+        B, T, R, _ = x.shape
+        gz = act_grad(y, gy.contiguous(), ctx.act).contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            kt = kernel.transpose(1, 2).contiguous()                 # (k, h, f): tap j -> W_j^T
+            if ctx.precision == 'bf16x3' and _lib.rowgemm_supported(k * h, h, f):
+                dx = _lib.rowgemm_forward(gz, _lib.rowgemm_pack(kt.reshape(k * h, f)), None, f, 'linear', taps=k, dilation=-ctx.dil)
+            else:
+                dx = _lib.conv1d_causal(gz, kt, None, -ctx.dil, 'linear')
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(kernel)
+            for j in range(k):
+                s = (k - 1 - j) * ctx.dil
+                if s < T:
+                    dw[j] = x[:, :T - s].reshape(-1, f).t().mm(gz[:, s:].reshape(-1, h))
+        if ctx.needs_input_grad[2]:
+            db = gz.reshape(-1, h).sum(0)
+        return dx, dw, db, None
+
+
+class SpmmFn(torch.autograd.Function):
+    """out = A(val) @ x on a CSR pattern (no bias / activation: NodeEdge on its support)."""
+
+    @staticmethod
+    def forward(ctx, val, x, handle):
+        xc = x.contiguous()
+        ctx.save_for_backward(val, xc)
+        ctx.handle = handle
+        return _lib.csr_spmm(handle, val, xc)
+
+    @staticmethod
+    def backward(ctx, g):
+        val, x = ctx.saved_tensors
+        g = g.contiguous()
+        dval = dx = None
+        if ctx.needs_input_grad[1]:
+            ht, perm = ctx.handle.transposed(g.device)
+            dx = _lib.csr_spmm(ht, val[perm.long()].contiguous(), g)
+        if ctx.needs_input_grad[0]:
+            dval = _lib.csr_sddmm(ctx.handle, g, x)
+        return dval, dx, None
+
+
+class GatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xa, xb, kernel, a_self, a_nbr, bias, act, handle, precision):
+        xa = xa.contiguous()
+        xb = None if xb is None else xb.contiguous()
+        out, (hx, s_self, s_nbr) = _lib.gat_forward(handle, xa, kernel, a_self, a_nbr, bias, act, xb, return_workspace=True)
+        ctx.save_for_backward(xa, xb, kernel, a_self, a_nbr, out, hx, s_self, s_nbr)
+        ctx.act, ctx.handle, ctx.precision, ctx.has_bias = act, handle, precision, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        xa, xb, kernel, a_self, a_nbr, out, hx, s_self, s_nbr = ctx.saved_tensors
+        S, n, d = out.shape
+        g = act_grad(out, gout.contiguous(), ctx.act).contiguous()
+        ht, perm = ctx.handle.transposed(g.device)
+        d_hx, ds_self, ds_nbr = _lib.gat_backward(ctx.handle, ht, perm, g, hx, s_self, s_nbr, a_self.reshape(-1).contiguous(),
+                                                  a_nbr.reshape(-1).contiguous())
+        hx2, dh2 = hx.reshape(-1, d), d_hx.reshape(-1, d)
+        fa = xa.shape[-1]
+        w2 = kernel.reshape(-1, d)
+        dxa = dxb = dk = das = dan = db = None
+        if ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1]):
+            dz = rows_matmul(d_hx, w2.t(), ctx.precision)
+            dxa = dz[..., :fa] if ctx.needs_input_grad[0] else None
+            dxb = dz[..., fa:] if xb is not None and ctx.needs_input_grad[1] else None
+        if ctx.needs_input_grad[2]:
+            z2 = xa.reshape(-1, fa) if xb is None else torch.cat([xa, xb], dim=-1).reshape(-1, w2.shape[0])
+            dk = z2.t().mm(dh2).reshape(kernel.shape)
+        if ctx.needs_input_grad[3]:
+            das = (ds_self.reshape(1, -1).mm(hx2)).reshape(a_self.shape)
+        if ctx.needs_input_grad[4]:
+            dan = (ds_nbr.reshape(1, -1).mm(hx2)).reshape(a_nbr.shape)
+        if ctx.has_bias and ctx.needs_input_grad[5]:
+            db = g.reshape(-1, d).sum(0)
+        return dxa, dxb, dk, das, dan, db, None, None, None
+
+
+class CumsumActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, act):
+        y = _lib.cumsum_act(x.contiguous(), None if res is None else res.contiguous(), act)
+        ctx.save_for_backward(y)
+        ctx.act, ctx.has_res = act, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gz = act_grad(y, gy, ctx.act)
+        dx = torch.flip(torch.cumsum(torch.flip(gz, dims=[1]), dim=1), dims=[1]) if ctx.needs_input_grad[0] else None
+        dres = gz.sum(dim=1, keepdim=True) if ctx.has_res and ctx.needs_input_grad[1] else None
+        return dx, dres, None
+
+
+class FlowBalanceFn(torch.autograd.Function):
+    """q_in, q_out (S,N) from signed link flows (S,E) (`emulator.py:717-724`); edges (E,2) int64 = [from, to] per link."""
+
+    @staticmethod
+    def forward(ctx, flow, handle, sign, scale_in, scale_out, edges):
+        flow = flow.contiguous()
+        ctx.save_for_backward(flow, scale_in, scale_out, edges)
+        return _lib.flow_balance(handle, sign, flow, scale_in, scale_out)
+
+    @staticmethod
+    def backward(ctx, g_in, g_out):
+        flow, scale_in, scale_out, edges = ctx.saved_tensors
+        gi, go = g_in * scale_in, g_out * scale_out                     # (S,N)
+        u, v = edges[:, 0], edges[:, 1]
+        # from-node u: q_out += max(f,0), q_in += max(-f,0); to-node v: q_in += max(f,0), q_out += max(-f,0)
+        pos = go[:, u] + gi[:, v]
+        neg = gi[:, u] + go[:, v]
+        dflow = torch.where(flow > 0, pos, torch.zeros_like(pos)) - torch.where(flow < 0, neg, torch.zeros_like(neg))
+        return dflow, None, None, None, None, None
+
+
+def grad_on(*tensors):
+    """True when autograd is recording and one of the tensors needs a gradient: the modules then take the Function path."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)

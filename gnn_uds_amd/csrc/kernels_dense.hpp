@@ -17,7 +17,8 @@ struct DenseArgs {
   int fa, fb, fo, act;
   int64_t rows;
   // causal dilated Conv1D over time as a GEMM on time-shifted rows (taps = 0: plain dense).  Rows are (b, t, r) with
-  // r fastest: tap j reads the row `(taps-1-j)*dil` time steps earlier (t_rows rows back) or zero before t = 0.
+  // r fastest: tap j reads the row `(taps-1-j)*dil` time steps earlier (t_rows rows back) or zero outside [0, T)
+  // (dil < 0 looks ahead instead: the input-gradient of the causal convolution).
   int taps = 0, dil = 1, T = 1, t_rows = 1;
 };
 
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void k_dense_act(DenseArgs a) {
           const int j = kk / a.fa, f = kk - j * a.fa;
           const int shift = (a.taps - 1 - j) * a.dil;
           const int t = (int)((grow / a.t_rows) % a.T);
-          if (t >= shift) v = a.xa[(grow - (int64_t)shift * a.t_rows) * a.fa + f];
+          if (t - shift >= 0 && t - shift < a.T) v = a.xa[(grow - (int64_t)shift * a.t_rows) * a.fa + f];
         } else if (kk < a.fa) {
           v = a.xa[grow * a.fa + kk];
         } else {

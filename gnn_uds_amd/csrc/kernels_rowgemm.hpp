@@ -125,14 +125,18 @@ __global__ __launch_bounds__(512, 2) void k_rowgemm_mfma(RowGemmArgs a) {
     }
   };
   const unsigned my_lds = __builtin_amdgcn_readfirstlane(lds_addr(ring));
-  // piece (k-step t, row rw at time index tx): two 1-KiB halves.  A row before t = 0 of the causal window is fetched
-  // from the row itself (always in bounds) and zeroed at use.
-  auto live_of = [&](int t, int tx) { return tx >= (a.taps - 1 - (32 * t) / a.F) * a.dil; };
+  // piece (k-step t, row rw at time index tx): two 1-KiB halves.  A row outside [0, T) of the (causal, or for
+  // dil < 0 look-ahead) window is fetched from the row itself (always in bounds) and zeroed at use.
+  auto live_of = [&](int t, int tx) {
+    const int ts = tx - (a.taps - 1 - (32 * t) / a.F) * a.dil;
+    return ts >= 0 && ts < a.T;
+  };
   auto issue = [&](int t, int rw, int tx, int slot) {
     const int k0 = 32 * t;
     const int j = k0 / a.F, f0 = k0 - j * a.F;
     const int shift = (a.taps - 1 - j) * a.dil;
-    const float *src = a.x + (int64_t)(rw - (tx >= shift ? shift * a.t_rows : 0)) * a.F + f0 + 4 * qd;
+    const bool live = tx - shift >= 0 && tx - shift < a.T;
+    const float *src = a.x + (int64_t)(rw - (live ? shift * a.t_rows : 0)) * a.F + f0 + 4 * qd;
     glds16_pair(src, src + 16, my_lds + (unsigned)slot * 2048);
   };
 

@@ -14,6 +14,7 @@
 #include "../../include/uds_hip.h"
 #include "kernels_dense.hpp"
 #include "kernels_sparse.hpp"
+#include "kernels_backward.hpp"
 #include "kernels_fused.hpp"
 #include "kernels_rowgemm.hpp"
 #include "tile_plan.hpp"
@@ -51,7 +52,7 @@ inline int64_t align4(int64_t floats) { return (floats + 3) & ~int64_t(3); }  //
 struct uds_csr {
   int64_t n_rows = 0, n_cols = 0, nnz = 0;
   int32_t max_degree = 0;
-  int32_t *d_rowptr = nullptr, *d_col = nullptr, *d_order = nullptr;
+  int32_t *d_rowptr = nullptr, *d_col = nullptr, *d_order = nullptr, *d_rowidx = nullptr;   // rowidx: row of every entry
   std::vector<int32_t> h_order;
   uds::HostCsr host;   // kept for the tile planner
 };
@@ -171,15 +172,21 @@ int uds_csr_create(const int32_t *rowptr, const int32_t *col, int64_t n_rows, in
     hipFree(c->d_rowptr);
     hipFree(c->d_col);
     hipFree(c->d_order);
+    hipFree(c->d_rowidx);
     delete c;
     return code;
   };
   hipError_t e;
   if ((e = hipMalloc(&c->d_rowptr, sizeof(int32_t) * (n_rows + 1))) != hipSuccess ||
       (e = hipMalloc(&c->d_col, sizeof(int32_t) * std::max<int64_t>(nnz, 1))) != hipSuccess ||
-      (e = hipMalloc(&c->d_order, sizeof(int32_t) * std::max<int64_t>(n_rows, 1))) != hipSuccess)
+      (e = hipMalloc(&c->d_order, sizeof(int32_t) * std::max<int64_t>(n_rows, 1))) != hipSuccess ||
+      (e = hipMalloc(&c->d_rowidx, sizeof(int32_t) * std::max<int64_t>(nnz, 1))) != hipSuccess)
     return cleanup(fail(UDS_ENOMEM, "uds_csr_create: hipMalloc -> %s", hipGetErrorString(e)));
+  std::vector<int32_t> rowidx((size_t)nnz);
+  for (int64_t r = 0; r < n_rows; ++r)
+    for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p) rowidx[p] = (int32_t)r;
   if ((e = hipMemcpy(c->d_rowptr, rowptr, sizeof(int32_t) * (n_rows + 1), hipMemcpyHostToDevice)) != hipSuccess ||
+      (nnz && (e = hipMemcpy(c->d_rowidx, rowidx.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice)) != hipSuccess) ||
       (nnz && (e = hipMemcpy(c->d_col, col, sizeof(int32_t) * nnz, hipMemcpyHostToDevice)) != hipSuccess) ||
       (n_rows && (e = hipMemcpy(c->d_order, c->h_order.data(), sizeof(int32_t) * n_rows, hipMemcpyHostToDevice)) != hipSuccess))
     return cleanup(fail(UDS_EHIP, "uds_csr_create: hipMemcpy -> %s", hipGetErrorString(e)));
@@ -192,6 +199,7 @@ int uds_csr_destroy(uds_csr_t *c) {
   hipFree(c->d_rowptr);
   hipFree(c->d_col);
   hipFree(c->d_order);
+  hipFree(c->d_rowidx);
   delete c;
   return UDS_OK;
 }
@@ -234,7 +242,7 @@ int uds_dense_act(const float *xa, int64_t fa, const float *xb, int64_t fb, int6
 int uds_conv1d_causal(const float *x, int64_t B, int64_t T, int64_t R, int64_t F, const float *kernel, const float *bias,
                       int64_t taps, int64_t dil, int64_t H, int act, float *out, uds_stream_t stream) {
   UDS_REQUIRE(x && kernel && out, "uds_conv1d_causal: NULL x/kernel/out");
-  UDS_REQUIRE(B >= 0 && T > 0 && R > 0 && F > 0 && taps > 0 && taps <= 16 && dil > 0 && H > 0 && H <= 256 && taps * F <= 4096,
+  UDS_REQUIRE(B >= 0 && T > 0 && R > 0 && F > 0 && taps > 0 && taps <= 16 && dil != 0 && H > 0 && H <= 256 && taps * F <= 4096,
               "uds_conv1d_causal: bad sizes B=%lld T=%lld R=%lld F=%lld taps=%lld dil=%lld H=%lld", (long long)B, (long long)T,
               (long long)R, (long long)F, (long long)taps, (long long)dil, (long long)H);
   UDS_REQUIRE(act >= UDS_ACT_LINEAR && act <= UDS_ACT_HARD_SIGMOID, "uds_conv1d_causal: unknown activation %d", act);
@@ -271,7 +279,7 @@ int uds_rowgemm_pack(const float *W, int64_t k_total, int64_t f_out, void *packe
 int uds_rowgemm_forward(const float *x, int64_t B, int64_t T, int64_t R, int64_t F, const void *packed, const float *bias,
                         int64_t taps, int64_t dil, int64_t f_out, int act, float *out, uds_stream_t stream) {
   UDS_REQUIRE(x && packed && out, "uds_rowgemm_forward: NULL x/packed/out");
-  UDS_REQUIRE(B >= 0 && T > 0 && R > 0 && F > 0 && F % 32 == 0 && taps > 0 && taps <= 16 && dil > 0 && f_out > 0 && f_out <= 64,
+  UDS_REQUIRE(B >= 0 && T > 0 && R > 0 && F > 0 && F % 32 == 0 && taps > 0 && taps <= 16 && dil != 0 && f_out > 0 && f_out <= 64,
               "uds_rowgemm_forward: needs F %% 32 == 0, f_out <= 64 (B=%lld T=%lld R=%lld F=%lld taps=%lld f_out=%lld)", (long long)B,
               (long long)T, (long long)R, (long long)F, (long long)taps, (long long)f_out);
   UDS_REQUIRE(act >= UDS_ACT_LINEAR && act <= UDS_ACT_HARD_SIGMOID, "uds_rowgemm_forward: unknown activation %d", act);
@@ -349,6 +357,44 @@ int uds_gat_forward(const uds_csr_t *g, const float *xa, int64_t fa, const float
   uds::GatArgs a{g->d_rowptr, g->d_col, g->d_order, hx, s_self, s_nbr, bias, out, (int)n, (int)(d / 4), act, (int)S};
   hipError_t e = uds::launch_gat_aggregate(a, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(UDS_EHIP, "uds_gat_forward: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
+int uds_gat_backward(const uds_csr_t *g, const uds_csr_t *gt, const int32_t *perm_t, const float *grad, const float *hx,
+                     const float *s_self, const float *s_nbr, const float *a_self, const float *a_nbr, int64_t S, int64_t d,
+                     float *alpha_ws, float *de_ws, float *d_hx, float *ds_self, float *ds_nbr, uds_stream_t stream) {
+  UDS_REQUIRE(g && gt && perm_t && grad && hx && s_self && s_nbr && a_self && a_nbr && alpha_ws && de_ws && d_hx && ds_self && ds_nbr,
+              "uds_gat_backward: NULL argument");
+  UDS_REQUIRE(g->n_rows == g->n_cols && gt->n_rows == g->n_rows && gt->n_cols == g->n_cols && gt->nnz == g->nnz,
+              "uds_gat_backward: the pattern and its transpose must be square with the same shape and entry count");
+  UDS_REQUIRE(d > 0 && d % 4 == 0 && d <= 256, "uds_gat_backward: d=%lld must be a multiple of 4, at most 256", (long long)d);
+  UDS_REQUIRE(S >= 0 && S <= 65535, "uds_gat_backward: S=%lld outside [0,65535]", (long long)S);
+  UDS_REQUIRE(aligned16(grad) && aligned16(hx) && aligned16(d_hx) && aligned16(a_self) && aligned16(a_nbr),
+              "uds_gat_backward: grad/hx/d_hx/a_self/a_nbr must be 16-byte aligned");
+  if (S == 0 || g->n_rows == 0) return UDS_OK;
+  const int d4 = (int)(d / 4);
+  uds::GatBwdRowsArgs ra{g->d_rowptr, g->d_col, grad, hx, s_self, s_nbr, alpha_ws, de_ws, ds_self,
+                         (int)g->n_rows, d4, (int)S, uds::lanes_per_item(d4), g->nnz};
+  hipError_t e = uds::launch_gat_bwd_rows(ra, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_gat_backward: row pass launch -> %s", hipGetErrorString(e));
+  uds::GatBwdColsArgs ca{gt->d_rowptr, gt->d_col, perm_t, grad, alpha_ws, de_ws, ds_self, a_self, a_nbr, d_hx, ds_nbr,
+                         (int)g->n_rows, d4, (int)S, g->nnz};
+  e = uds::launch_gat_bwd_cols(ca, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_gat_backward: column pass launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
+int uds_csr_sddmm(const uds_csr_t *csr, const float *a, const float *b, int64_t S, int64_t F, float *out, uds_stream_t stream) {
+  UDS_REQUIRE(csr && a && b && out, "uds_csr_sddmm: NULL argument");
+  UDS_REQUIRE(S >= 0 && F > 0 && F % 4 == 0, "uds_csr_sddmm: S=%lld F=%lld (F must be a positive multiple of 4)", (long long)S,
+              (long long)F);
+  UDS_REQUIRE(aligned16(a) && aligned16(b), "uds_csr_sddmm: a/b must be 16-byte aligned");
+  if (csr->nnz == 0) return UDS_OK;
+  const int f4 = (int)(F / 4);
+  uds::SddmmArgs sa{csr->d_rowidx, csr->d_col, a, b, out, (int)csr->n_rows, (int)csr->n_cols, f4, (int)S, uds::lanes_per_item(f4),
+                    csr->nnz};
+  hipError_t e = uds::launch_csr_sddmm(sa, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_csr_sddmm: launch -> %s", hipGetErrorString(e));
   return UDS_OK;
 }
 

@@ -233,3 +233,37 @@ def hip_layers(prob, global_params, embed_size, activation='relu', precision='bf
             m.attn_kernel_self.data, m.attn_kernel_neighs.data = f(p[k + '_as']), f(p[k + '_an'])
         layers.append(ly)
     return layers
+
+
+def allreduce_gradients(params, group=None, bucket_bytes=64 << 20):
+    """Data-parallel training (snapshot / scenario sharding adds ONE gradient all-reduce per step): average
+    the `.grad` of `params` over the ranks.  Gradients are packed into flat fp32 buckets (one bucket for a whole emulator:
+    a few MB) so the ring all-reduce over xGMI runs once on a large message instead of once per tensor; parameters a rank
+    did not touch count as zero.  No-op when torch.distributed is not initialised or the world has one rank."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 0
+    params = [p for p in params if p.requires_grad]
+    n_calls, i = 0, 0
+    while i < len(params):
+        j, size = i, 0
+        while j < len(params) and (j == i or (size + params[j].numel()) * 4 <= bucket_bytes):
+            size += params[j].numel()
+            j += 1
+        flat = torch.zeros(size, dtype=torch.float32, device=params[i].device)
+        off = 0
+        for p in params[i:j]:
+            if p.grad is not None:
+                flat[off:off + p.numel()] = p.grad.reshape(-1)
+            off += p.numel()
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat /= world
+        off = 0
+        for p in params[i:j]:
+            p.grad = flat[off:off + p.numel()].reshape(p.shape).clone()
+            off += p.numel()
+        n_calls += 1
+        i = j
+    return n_calls

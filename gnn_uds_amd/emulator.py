@@ -25,6 +25,7 @@ from torch import nn
 
 from . import _lib
 from .graph import DrainageGraph, csr_from_dense
+from . import autograd as _ag
 from .layers import Dense, SpatialBlock, _glorot_uniform, _packed_kernel, _param
 
 
@@ -42,12 +43,42 @@ class Conv1D(nn.Module):
         self.bias = _param(torch.zeros(self.filters))
 
     def forward(self, x):
+        if _ag.grad_on(x, self.kernel, self.bias):
+            return _ag.Conv1DFn.apply(x, self.kernel, self.bias, self)
         x = x.contiguous()
         k, f, h = self.kernel.shape
         if self.precision == 'bf16x3' and _lib.rowgemm_supported(k * f, f, h):     # matrix-core path (split-bf16, 3 products)
             return _lib.rowgemm_forward(x, _packed_kernel(self, self.kernel.reshape(k * f, h)), self.bias, h, self.activation,
                                         taps=k, dilation=self.dilation_rate)
         return _lib.conv1d_causal(x, self.kernel, self.bias, self.dilation_rate, self.activation)
+
+
+class KerasAdam:
+    """keras.optimizers.Adam(learning_rate, clipnorm) as TF 2.10 applies it (emulator.py:111): every gradient is clipped
+    by ITS OWN norm (tf.clip_by_norm), then m, v are updated and var -= lr * sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + 1e-7)."""
+
+    def __init__(self, params, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, clipnorm=None):
+        self.params = list(params)
+        self.lr, self.b1, self.b2, self.eps, self.clipnorm = learning_rate, beta_1, beta_2, epsilon, clipnorm
+        self.t = 0
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+
+    @torch.no_grad()
+    def step(self):
+        self.t += 1
+        lr_t = self.lr * (1 - self.b2 ** self.t) ** 0.5 / (1 - self.b1 ** self.t)
+        for p, m, v in zip(self.params, self.m, self.v):
+            if p.grad is None:
+                continue
+            g = p.grad
+            if not bool(torch.isfinite(g).all()):
+                raise FloatingPointError('grads contain NaN/Inf!')
+            if self.clipnorm is not None:
+                g = g * (self.clipnorm / torch.clamp(g.norm(), min=self.clipnorm))
+            m.mul_(self.b1).add_(g, alpha=1 - self.b1)
+            v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+            p.sub_(lr_t * m / (v.sqrt() + self.eps))
 
 
 class Emulator(nn.Module):
@@ -80,6 +111,10 @@ class Emulator(nn.Module):
         self.act_edges = np.asarray(g('act_edges', np.zeros((0, 2), dtype=int))) if self.act else None
         self.roll = int(g('roll', 0))
         self.model_dir = g('model_dir')
+        self.balance = bool(g('balance', False))
+        self.gradnorm = bool(g('gradnorm', False))
+        self.learning_rate = float(g('learning_rate', 1e-3))
+        self._args, self._optimizer, self._lw = args, None, None
         self.resnet = bool(resnet)
         self.conv = False if conv in (None, 'None', 'False', 'NoneType', False) else conv
         self.recurrent = recurrent
@@ -162,10 +197,10 @@ class Emulator(nn.Module):
         c = lambda t: t.contiguous()
         # the embedding is linear, its last step is kept as the residual, then the activation is applied (:198-201):
         # two launches of the same GEMM (same per-row arithmetic), one with and one without the activation
-        x_lin_last = _lib.dense_act(c(X[:, -1:]), self.embed_x.kernel, self.embed_x.bias, 'linear')
-        x = _lib.dense_act(c(X), self.embed_x.kernel, self.embed_x.bias, self.activation)
-        e_lin_last = _lib.dense_act(c(E[:, -1:]), self.embed_e.kernel, self.embed_e.bias, 'linear')
-        e = _lib.dense_act(c(E), self.embed_e.kernel, self.embed_e.bias, self.activation)
+        x_lin_last = self.embed_x(c(X[:, -1:]), 'linear')
+        x = self.embed_x(c(X), self.activation)
+        e_lin_last = self.embed_e(c(E[:, -1:]), 'linear')
+        e = self.embed_e(c(E), self.activation)
         b = self.embed_b(c(B))
         ae = self.embed_ae(c(AE)) if self.act else None
 
@@ -190,8 +225,12 @@ class Emulator(nn.Module):
             e = ly(e)
         x, e = self.res_x(x), self.res_e(e)
         if self.resnet:                                               # :315-320
-            x = _lib.cumsum_act(x, x_lin_last, self.activation)
-            e = _lib.cumsum_act(e, e_lin_last, self.activation)
+            if _ag.grad_on(x, e, x_lin_last, e_lin_last):
+                x = _ag.CumsumActFn.apply(x, x_lin_last, self.activation)
+                e = _ag.CumsumActFn.apply(e, e_lin_last, self.activation)
+            else:
+                x = _lib.cumsum_act(x, x_lin_last, self.activation)
+                e = _lib.cumsum_act(e, e_lin_last, self.activation)
         out = self.out(x)
         if self.if_flood:
             f = x
@@ -248,8 +287,13 @@ class Emulator(nn.Module):
         s_out = (ny[0, :, 2] > 1e-3).float() / ny[0, :, 2]
         s_in = (ny[0, :, 1] > 1e-3).float() / ny[0, :, 1]
         lead = flow.shape[:-2]
-        q_in, q_out = _lib.flow_balance(self._inc_handle, self._inc_sign, flow.reshape(-1, self.n_edge).contiguous(),
-                                        s_in.contiguous(), s_out.contiguous())
+        if _ag.grad_on(flow):
+            edges = torch.as_tensor(self.edges, dtype=torch.int64, device=flow.device)
+            q_in, q_out = _ag.FlowBalanceFn.apply(flow.reshape(-1, self.n_edge), self._inc_handle, self._inc_sign,
+                                                  s_in.contiguous(), s_out.contiguous(), edges)
+        else:
+            q_in, q_out = _lib.flow_balance(self._inc_handle, self._inc_sign, flow.reshape(-1, self.n_edge).contiguous(),
+                                            s_in.contiguous(), s_out.contiguous())
         return q_in.reshape(lead + (self.n_node, 1)), q_out.reshape(lead + (self.n_node, 1))
 
     def post_proc_tf(self, preds, a, b):
@@ -337,8 +381,6 @@ class Emulator(nn.Module):
 
     def _model(self, x, a, b, ex, ae=None, adj=None, fit=False):
         """emulator.py:400-438 on normalised tensors; `roll` > 0 = autoregressive chunks of seq_out steps."""
-        if fit:
-            raise NotImplementedError('training (fit_eval, SURVEY.md a10) is not built')
         if self.roll:
             ys, eys = [], []
             for i in range(self.roll):
@@ -370,8 +412,88 @@ class Emulator(nn.Module):
         runoff = runoff[:, :self.seq_out]
         return self.predict_tf(states, runoff, a, edge_states)
 
-    def fit_eval(self, *args, **kwargs):
-        raise NotImplementedError('training (fit_eval, emulator.py:457-484; SURVEY.md a10) is not built: forward engine only')
+    # ------------------------------------------------------------------ training step (:440-484)
+    def _loss_setup(self, device):
+        """nwei / ewei / poswei exactly as the constructor of the reference builds them (emulator.py:82,99-106,116)."""
+        if getattr(self, '_lw', None) is not None and self._lw[0] == device:
+            return self._lw[1]
+        g = lambda k, d: np.asarray(getattr(self._args, k, d), dtype=np.float64)
+        nwei = np.repeat(g('nwei', np.ones(self.n_node))[:, None], 3 + int(self.balance), axis=-1).astype(np.float32)
+        hmax, hmin, outf = (self.hmax.cpu().numpy().astype(np.float64), self.hmin.cpu().numpy().astype(np.float64),
+                            self.is_outfall.cpu().numpy().astype(np.float64))
+        if hmin.max() > 0:
+            wei = (hmax - hmin) * (1 - outf) + (hmax - hmin).mean() * outf
+            wei = (hmax.max() - hmin.min()) / wei
+            nwei = nwei * np.stack([wei] + (2 + int(self.balance)) * [np.ones_like(wei)], axis=-1)
+        t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32), device=device)
+        lw = dict(nwei=t(nwei), ewei=t(g('ewei', np.ones(self.n_edge))), poswei=t(g('poswei', np.ones(self.n_node))))
+        self._lw = (device, lw)
+        return lw
+
+    @staticmethod
+    def _mse(y_true, y_pred, sample_weight=None):
+        """keras MeanSquaredError(): mean over the last axis, optional per-sample weights, then the mean over all samples."""
+        per = ((y_pred - y_true) ** 2).mean(dim=-1)
+        if sample_weight is not None:
+            per = per * sample_weight
+        return per.mean()
+
+    @staticmethod
+    def _bce(y_true, y_pred, sample_weight):
+        """keras BinaryCrossentropy() on probabilities (clipped to [1e-7, 1 - 1e-7]), weighted, mean over all samples."""
+        p = y_pred.clamp(1e-7, 1 - 1e-7)
+        per = -(y_true * torch.log(p) + (1 - y_true) * torch.log(1 - p)).mean(dim=-1)
+        return (per * sample_weight).mean()
+
+    def get_node_loss(self, y, b, preds):
+        lw = self._loss_setup(preds.device)
+        if self.balance:
+            q_w, pr = self.constrain_tf(self.normalize(preds, 'y', True), self.normalize(b, 'b', True)[..., :1])
+            q_w = (q_w / self._norm('y', preds.device)[0, :, -1]).unsqueeze(-1)
+            pr = self.normalize(pr, 'y').clamp(0, 1)
+            return self._mse(torch.cat([y[..., :3], y[..., -1:]], dim=-1) * lw['nwei'], torch.cat([pr[..., :3], q_w], dim=-1) * lw['nwei'])
+        return self._mse(y[..., :3] * lw['nwei'], preds[..., :3] * lw['nwei'])
+
+    def get_flood_loss(self, y, preds):
+        lw = self._loss_setup(preds.device)
+        weight = lw['poswei'] * y[..., -2] + lw['nwei'][:, -1] * (1 - y[..., -2])
+        return self._bce(y[..., -2:-1], preds[..., -1:], weight)
+
+    def fit_eval(self, x, a, b, y, ex, ey, fit=True):
+        """One training (fit=True) or evaluation step on NORMALISED tensors (emulator.py:457-484): forward through
+        `_model`, node MSE (+ weighted flood BCE) + link MSE, reverse mode through the HIP operators (autograd.py), Adam with
+        per-variable clipnorm=1.  Returns [node_loss, (flood_loss,) edge_loss] as 0-d tensors."""
+        if self.gradnorm:
+            raise NotImplementedError('gradnorm multi-task weighting (emulator.py:486-519) is not built')
+        params = [p for p in self.parameters()]
+        if fit:
+            for p in params:
+                p.requires_grad_(True)
+        with torch.set_grad_enabled(bool(fit)):
+            ae = self.get_edge_action(a, True) if self.act else None
+            preds, edge_preds = self._model(x, a, b, ex, ae, None, fit)
+            lw = self._loss_setup(preds.device)
+            node_loss = self.get_node_loss(y, b, preds)
+            fl_loss = self.get_flood_loss(y, preds) if self.if_flood and not self.balance else None
+            edge_loss = self._mse(ey, edge_preds, lw['ewei'])
+            if fit:
+                loss = node_loss + edge_loss
+                if self.if_flood:
+                    if fl_loss is None:
+                        raise NotImplementedError('if_flood with balance: the reference leaves fl_loss undefined here (emulator.py:466,473)')
+                    loss = loss + fl_loss
+                if not bool(torch.isfinite(loss)):
+                    raise FloatingPointError('Loss contains NaN or Inf values.')
+                for p in params:
+                    p.grad = None
+                loss.backward()
+                from .dist import allreduce_gradients
+                allreduce_gradients(params)          # data-parallel ranks: one bucketed all-reduce (no-op on one rank)
+                if self._optimizer is None:
+                    self._optimizer = KerasAdam(params, self.learning_rate, clipnorm=1.0)
+                self._optimizer.step()
+        out = [node_loss.detach()] + ([fl_loss.detach()] if self.if_flood and fl_loss is not None else []) + [edge_loss.detach()]
+        return out
 
     # ------------------------------------------------------------------ checkpoints (:814-852)
     def save(self, model_dir=None):

@@ -10,9 +10,10 @@ same tensor layouts -- re-expressed as `torch.nn.Module`s
     GCNConv(channels, activation=..) + preprocess spektral GCNConv via emulator.py:131-134
     SpatialLayer / SpatialBlock                   the loop bodies emulator.py:219-235, 272-288
 
-Forward only (the training step, SURVEY.md a10, is a later row): parameters are created with
-requires_grad=False and no autograd graph is recorded.  All compute is HIP kernels behind the C ABI
-(gnn_uds_amd/_lib.py); CPU tensors raise.
+Parameters are created with requires_grad=False (inference: no autograd graph is recorded).  After
+`module.requires_grad_(True)` the same modules run through the autograd Functions of `autograd.py`
+(HIP backward kernels; the training step of SURVEY.md a10).  All compute is HIP kernels behind the
+C ABI (gnn_uds_amd/_lib.py); CPU tensors raise.
 """
 import math
 
@@ -21,6 +22,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from . import autograd as _ag
 from .graph import CSR, DrainageGraph, csr_from_dense
 
 
@@ -81,14 +83,19 @@ class Dense(nn.Module):
         self.kernel = _param(_glorot_uniform((int(in_features), self.units), device, self._gen))
         self.bias = _param(torch.zeros(self.units, device=device)) if self.use_bias else None
 
-    def forward(self, x):
+    def forward(self, x, activation=None):
+        """activation: override of the layer's own (the reference applies the embedding's activation outside the layer,
+        emulator.py:198-201)."""
         if self.kernel is None:
             self.build(x.shape[-1], x.device)
+        act = activation or self.activation
+        if _ag.grad_on(x, self.kernel, self.bias):
+            return _ag.DenseFn.apply(x, self.kernel, self.bias, self, act)
         xc = x.contiguous()
         fi = xc.shape[-1]
         if self.precision == 'bf16x3' and _lib.rowgemm_supported(fi, fi, self.units):
-            return _lib.rowgemm_forward(xc, _packed_kernel(self, self.kernel), self.bias, self.units, self.activation)
-        return _lib.dense_act(xc, self.kernel, self.bias, self.activation)
+            return _lib.rowgemm_forward(xc, _packed_kernel(self, self.kernel), self.bias, self.units, act)
+        return _lib.dense_act(xc, self.kernel, self.bias, act)
 
 
 class _GraphArg:
@@ -135,6 +142,7 @@ class GATConv(nn.Module):
         self.activation, self.use_bias = activation or 'linear', use_bias
         self._gen = generator
         self._graphs = _GraphArg()
+        self.precision = 'fp32'      # numerics of the backward row GEMMs (the forward linear part is the exact kernel)
         self.kernel = self.attn_kernel_self = self.attn_kernel_neighs = self.bias = None
         if in_channels is not None:
             self.build(in_channels, 'cpu')
@@ -153,6 +161,10 @@ class GATConv(nn.Module):
         h = self._graphs.handle(a, self.add_self_loops)
         xs, lead = _flatten_snapshots(x)
         xbs = None if xb is None else _flatten_snapshots(xb)[0]
+        if _ag.grad_on(xs, xbs, self.kernel, self.attn_kernel_self, self.attn_kernel_neighs, self.bias):
+            out = _ag.GatFn.apply(xs, xbs, self.kernel, self.attn_kernel_self, self.attn_kernel_neighs, self.bias,
+                                  self.activation, h, self.precision)
+            return out.reshape(lead + out.shape[-2:])
         out = _lib.gat_forward(h, xs, self.kernel, self.attn_kernel_self, self.attn_kernel_neighs, self.bias,
                                self.activation, xbs)
         return out.reshape(lead + out.shape[-2:])
@@ -202,6 +214,8 @@ class GCNConv(nn.Module):
         x, a = inputs
         if self.kernel is None:
             self.build(x.shape[-1], x.device)
+        if _ag.grad_on(x, self.kernel, self.bias):
+            raise NotImplementedError('training through GCNConv is not built (GAT is)')
         h, val = self._filter(a, x.device)
         xs, lead = _flatten_snapshots(x)
         hx = _lib.dense_act(xs, self.kernel, None, 'linear')
@@ -266,8 +280,24 @@ class NodeEdge(nn.Module):
     def forward(self, x):
         if x.shape[-2] != self.shape[1]:
             raise _lib.UdsError('NodeEdge expects %d elements on axis -2, got %r' % (self.shape[1], tuple(x.shape)))
-        val, rest = self.support_values()
         xs, lead = _flatten_snapshots(x)
+        if _ag.grad_on(xs, self.weight, self.bias):
+            # training: the support values are re-derived under autograd (gradients reach `weight` and `bias`); with the
+            # reference's dense (R, M) parameters the bias also trains OFF the support (emulator.py:36-39,44), which is
+            # a dense GEMM and only feasible for small networks -- sparse=True keeps one trainable entry per support element
+            flat, ival = self._flat.to(self.weight.device), self._ival.to(self.weight.device)
+            if self.sparse:
+                val = self.weight * ival + self.bias
+                out = _ag.SpmmFn.apply(val, xs, self.handle())
+            else:
+                val = self.weight.reshape(-1)[flat] * ival + self.bias.reshape(-1)[flat]
+                out = _ag.SpmmFn.apply(val, xs, self.handle())
+                if self.bias.requires_grad:
+                    off = torch.ones_like(self.bias)
+                    off.reshape(-1)[flat] = 0.0
+                    out = out + torch.matmul(self.bias * off, xs)
+            return out.reshape(lead + out.shape[-2:])
+        val, rest = self.support_values()
         out = _lib.csr_spmm(self.handle(), val, xs)
         if rest is not None:
             out = out + torch.matmul(rest, xs)
@@ -306,8 +336,8 @@ class SpatialLayer(nn.Module):
         fx = self.d if fx is None else int(fx)
         fe = self.d if fe is None else int(fe)
         g = generator
-        self.dense_xe = Dense(self.h, activation, in_features=fe, generator=g)          # emulator.py:225
-        self.dense_ex = Dense(self.h, activation, in_features=fx, generator=g)          # emulator.py:226
+        self.dense_xe = Dense(self.h, activation, in_features=fe, generator=g, precision=precision)          # emulator.py:225
+        self.dense_ex = Dense(self.h, activation, in_features=fx, generator=g, precision=precision)          # emulator.py:226
         abs_n = CSR(graph.inc_n.rowptr, graph.inc_n.col, graph.n_node, graph.n_edge, np.abs(graph.inc_n.val))
         abs_e = CSR(graph.inc_e.rowptr, graph.inc_e.col, graph.n_edge, graph.n_node, np.abs(graph.inc_e.val))
         self.node_edge_n = NodeEdge(abs_n, sparse=sparse_params, generator=g)           # emulator.py:227
@@ -315,6 +345,7 @@ class SpatialLayer(nn.Module):
         if conv == 'GAT':
             self.gat_x = GATConv(self.d, activation=activation, in_channels=fx + self.h, generator=g)   # :229
             self.gat_e = GATConv(self.d, activation=activation, in_channels=fe + self.h, generator=g)   # :230
+            self.gat_x.precision = self.gat_e.precision = precision
         else:
             self.gcn_x = GCNConv(self.d, activation=activation, in_channels=fx + self.h, generator=g)
             self.gcn_e = GCNConv(self.d, activation=activation, in_channels=fe + self.h, generator=g)
@@ -356,9 +387,18 @@ class SpatialLayer(nn.Module):
         xs, lead_x = _flatten_snapshots(x)
         es, lead_e = _flatten_snapshots(e)
         if self.conv == 'GCN':     # a_hat @ ([x | agg] W) + b: unfused composition of the Dense / NodeEdge / spmm kernels
+            if _ag.grad_on(xs, es, *self.parameters()):
+                raise NotImplementedError('training through the GCN spatial layer is not built (GAT is)')
             x_e, e_x = self.dense_xe(es), self.dense_ex(xs)
             ox = self.gcn_x([torch.cat([xs, self.node_edge_n(x_e)], dim=-1), self.filters[0]])
             oe = self.gcn_e([torch.cat([es, self.node_edge_e(e_x)], dim=-1), self.filters[1]])
+            return ox.reshape(lead_x + ox.shape[-2:]), oe.reshape(lead_e + oe.shape[-2:])
+        if _ag.grad_on(xs, es, *self.parameters()):
+            # training: the unfused chain, every operator with its own HIP backward (autograd.py)
+            net = self.network()
+            x_e, e_x = self.dense_xe(es), self.dense_ex(xs)
+            ox = self.gat_x([xs, net.adj], xb=self.node_edge_n(x_e))
+            oe = self.gat_e([es, net.edge_adj], xb=self.node_edge_e(e_x))
             return ox.reshape(lead_x + ox.shape[-2:]), oe.reshape(lead_e + oe.shape[-2:])
         vn, rest_n = self.node_edge_n.support_values()
         ve, rest_e = self.node_edge_e.support_values()

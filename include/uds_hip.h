@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 2
+#define UDS_ABI_VERSION 3
 
 enum {
   UDS_OK = 0,
@@ -86,7 +86,8 @@ int uds_csr_spmm(const uds_csr_t *csr, const float *val, const float *x, int64_t
                  const float *bias, int act, float *out, uds_stream_t stream);
 
 /* keras Conv1D(H, taps, padding='causal', dilation_rate=dil, activation) along T on x laid out (B, T, R, F) with no
- * transposes: out[b,t,r,:] = act(sum_j x[b, t-(taps-1-j)*dil, r, :] @ kernel[j] + bias), zero before t = 0.
+ * transposes: out[b,t,r,:] = act(sum_j x[b, t-(taps-1-j)*dil, r, :] @ kernel[j] + bias), zero outside [0, T).
+ * dil < 0 looks ahead instead of back: with kernel[j] transposed this is the input gradient of the causal layer.
  * kernel is (taps, F, H) row-major (the Keras layout); out is (B, T, R, H).   emulator.py:155-157,244-257,299-310 */
 int uds_conv1d_causal(const float *x, int64_t B, int64_t T, int64_t R, int64_t F, const float *kernel,
                       const float *bias, int64_t taps, int64_t dil, int64_t H, int act, float *out,
@@ -126,6 +127,26 @@ int uds_gat_forward(const uds_csr_t *graph, const float *xa, int64_t fa, const f
                     int64_t fb, int64_t S, const float *W, const float *a_self,
                     const float *a_nbr, const float *bias, int64_t d, int act, float *workspace,
                     float *out, uds_stream_t stream);
+
+/* ---- reverse mode of the sparse operators (the GradientTape of fit_eval, emulator.py:457-484) ---------- */
+
+/* Attention part of uds_gat_forward, backwards.  With pre_i = sum_j alpha_ij hx_j (before bias / activation) and
+ * grad = dL/dpre (S,n,d), hx / s_self / s_nbr as uds_gat_forward left them in its workspace:
+ *   d_hx (S,n,d)   = dL/dhx (aggregation + both attention scores),
+ *   ds_self, ds_nbr (S,n) = dL/ds_self, dL/ds_nbr  (for the gradients of the attention kernels: sum hx * ds),
+ * graph_t = the transposed pattern as its own handle, perm_t (device, nnz int32) = for every entry of graph_t the
+ * position of the same entry in graph's row-major order.  alpha_ws / de_ws: S * nnz floats of workspace each.
+ * Replaces the tape through spektral GATConv._call_dense (emulator.py:229-230,282-283). */
+int uds_gat_backward(const uds_csr_t *graph, const uds_csr_t *graph_t, const int32_t *perm_t, const float *grad,
+                     const float *hx, const float *s_self, const float *s_nbr, const float *a_self,
+                     const float *a_nbr, int64_t S, int64_t d, float *alpha_ws, float *de_ws, float *d_hx,
+                     float *ds_self, float *ds_nbr, uds_stream_t stream);
+
+/* out[k] = sum_s <a[s, row(k), :], b[s, col(k), :]> for every entry k of the pattern (row-major order): the gradient
+ * of the per-entry values of uds_csr_spmm (a = dL/dout (S,n_rows,F), b = x (S,n_cols,F)) -- NodeEdge.weight / bias
+ * on the incidence support (emulator.py:34-45). */
+int uds_csr_sddmm(const uds_csr_t *csr, const float *a, const float *b, int64_t S, int64_t F, float *out,
+                  uds_stream_t stream);
 
 /* ---- one spatial layer (node side + link side) ---------------------------------------------- */
 typedef struct uds_network uds_network_t;

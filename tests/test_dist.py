@@ -132,3 +132,42 @@ def test_sharded_block_two_processes_gloo():
         assert p.exitcode == 0
     err, nbytes, peers = result.get(timeout=10)
     assert err < 1e-11 and peers == 1 and 0 < nbytes < S * (N + E) * DM * 4 * 0.2     # a small halo, one peer
+
+
+def _grad_worker(rank, world, port, result):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(7)
+        params = [torch.nn.Parameter(torch.zeros(s)) for s in ((5, 3), (7,), (2, 2, 2))]
+        grads = [[torch.rand(p.shape, generator=g) for p in params] for _ in range(world)]      # every rank draws all of them
+        for p, gr in zip(params, grads[rank]):
+            p.grad = gr.clone()
+        params[1].grad = None if rank == 1 else params[1].grad                                   # an untouched parameter counts as 0
+        calls_one = D.allreduce_gradients(params)
+        want = [sum(grads[r][k] if not (k == 1 and r == 1) else torch.zeros_like(grads[r][k]) for r in range(world)) / world
+                for k in range(len(params))]
+        err = max(float((p.grad - w).abs().max()) for p, w in zip(params, want))
+        for p, gr in zip(params, grads[rank]):
+            p.grad = gr.clone()
+        calls_small = D.allreduce_gradients(params, bucket_bytes=40)                              # forces several buckets
+        err = max(err, max(float((p.grad - sum(grads[r][k] for r in range(world)) / world).abs().max())
+                           for k, p in enumerate(params)))
+        if rank == 0:
+            result.put((err, calls_one, calls_small))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_two_processes_gloo():
+    ctx = mp.get_context('spawn')
+    result = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, result)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    err, calls_one, calls_small = result.get(timeout=10)
+    assert err < 1e-7 and calls_one == 1 and calls_small == 3

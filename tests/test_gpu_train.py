@@ -1,0 +1,274 @@
+"""GPU parity of the reverse-mode path (`fit_eval`, emulator.py:440-484) against torch autograd over the
+fp64 CPU oracle: every autograd Function of gnn_uds_amd/autograd.py on its own, the gradients of all Emulator
+parameters, and the parameters after Adam steps.  The oracle is "parity unpinned" (oracle/__init__.py): the reference
+holds no gradients or trained weights to pin it.
+
+Stated tolerances (relative to max(1, max|reference tensor|) unless said otherwise):
+  exact-fp32 kernels ('fp32')         2e-5 per operator
+  split-bf16 MFMA kernels ('bf16x3')  2e-4 per operator
+  whole-model gradients               1e-2 * max|grad of that tensor| + 1e-10 * max|grad of any tensor| (measured: <= 5e-3;
+                                      first-layer gradients are cancelling sums through up to 12 split-bf16 GEMMs)
+"""
+import numpy as np
+import pytest
+import torch
+
+import gnn_uds_amd as U
+from gnn_uds_amd import _lib
+from gnn_uds_amd import autograd as AG
+from oracle import emulator_ref as OE
+from oracle import sparse_csr as OS
+from oracle import spektral_dense as OD
+from oracle import train_ref as OT
+from tests.util import emulator_args, emulator_norms, emulator_param_pairs, load_emulator
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    _lib.load()
+    return torch.device('cuda', 0)
+
+
+def close(out, ref, tol):
+    out = out.detach().double().cpu()
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    err = float((out - ref).abs().max()) if ref.numel() else 0.0
+    lim = tol * max(1.0, float(ref.abs().max()) if ref.numel() else 1.0)
+    assert err <= lim, 'max abs err %.3e > %.3e' % (err, lim)
+
+
+def rnd(g, *shape):
+    return torch.rand(*shape, generator=g, dtype=torch.float64)
+
+
+def leaf(t):
+    return t.clone().requires_grad_(True)
+
+
+def dev_leaf(t, dev):
+    return t.float().to(dev).requires_grad_(True)
+
+
+class _Mod:
+    """the attributes the Functions read from a module"""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+@pytest.mark.parametrize('rows,fi,fo,act,prec', [(70, 64, 32, 'relu', 'bf16x3'), (70, 64, 64, 'tanh', 'bf16x3'), (33, 5, 64, 'linear', 'fp32'),
+                                                 (50, 96, 32, 'relu', 'bf16x3'), (41, 32, 1, 'sigmoid', 'bf16x3'),
+                                                 (20, 64, 3, 'hard_sigmoid', 'fp32')])
+def test_dense_backward(dev, rows, fi, fo, act, prec):
+    g = torch.Generator().manual_seed(rows + fo)
+    x, k, b, gy = rnd(g, 2, rows, fi) - 0.5, rnd(g, fi, fo) - 0.5, rnd(g, fo) - 0.5, rnd(g, 2, rows, fo) - 0.5
+    xr, kr, br = leaf(x), leaf(k), leaf(b)
+    (OD.dense(xr, kr, br, act) * gy).sum().backward()
+    xd, kd, bd = dev_leaf(x, dev), dev_leaf(k, dev), dev_leaf(b, dev)
+    m = _Mod(precision=prec, units=fo, kernel=kd)
+    (AG.DenseFn.apply(xd, kd, bd, m, act) * gy.float().to(dev)).sum().backward()
+    tol = 2e-5 if prec == 'fp32' else 2e-4
+    close(xd.grad, xr.grad, tol)
+    close(kd.grad, kr.grad, tol)
+    close(bd.grad, br.grad, tol)
+
+
+@pytest.mark.parametrize('B,T,R,F,H,dil,act,prec', [(2, 7, 5, 64, 64, 1, 'relu', 'bf16x3'), (1, 12, 3, 64, 64, 4, 'relu', 'bf16x3'),
+                                                    (2, 6, 4, 10, 6, 2, 'tanh', 'fp32'), (1, 9, 4200, 32, 32, 2, 'relu', 'bf16x3')])
+def test_conv1d_backward(dev, B, T, R, F, H, dil, act, prec):
+    g = torch.Generator().manual_seed(T + R)
+    x, k, b, gy = rnd(g, B, T, R, F) - 0.5, rnd(g, 3, F, H) - 0.5, rnd(g, H) - 0.5, rnd(g, B, T, R, H) - 0.5
+    xr, kr, br = leaf(x), leaf(k), leaf(b)
+    ref = OE.conv1d_causal(xr.permute(0, 2, 1, 3).reshape(B * R, T, F), kr, br, dil, act).reshape(B, R, T, H).permute(0, 2, 1, 3)
+    (ref * gy).sum().backward()
+    xd, kd, bd = dev_leaf(x, dev), dev_leaf(k, dev), dev_leaf(b, dev)
+    m = _Mod(precision=prec, activation=act, dilation_rate=dil, kernel=kd)
+    (AG.Conv1DFn.apply(xd, kd, bd, m) * gy.float().to(dev)).sum().backward()
+    tol = 2e-5 if prec == 'fp32' else 2e-4
+    close(xd.grad, xr.grad, tol)
+    close(kd.grad, kr.grad, tol * (10 if R > 1000 else 1))       # sums over B*T*R rows
+    close(bd.grad, br.grad, tol * (10 if R > 1000 else 1))
+
+
+@pytest.mark.parametrize('name,d,fb,act', [('chaohu', 8, 0, 'relu'), ('shunqing', 64, 32, 'relu'), ('astlingen', 16, 4, 'tanh'),
+                                           ('hub', 64, 0, 'linear')])
+def test_gat_backward(dev, networks, name, d, fb, act):
+    if name == 'hub':      # a junction with 30 conduits plus a chain: rows with more than 16 neighbours
+        edges = np.array([[0, i] for i in range(1, 31)] + [[i, i + 1] for i in range(30, 45)])
+        gph = U.DrainageGraph.from_edges(edges, 46)
+    else:
+        net = networks[name]
+        gph = U.DrainageGraph.from_edges(np.array(net['edges']), net['n_node'])
+    for csr in (gph.adj, gph.edge_adj):
+        n, S, fa = csr.n_rows, 3, 12
+        g = torch.Generator().manual_seed(n + d)
+        xa, xb = rnd(g, S, n, fa) - 0.5, (rnd(g, S, n, fb) - 0.5 if fb else None)
+        k, a_s, a_n, b = rnd(g, fa + fb, 1, d) - 0.5, rnd(g, d, 1, 1) - 0.5, rnd(g, d, 1, 1) - 0.5, rnd(g, d) - 0.5
+        gy = rnd(g, S, n, d) - 0.5
+        ref_in = [leaf(t) for t in (xa, k, a_s, a_n, b)] + ([leaf(xb)] if fb else [])
+        z = ref_in[0] if not fb else torch.cat([ref_in[0], ref_in[5]], dim=-1)
+        (OS.gat_conv_csr(z, csr.rowptr, csr.col, ref_in[1], ref_in[2], ref_in[3], ref_in[4], act) * gy).sum().backward()
+        dv = [dev_leaf(t, dev) for t in (xa, k, a_s, a_n, b)] + ([dev_leaf(xb, dev)] if fb else [])
+        h = _lib.CsrHandle(csr)
+        out = AG.GatFn.apply(dv[0], dv[5] if fb else None, dv[1], dv[2], dv[3], dv[4], act, h, 'fp32')
+        (out * gy.float().to(dev)).sum().backward()
+        for got, ref in zip(dv, ref_in):
+            close(got.grad, ref.grad, 5e-5)
+
+
+def test_gat_backward_transposed_pattern_directed(dev):
+    """A non-symmetric pattern (directed adjacency): the column pass must walk the true transpose."""
+    rowptr = np.array([0, 2, 3, 6, 7], dtype=np.int32)
+    col = np.array([0, 2, 1, 0, 1, 2, 3], dtype=np.int32)
+    csr = U.graph.CSR(rowptr, col, 4, 4)
+    g = torch.Generator().manual_seed(5)
+    S, f, d = 2, 8, 8
+    x, k, a_s, a_n, b, gy = (rnd(g, S, 4, f) - 0.5, rnd(g, f, 1, d) - 0.5, rnd(g, d, 1, 1) - 0.5, rnd(g, d, 1, 1) - 0.5, rnd(g, d) - 0.5,
+                             rnd(g, S, 4, d) - 0.5)
+    ref_in = [leaf(t) for t in (x, k, a_s, a_n, b)]
+    (OS.gat_conv_csr(*ref_in[:1], rowptr, col, *ref_in[1:], 'relu') * gy).sum().backward()
+    dv = [dev_leaf(t, dev) for t in (x, k, a_s, a_n, b)]
+    h = _lib.CsrHandle(csr)
+    ht, perm = h.transposed(dev)
+    assert ht.n_rows == 4 and perm.cpu().tolist() == [0, 3, 2, 4, 1, 5, 6]       # column-major walk of the entries
+    (AG.GatFn.apply(dv[0], None, dv[1], dv[2], dv[3], dv[4], 'relu', h, 'fp32') * gy.float().to(dev)).sum().backward()
+    for got, ref in zip(dv, ref_in):
+        close(got.grad, ref.grad, 5e-5)
+
+
+@pytest.mark.parametrize('name,F', [('chaohu', 32), ('hague', 8)])
+def test_spmm_backward_and_sddmm(dev, networks, name, F):
+    net = networks[name]
+    gph = U.DrainageGraph.from_edges(np.array(net['edges']), net['n_node'])
+    for csr in (gph.inc_n, gph.inc_e):
+        g = torch.Generator().manual_seed(csr.n_rows)
+        S = 4
+        val, x, gy = rnd(g, csr.nnz) - 0.5, rnd(g, S, csr.n_cols, F) - 0.5, rnd(g, S, csr.n_rows, F) - 0.5
+        vr, xr = leaf(val), leaf(x)
+        (OS.incidence_aggregate_csr(xr, csr.rowptr, csr.col, vr, csr.n_rows) * gy).sum().backward()
+        vd, xd = dev_leaf(val, dev), dev_leaf(x, dev)
+        h = _lib.CsrHandle(csr)
+        (AG.SpmmFn.apply(vd, xd, h) * gy.float().to(dev)).sum().backward()
+        close(xd.grad, xr.grad, 2e-5)
+        close(vd.grad, vr.grad, 2e-5)
+
+
+def test_cumsum_and_flow_balance_backward(dev, networks):
+    g = torch.Generator().manual_seed(1)
+    x, res, gy = rnd(g, 2, 6, 9, 8) - 0.5, rnd(g, 2, 1, 9, 8) - 0.5, rnd(g, 2, 6, 9, 8) - 0.5
+    xr, rr = leaf(x), leaf(res)
+    (torch.relu(torch.cumsum(xr, 1) + rr) * gy).sum().backward()
+    xd, rd = dev_leaf(x, dev), dev_leaf(res, dev)
+    (AG.CumsumActFn.apply(xd, rd, 'relu') * gy.float().to(dev)).sum().backward()
+    close(xd.grad, xr.grad, 1e-5)
+    close(rd.grad, rr.grad, 1e-5)
+
+    net = networks['chaohu']
+    edges = np.array(net['edges'])
+    gph = U.DrainageGraph.from_edges(edges, net['n_node'])
+    ne = torch.from_numpy(gph.inc_n.to_dense())
+    flow = rnd(g, 4, gph.n_edge) - 0.5
+    s_in, s_out = rnd(g, gph.n_node), rnd(g, gph.n_node)
+    g_in, g_out = rnd(g, 4, gph.n_node) - 0.5, rnd(g, 4, gph.n_node) - 0.5
+    fr = leaf(flow)
+    pos, neg = ne.clamp(0, 1), ne.clamp(-1, 0).abs()
+    fp, fn = fr.clamp(min=0).unsqueeze(-1), (-fr.clamp(max=0)).unsqueeze(-1)
+    q_out, q_in = (pos @ fp + neg @ fn)[..., 0] * s_out, (neg @ fp + pos @ fn)[..., 0] * s_in
+    ((q_in * g_in).sum() + (q_out * g_out).sum()).backward()
+    f32 = lambda t: t.float().to(dev)
+    fd = dev_leaf(flow, dev)
+    qi, qo = AG.FlowBalanceFn.apply(fd, _lib.CsrHandle(gph.inc_n), f32(torch.as_tensor(gph.inc_n.val)), f32(s_in), f32(s_out),
+                                    torch.as_tensor(edges, dtype=torch.int64, device=dev))
+    ((qi * f32(g_in)).sum() + (qo * f32(g_out)).sum()).backward()
+    close(fd.grad, fr.grad, 1e-5)
+
+
+def _problem(networks, name, dev, seed=3, B=2, **over):
+    net = networks[name]
+    edges, n = np.array(net['edges']), net['n_node']
+    args = emulator_args(edges, n, **over)
+    norms = emulator_norms(args)
+    params = OE.init_params(args, seed=1)
+    c = OE.config(args)
+    g = torch.Generator().manual_seed(seed)
+    T_out = c.seq_out * max(c.roll, 1)
+    x, b, ex = rnd(g, B, c.seq_in, n, c.n_in), rnd(g, B, T_out, n, c.b_in) * 0.1, rnd(g, B, c.seq_in, len(edges), c.e_in)
+    a = rnd(g, B, T_out, len(args.act_edges)) if c.act else None
+    y = rnd(g, B, T_out, n, 5)
+    y[..., -2] = (y[..., -2] > 0.7).double()
+    ey = rnd(g, B, T_out, len(edges), 3)
+    emul = U.Emulator(args.conv, args.resnet, args.recurrent, args, precision=over.get('precision', 'bf16x3'))
+    load_emulator(emul, params, dev)
+    emul.set_norm(*(norms[k].numpy() for k in 'xbyre'))
+    f32 = lambda t: None if t is None else t.float().to(dev)
+    return args, norms, params, emul, (x, a, b, y, ex, ey), tuple(f32(t) for t in (x, a, b, y, ex, ey))
+
+
+@pytest.mark.parametrize('name,over', [('astlingen', dict(embed_size=8, hidden_dim=8, n_sp_layer=1, n_tp_layer=1, if_flood=1)),
+                                       ('shunqing', dict()),
+                                       ('hague', dict(act=False, if_flood=0, edge_fusion=False, resnet=False, n_sp_layer=1)),
+                                       ('astlingen', dict(roll=2, seq_in=4, seq_out=2, n_sp_layer=1))])
+def test_emulator_gradients(dev, networks, name, over):
+    args, norms, params, emul, cpu_in, dev_in = _problem(networks, name, dev, **over)
+    x, a, b, y, ex, ey = cpu_in
+    ref_losses, ref_grads = OT.grads(args, params, norms, x, a, b, y, ex, ey)
+    emul.requires_grad_(True)
+    xd, ad, bd, yd, exd, eyd = dev_in
+    ae = emul.get_edge_action(ad, True) if emul.act else None
+    preds, edge_preds = emul._model(xd, ad, bd, exd, ae, None, True)
+    lw = emul._loss_setup(dev)
+    ls = [emul.get_node_loss(yd, bd, preds)] + ([emul.get_flood_loss(yd, preds)] if emul.if_flood else []) + [emul._mse(eyd, edge_preds, lw['ewei'])]
+    for got, ref in zip(ls, ref_losses):
+        close(got, ref, 5e-4)
+    sum(ls).backward()
+    n_checked = 0
+    gmax = max(float(t.abs().max()) for t in ref_grads.values())
+    for pname, p, ref in emulator_param_pairs(emul, ref_grads):
+        got = p.grad.detach().double().cpu() if p.grad is not None else torch.zeros_like(ref)
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        # relative to the tensor's own largest gradient; the absolute floor only matters for attn_kernel_self, whose
+        # gradient is ~1e-24 (softmax is shift-invariant in s_self: exactly zero where leaky_relu is linear)
+        assert err <= 1e-2 * scale + 1e-10 * gmax, '%s: grad err %.3e vs max|grad| %.3e' % (pname, err, scale)
+        n_checked += 1
+    assert n_checked == len(list(emul.parameters()))
+
+
+def test_fit_eval_steps_match_oracle_adam(dev, networks):
+    args, norms, params, emul, cpu_in, dev_in = _problem(networks, 'astlingen', dev, embed_size=64, n_sp_layer=1, learning_rate=1e-3)
+    x, a, b, y, ex, ey = cpu_in
+    opt = OT.Adam(lr=1e-3)
+    leaves = list(OT.tree_leaves(params))
+    ref_hist = []
+    for _ in range(3):
+        ls, gr = OT.grads(args, params, norms, x, a, b, y, ex, ey)
+        ref_hist.append([float(l) for l in ls])
+        opt.step(leaves, gr)
+    hist = [[float(l) for l in emul.fit_eval(*dev_in)] for _ in range(3)]
+    for h, r in zip(hist, ref_hist):
+        assert np.allclose(h, r, rtol=2e-3, atol=1e-5), (hist, ref_hist)
+    after = dict(OT.tree_leaves(params))
+    for pname, p, ref in emulator_param_pairs(emul, after):
+        err = float((p.detach().double().cpu() - ref).abs().max())
+        assert err <= 3e-4, '%s: parameter after 3 Adam steps differs by %.3e' % (pname, err)       # each step moves <= lr = 1e-3
+    ev = emul.fit_eval(*dev_in, fit=False)
+    assert len(ev) == 3 and all(np.isfinite(float(v)) for v in ev)
+
+
+def test_fit_eval_reduces_the_loss(dev, networks):
+    args, norms, params, emul, cpu_in, dev_in = _problem(networks, 'hague', dev, n_sp_layer=2, learning_rate=2e-3)
+    first = sum(float(v) for v in emul.fit_eval(*dev_in))
+    for _ in range(25):
+        last = sum(float(v) for v in emul.fit_eval(*dev_in))
+    assert last < 0.8 * first, (first, last)
+
+
+def test_training_uses_no_cpu_fallback(dev, networks):
+    args, norms, params, emul, cpu_in, dev_in = _problem(networks, 'astlingen', dev, n_sp_layer=1)
+    emul.requires_grad_(True)
+    with pytest.raises(_lib.UdsError):
+        emul.forward(cpu_in[0].float().requires_grad_(True), cpu_in[2].float(), cpu_in[4].float(),
+                     torch.ones(2, 5, emul.n_edge, 1))

@@ -126,3 +126,23 @@ def load_emulator(emul, p, device):
         dense(emul.flood_out, p['flood_out'])
     dense(emul.e_out_layer, p['e_out'])
     return emul
+
+
+def emulator_param_pairs(emul, flat):
+    """(name, module parameter, tensor) for every entry of `flat` -- a name -> tensor dict keyed like
+    oracle.train_ref.tree_leaves(oracle params) ('block1.0.gat_x.kernel', 'tem1_x.1.bias', 'e_out.kernel', ...)."""
+    out = []
+    for name, t in flat.items():
+        parts = name.split('.')
+        m = emul
+        for i, part in enumerate(parts[:-1]):
+            if part == 'e_out':
+                m = m.e_out_layer
+            elif part in ('block1', 'block2'):
+                m = getattr(m, part).layers
+            elif part.isdigit():
+                m = m[int(part)]
+            else:
+                m = getattr(m, part)
+        out.append((name, getattr(m, parts[-1]), t))
+    return out
