@@ -158,6 +158,70 @@ def bench_c4(args, U, dist, world, rank, dev):
         dist.destroy_process_group()
 
 
+def bench_c5(args, U, dist, world, rank, dev):
+    """BASELINE.json config 5: training forward + backward on a block-diagonal batch of mini-graphs (default 1 000 graphs
+    x 2 000 nodes / 2 500 links, split over the ranks), L-layer GAT spatial block, MSE loss, reverse mode through the HIP
+    backward kernels, one bucketed gradient all-reduce, Adam step.  Unit: one mini-graph through one layer, forward and
+    backward ("training graph-step")."""
+    from gnn_uds_amd import dist as D
+    from gnn_uds_amd.emulator import KerasAdam
+    G_total = 1000 if args.snapshots == 60 else args.snapshots           # --snapshots doubles as the number of mini-graphs
+    n1 = 2000 if args.nodes == 10000 else args.nodes
+    e1 = 2500 if args.links == 12000 else args.links
+    G = max(1, G_total // world)
+    d, L = args.embed, args.layers
+    edges = np.concatenate([U.synthetic_drainage_network(n1, e1, seed=rank * G + k) + n1 * k for k in range(G)])
+    g = U.DrainageGraph.from_edges(edges, n1 * G)
+    block = U.SpatialBlock(g, d, L, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1), precision=args.precision).to(dev)
+    block.requires_grad_(True)
+    params = list(block.parameters())
+    opt = KerasAdam(params, 1e-3, clipnorm=1.0)
+    gen = torch.Generator().manual_seed(2 + rank)
+    x, e = torch.rand(1, g.n_node, d, generator=gen).to(dev), torch.rand(1, g.n_edge, d, generator=gen).to(dev)
+    tx, te = torch.rand(1, g.n_node, d, generator=gen).to(dev), torch.rand(1, g.n_edge, d, generator=gen).to(dev)
+
+    def step():
+        for p in params:
+            p.grad = None
+        ox, oe = block(x, e)
+        loss = ((ox - tx) ** 2).mean() + ((oe - te) ** 2).mean()
+        loss.backward()
+        D.allreduce_gradients(params)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    if rank == 0:
+        units = args.steps * L * G * world
+        print(json.dumps({
+            'metric': 'training graph-steps/sec (one mini-graph through one spatial layer, forward + backward)', 'value': units / wall,
+            'unit': 'graph-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.precision == 'fp32' else 'f32 storage/accumulate, GEMM operands as bf16 hi+lo split (3 MFMA products)',
+            'data': 'synthetic',
+            'config': {'workload': 'C5 training: %d mini-graphs x (N=%d, E=%d) per GPU as one block-diagonal batch, %d-layer GAT spatial '
+                                   'block d=%d, MSE loss, backward, gradient all-reduce, Adam(clipnorm=1)' % (G, n1, e1, L, d),
+                       'precision': args.precision, 'final_loss': float(loss)},
+            'roofline': None}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -171,7 +235,7 @@ def main():
     ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'fp32'],
                     help="bf16x3: fused kernel, GEMM operands split into bf16 hi+lo (3 MFMA products, fp32 accumulate); "
                          "fp32: exact-fp32 unfused kernels")
-    ap.add_argument('--workload', default='headline', choices=['headline', 'c4'],
+    ap.add_argument('--workload', default='headline', choices=['headline', 'c4', 'c5'],
                     help='c4: 200k-node / 240k-link network partitioned over the ranks with per-layer halo exchange')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -191,6 +255,8 @@ def main():
 
     import gnn_uds_amd as U
 
+    if args.workload == 'c5':
+        return bench_c5(args, U, dist if world > 1 else None, world, rank, dev)
     if args.workload == 'c4':
         return bench_c4(args, U, dist, world, rank, dev)
     g = U.DrainageGraph.from_edges(U.synthetic_drainage_network(args.nodes, args.links, seed=0))

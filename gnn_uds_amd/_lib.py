@@ -48,6 +48,8 @@ SYMBOLS = {
     'uds_gat_backward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr,
                                   _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'uds_csr_sddmm': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
+    'uds_wgrad_workspace_floats': (_c_i64, [_c_i64, _c_i64, _c_i64, _c_int]),
+    'uds_wgrad': (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'uds_network_create': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, ctypes.POINTER(_c_ptr)]),
     'uds_network_destroy': (_c_int, [_c_ptr]),
     'uds_network_plan_info': (_c_int, [_c_ptr, _c_ptr]),
@@ -420,6 +422,29 @@ def gat_backward(handle, handle_t, perm_t, grad, hx, s_self, s_nbr, a_self, a_nb
                                 S, d, _dev(ws[0], 'alpha_ws'), _dev(ws[1], 'de_ws'), _dev(d_hx, 'd_hx'),
                                 _dev(ds_self, 'ds_self'), _dev(ds_nbr, 'ds_nbr'), _stream()), 'uds_gat_backward')
     return d_hx, ds_self, ds_nbr
+
+
+def wgrad_supported(F, H, with_bias=True):
+    return load().uds_wgrad_workspace_floats(128, F, H, int(with_bias)) > 0
+
+
+def wgrad(a, g, shift=0, with_bias=True):
+    """d_kernel (F,H) [, d_bias (H)] of out = a @ kernel (+ bias): sums over all rows of a (B,T,R,F)^T g (B,T,R,H), for a
+    causal Conv1D tap with the input `shift` time steps back.  Matrix cores, split-bf16, deterministic."""
+    lib = load()
+    B, T, R, F = a.shape
+    H = g.shape[-1]
+    if tuple(g.shape[:-1]) != (B, T, R):
+        raise UdsError('wgrad: a %r and g %r disagree' % (tuple(a.shape), tuple(g.shape)))
+    n_ws = lib.uds_wgrad_workspace_floats(max(B * T * R, 1), F, H, int(with_bias))
+    if n_ws <= 0:
+        raise UdsError('wgrad: F=%d / H=%d not supported' % (F, H))
+    dk = torch.empty((F, H), device=a.device, dtype=torch.float32)
+    db = torch.empty(H, device=a.device, dtype=torch.float32) if with_bias else None
+    ws = torch.empty(n_ws, device=a.device, dtype=torch.float32)
+    _check(lib.uds_wgrad(_dev(a, 'a'), _dev(g, 'g'), B, T, R, F, H, shift, int(with_bias), _dev(ws, 'workspace'), _dev(dk, 'd_kernel'),
+                         _dev(db, 'd_bias', True), _stream()), 'uds_wgrad')
+    return dk, db
 
 
 def csr_sddmm(handle, a, b):

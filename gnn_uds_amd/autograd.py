@@ -55,6 +55,21 @@ def rows_matmul(x, w, precision='bf16x3'):
     return _lib.dense_act(x3, w.contiguous(), None, 'linear').reshape(lead + (M,))
 
 
+def weight_grad(x, gz, precision, want_bias, shift=0):
+    """(dW, db) of y = x @ W + b summed over all leading axes: the HIP split-K MFMA kernel ('bf16x3'), else rocBLAS."""
+    F, H = x.shape[-1], gz.shape[-1]
+    if precision == 'bf16x3' and _lib.wgrad_supported(F, H, want_bias):
+        x4 = x.contiguous().reshape((1, 1, -1, F)) if shift == 0 else x.contiguous()
+        g4 = gz.contiguous().reshape((1, 1, -1, H)) if shift == 0 else gz.contiguous()
+        return _lib.wgrad(x4, g4, shift, want_bias)
+    if shift:
+        T = x.shape[1]
+        dw = x[:, :T - shift].reshape(-1, F).t().mm(gz[:, shift:].reshape(-1, H)) if shift < T else torch.zeros(F, H, device=x.device)
+    else:
+        dw = x.reshape(-1, F).t().mm(gz.reshape(-1, H))
+    return dw, (gz.reshape(-1, H).sum(0) if want_bias else None)
+
+
 class DenseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kernel, bias, module, act):
@@ -75,8 +90,9 @@ class DenseFn(torch.autograd.Function):
         gz = act_grad(y, gy.contiguous(), ctx.act)
         g2 = gz.reshape(-1, gz.shape[-1])
         dx = rows_matmul(gz, kernel.t(), ctx.precision) if ctx.needs_input_grad[0] else None
-        dw = x.reshape(-1, x.shape[-1]).t().mm(g2) if ctx.needs_input_grad[1] else None
-        db = g2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dw, db = weight_grad(x, gz, ctx.precision, ctx.has_bias and ctx.needs_input_grad[2]) if ctx.needs_input_grad[1] else (None, None)
+        if dw is None and ctx.has_bias and ctx.needs_input_grad[2]:
+            db = g2.sum(0)
         return dx, dw, db, None, None
 
 
@@ -109,12 +125,11 @@ class Conv1DFn(torch.autograd.Function):
             else:
                 dx = _lib.conv1d_causal(gz, kt, None, -ctx.dil, 'linear')
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(kernel)
+            dw = torch.empty_like(kernel)
             for j in range(k):
-                s = (k - 1 - j) * ctx.dil
-                if s < T:
-                    dw[j] = x[:, :T - s].reshape(-1, f).t().mm(gz[:, s:].reshape(-1, h))
-        if ctx.needs_input_grad[2]:
+                dw[j], dbj = weight_grad(x, gz, ctx.precision, j == k - 1 and ctx.needs_input_grad[2], shift=(k - 1 - j) * ctx.dil)
+                db = dbj if dbj is not None else db
+        if db is None and ctx.needs_input_grad[2]:
             db = gz.reshape(-1, h).sum(0)
         return dx, dw, db, None
 
@@ -169,12 +184,12 @@ class GatFn(torch.autograd.Function):
             dxa = dz[..., :fa] if ctx.needs_input_grad[0] else None
             dxb = dz[..., fa:] if xb is not None and ctx.needs_input_grad[1] else None
         if ctx.needs_input_grad[2]:
-            z2 = xa.reshape(-1, fa) if xb is None else torch.cat([xa, xb], dim=-1).reshape(-1, w2.shape[0])
-            dk = z2.t().mm(dh2).reshape(kernel.shape)
-        if ctx.needs_input_grad[3]:
-            das = (ds_self.reshape(1, -1).mm(hx2)).reshape(a_self.shape)
-        if ctx.needs_input_grad[4]:
-            dan = (ds_nbr.reshape(1, -1).mm(hx2)).reshape(a_nbr.shape)
+            z = xa if xb is None else torch.cat([xa, xb], dim=-1)
+            dk = weight_grad(z, d_hx, ctx.precision, False)[0].reshape(kernel.shape)
+        if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+            # d a_self = sum_r ds_self[r] hx[r, :], d a_nbr likewise: one (rows, 2)^T (rows, d) reduction
+            da = weight_grad(torch.stack([ds_self, ds_nbr], dim=-1), hx, ctx.precision, False)[0]
+            das, dan = da[0].reshape(a_self.shape), da[1].reshape(a_nbr.shape)
         if ctx.has_bias and ctx.needs_input_grad[5]:
             db = g.reshape(-1, d).sum(0)
         return dxa, dxb, dk, das, dan, db, None, None, None

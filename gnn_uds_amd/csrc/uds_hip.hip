@@ -17,6 +17,7 @@
 #include "kernels_backward.hpp"
 #include "kernels_fused.hpp"
 #include "kernels_rowgemm.hpp"
+#include "kernels_wgrad.hpp"
 #include "tile_plan.hpp"
 
 namespace {
@@ -395,6 +396,45 @@ int uds_csr_sddmm(const uds_csr_t *csr, const float *a, const float *b, int64_t 
                     csr->nnz};
   hipError_t e = uds::launch_csr_sddmm(sa, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(UDS_EHIP, "uds_csr_sddmm: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
+int64_t uds_wgrad_workspace_floats(int64_t rows, int64_t F, int64_t H, int with_bias) {
+  const int mt = uds::wgrad_mt((int)(F + (with_bias ? 1 : 0))), nt = uds::wgrad_nt((int)H);
+  if (!mt || !nt || rows <= 0) return 0;
+  return (int64_t)uds::wgrad_grid(rows) * mt * 16 * nt * 16;
+}
+
+int uds_wgrad(const float *a, const float *g, int64_t B, int64_t T, int64_t R, int64_t F, int64_t H, int64_t shift, int with_bias,
+              float *workspace, float *d_kernel, float *d_bias, uds_stream_t stream) {
+  UDS_REQUIRE(a && g && workspace && d_kernel, "uds_wgrad: NULL argument");
+  UDS_REQUIRE(!with_bias || d_bias, "uds_wgrad: with_bias needs d_bias");
+  UDS_REQUIRE(B >= 0 && T > 0 && R > 0 && F > 0 && H > 0 && shift >= 0, "uds_wgrad: bad sizes");
+  const int fr = (int)(F + (with_bias ? 1 : 0));
+  const int mt = uds::wgrad_mt(fr), nt = uds::wgrad_nt((int)H);
+  UDS_REQUIRE(mt && nt, "uds_wgrad: F=%lld (at most 128 rows incl. the bias row) or H=%lld (at most 64) not supported", (long long)F, (long long)H);
+  UDS_REQUIRE(B * T * R < INT32_MAX, "uds_wgrad: %lld rows exceed the int32 row index", (long long)(B * T * R));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t rows = B * T * R;
+  if (rows == 0) {
+    hipError_t e0 = hipMemsetAsync(d_kernel, 0, sizeof(float) * F * H, st);
+    if (e0 == hipSuccess && with_bias) e0 = hipMemsetAsync(d_bias, 0, sizeof(float) * H, st);
+    if (e0 != hipSuccess) return fail(UDS_EHIP, "uds_wgrad: memset -> %s", hipGetErrorString(e0));
+    return UDS_OK;
+  }
+  const int grid = uds::wgrad_grid(rows);
+  int64_t rpw = (rows + (int64_t)grid * 4 - 1) / ((int64_t)grid * 4);
+  rpw = (rpw + 31) / 32 * 32;
+  uds::WgradArgs wa{a, g, workspace, rows, (int)F, (int)H, with_bias ? (int)F : -1, (int)shift, (int)T, (int)R, (int)rpw};
+  hipError_t e = uds::launch_wgrad(wa, mt, nt, grid, st);
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_wgrad: launch -> %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(uds::k_wgrad_reduce, dim3((unsigned)((F * H + 15) / 16)), dim3(256), 0, st, workspace, grid, mt * 16, nt * 16,
+                     (int)F, (int)H, d_kernel);
+  if (with_bias)
+    hipLaunchKernelGGL(uds::k_wgrad_reduce, dim3((unsigned)((H + 15) / 16)), dim3(256), 0, st, workspace + F * (nt * 16), grid,
+                       mt * 16, nt * 16, 1, (int)H, d_bias);
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_wgrad: reduce launch -> %s", hipGetErrorString(e));
   return UDS_OK;
 }
 

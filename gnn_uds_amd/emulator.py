@@ -68,17 +68,23 @@ class KerasAdam:
     def step(self):
         self.t += 1
         lr_t = self.lr * (1 - self.b2 ** self.t) ** 0.5 / (1 - self.b1 ** self.t)
-        for p, m, v in zip(self.params, self.m, self.v):
-            if p.grad is None:
-                continue
-            g = p.grad
-            if not bool(torch.isfinite(g).all()):
-                raise FloatingPointError('grads contain NaN/Inf!')
-            if self.clipnorm is not None:
-                g = g * (self.clipnorm / torch.clamp(g.norm(), min=self.clipnorm))
-            m.mul_(self.b1).add_(g, alpha=1 - self.b1)
-            v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
-            p.sub_(lr_t * m / (v.sqrt() + self.eps))
+        idx = [i for i, p in enumerate(self.params) if p.grad is not None]
+        if not idx:
+            return
+        ps, gs = [self.params[i] for i in idx], [self.params[i].grad for i in idx]
+        ms, vs = [self.m[i] for i in idx], [self.v[i] for i in idx]
+        norms = torch.stack(torch._foreach_norm(gs))                      # one launch group, one host sync below
+        if not bool(torch.isfinite(norms).all()):
+            raise FloatingPointError('grads contain NaN/Inf!')
+        if self.clipnorm is not None:
+            gs = torch._foreach_mul(gs, list((self.clipnorm / torch.clamp(norms, min=self.clipnorm)).unbind()))
+        torch._foreach_mul_(ms, self.b1)
+        torch._foreach_add_(ms, gs, alpha=1 - self.b1)
+        torch._foreach_mul_(vs, self.b2)
+        torch._foreach_addcmul_(vs, gs, gs, value=1 - self.b2)
+        den = torch._foreach_sqrt(vs)
+        torch._foreach_add_(den, self.eps)
+        torch._foreach_addcdiv_(ps, ms, den, value=-lr_t)
 
 
 class Emulator(nn.Module):

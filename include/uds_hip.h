@@ -148,6 +148,16 @@ int uds_gat_backward(const uds_csr_t *graph, const uds_csr_t *graph_t, const int
 int uds_csr_sddmm(const uds_csr_t *csr, const float *a, const float *b, int64_t S, int64_t F, float *out,
                   uds_stream_t stream);
 
+/* Weight (and bias) gradient of a row GEMM / causal Conv1D tap on the matrix cores (split-bf16, 3 products):
+ *   d_kernel[f, n] = sum_{b,t,r} a[b, t - shift, r, f] * g[b, t, r, n]   (terms with t < shift dropped),
+ *   d_bias[n]      = sum_{b,t,r} g[b, t, r, n]                            (with_bias != 0),
+ * a:(B,T,R,F), g:(B,T,R,H), F + (with_bias != 0) <= 128 and H <= 64 (uds_wgrad_workspace_floats() == 0 otherwise).
+ * Dense layers: T = 1, shift = 0.  Deterministic (no atomics).  workspace: uds_wgrad_workspace_floats() floats.
+ * Replaces the tape's `X^T dZ` products of emulator.py:457-484 (a library GEMM cannot split this reduction). */
+int64_t uds_wgrad_workspace_floats(int64_t rows, int64_t F, int64_t H, int with_bias);
+int uds_wgrad(const float *a, const float *g, int64_t B, int64_t T, int64_t R, int64_t F, int64_t H, int64_t shift,
+              int with_bias, float *workspace, float *d_kernel, float *d_bias, uds_stream_t stream);
+
 /* ---- one spatial layer (node side + link side) ---------------------------------------------- */
 typedef struct uds_network uds_network_t;
 

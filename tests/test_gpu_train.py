@@ -76,6 +76,25 @@ def test_dense_backward(dev, rows, fi, fo, act, prec):
     close(bd.grad, br.grad, tol)
 
 
+@pytest.mark.parametrize('B,T,R,F,H,shift,bias', [(1, 1, 1000, 64, 32, 0, True), (1, 1, 77, 5, 64, 0, True), (1, 1, 300, 96, 64, 0, True),
+                                                  (1, 1, 4000, 128, 64, 0, False), (2, 9, 40, 64, 64, 2, False), (1, 5, 33, 64, 3, 4, True),
+                                                  (1, 1, 31, 1, 32, 0, True), (1, 3, 20000, 32, 16, 1, True)])
+def test_wgrad_kernel(dev, B, T, R, F, H, shift, bias):
+    """Split-K MFMA weight gradient (split-bf16, 3 products): 2e-4 * max(1, max|ref|) * sqrt(rows / 1000) (fp32 sums over rows)."""
+    g = torch.Generator().manual_seed(R + F)
+    a, gz = rnd(g, B, T, R, F) - 0.5, rnd(g, B, T, R, H) - 0.5
+    ref = a[:, :T - shift].reshape(-1, F).t() @ gz[:, shift:].reshape(-1, H) if shift < T else torch.zeros(F, H, dtype=torch.float64)
+    dk, db = _lib.wgrad(a.float().to(dev), gz.float().to(dev), shift, bias)
+    tol = 2e-4 * max(1.0, (B * T * R / 1000) ** 0.5)
+    close(dk, ref, tol)
+    if bias:
+        close(db, gz.reshape(-1, H).sum(0), tol)
+    else:
+        assert db is None
+    dk2, _ = _lib.wgrad(a.float().to(dev), gz.float().to(dev), shift, bias)
+    assert torch.equal(dk, dk2)                                   # fixed summation order: bitwise reproducible
+
+
 @pytest.mark.parametrize('B,T,R,F,H,dil,act,prec', [(2, 7, 5, 64, 64, 1, 'relu', 'bf16x3'), (1, 12, 3, 64, 64, 4, 'relu', 'bf16x3'),
                                                     (2, 6, 4, 10, 6, 2, 'tanh', 'fp32'), (1, 9, 4200, 32, 32, 2, 'relu', 'bf16x3')])
 def test_conv1d_backward(dev, B, T, R, F, H, dil, act, prec):
