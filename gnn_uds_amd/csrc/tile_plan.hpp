@@ -133,14 +133,102 @@ inline void tile_footprint(const HostCsr &adj, const HostCsr &inc, const std::ve
   for (int32_t q : sec) mark_s[q] = 0;
 }
 
-// p_limit / q_limit (0 = none): a cluster whose primary or secondary footprint exceeds them is bisected in BFS
-// order until it fits, so one outlier cluster does not set the LDS size of every workgroup.
+// Greedy agglomeration of small clusters into tiles that FILL the footprint limits.  A tile costs a workgroup about
+// the same time whether it is half empty or full (its phases are one 16-row block per wave either way), so what counts
+// is the number of tiles.  Seeds are taken in BFS order; a seed keeps absorbing the adjacent cluster it shares the most
+// ADJ entries with, as long as the union still has <= own_limit own rows, <= p_limit primary rows (own + halo) and
+// <= q_limit secondary rows.  Merging neighbours also turns their mutual halo rows into own rows.
+inline void merge_clusters(const HostCsr &adj, const HostCsr &inc, const std::vector<int32_t> &bfs_index, int own_limit, int p_limit,
+                           int q_limit, std::vector<std::vector<int32_t>> &members) {
+  const int32_t n = (int32_t)adj.n_rows;
+  const int nc = (int)members.size();
+  std::vector<int32_t> cluster_of(n, -1);
+  for (int c = 0; c < nc; ++c)
+    for (int32_t r : members[c]) cluster_of[r] = c;
+  std::vector<int32_t> key(nc, INT32_MAX);
+  for (int c = 0; c < nc; ++c)
+    for (int32_t r : members[c]) key[c] = std::min(key[c], bfs_index[r]);
+  std::vector<int32_t> order(nc);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return key[x] < key[y]; });
+  std::vector<char> alive(nc, 1), done(nc, 0);
+  std::vector<int32_t> mark_p(n, 0), mark_s((size_t)inc.n_cols, 0), shared(nc, 0), touched;
+  std::vector<int32_t> trial;
+  for (int32_t seed : order) {
+    if (!alive[seed] || done[seed]) continue;
+    for (;;) {
+      // clusters adjacent to the seed and the number of ADJ entries that cross
+      touched.clear();
+      for (int32_t r : members[seed])
+        for (int32_t p = adj.rowptr[r]; p < adj.rowptr[r + 1]; ++p) {
+          const int32_t c = cluster_of[adj.col[p]];
+          if (c == seed || done[c]) continue;
+          if (shared[c]++ == 0) touched.push_back(c);
+        }
+      std::stable_sort(touched.begin(), touched.end(), [&](int32_t x, int32_t y) { return shared[x] > shared[y]; });
+      int32_t pick = -1;
+      for (int32_t c : touched) {
+        if ((int)(members[seed].size() + members[c].size()) > own_limit) continue;
+        trial.assign(members[seed].begin(), members[seed].end());
+        trial.insert(trial.end(), members[c].begin(), members[c].end());
+        int np_ = 0, nq_ = 0;
+        tile_footprint(adj, inc, trial, mark_p, mark_s, np_, nq_);
+        if (np_ <= p_limit && nq_ <= q_limit) {
+          pick = c;
+          break;
+        }
+      }
+      for (int32_t c : touched) shared[c] = 0;
+      if (pick < 0) break;
+      for (int32_t r : members[pick]) cluster_of[r] = seed;
+      members[seed].insert(members[seed].end(), members[pick].begin(), members[pick].end());
+      std::vector<int32_t>().swap(members[pick]);
+      alive[pick] = 0;
+    }
+    done[seed] = 1;
+  }
+  // Leftovers: pockets the grown tiles closed in.  A tile need not be connected (footprints of distant pieces simply
+  // add), so they are bin-packed -- largest first, first fit among the most recently opened bins, exact footprint.
+  std::vector<std::vector<int32_t>> out, small;
+  for (int32_t c : order)
+    if (alive[c] && !members[c].empty()) {
+      if ((int)members[c].size() * 4 >= own_limit * 3) out.push_back(std::move(members[c]));
+      else small.push_back(std::move(members[c]));
+    }
+  std::stable_sort(small.begin(), small.end(), [](const std::vector<int32_t> &x, const std::vector<int32_t> &y) { return x.size() > y.size(); });
+  std::vector<std::vector<int32_t>> bins;
+  constexpr size_t WINDOW = 48;
+  for (auto &piece : small) {
+    bool placed = false;
+    const size_t first = bins.size() > WINDOW ? bins.size() - WINDOW : 0;
+    for (size_t b = first; b < bins.size() && !placed; ++b) {
+      if ((int)(bins[b].size() + piece.size()) > own_limit) continue;
+      trial.assign(bins[b].begin(), bins[b].end());
+      trial.insert(trial.end(), piece.begin(), piece.end());
+      int np_ = 0, nq_ = 0;
+      tile_footprint(adj, inc, trial, mark_p, mark_s, np_, nq_);
+      if (np_ <= p_limit && nq_ <= q_limit) {
+        bins[b].swap(trial);
+        placed = true;
+      }
+    }
+    if (!placed) bins.push_back(std::move(piece));
+  }
+  for (auto &b : bins) out.push_back(std::move(b));
+  members.swap(out);
+}
+
+// p_limit / q_limit (0 = none): footprint limits of a tile (primary rows incl. halo / secondary rows).  With limits the
+// rows are first packed into small subtree clusters (t_max / 6 rows) which merge_clusters() then agglomerates into
+// tiles of at most t_max own rows that fill the limits; a cluster that still exceeds them (a hub row) is bisected in BFS
+// order until it fits, so one outlier does not set the LDS size of every workgroup.
 inline SidePlan build_side_plan(const HostCsr &adj, const HostCsr &inc, int t_max, int side,
                                 const std::vector<int32_t> *node_bfs, int p_limit = 0, int q_limit = 0) {
   SidePlan plan;
   std::vector<int32_t> cluster_of;
   int n_clusters = 0;
-  cluster_rows(adj, t_max, cluster_of, n_clusters, plan.bfs_index);
+  const bool limits = p_limit > 0 && q_limit > 0;
+  cluster_rows(adj, limits ? std::max(4, t_max / 6) : t_max, cluster_of, n_clusters, plan.bfs_index);
   const int32_t n = (int32_t)adj.n_rows;
   std::vector<std::vector<int32_t>> members(n_clusters);
   for (int32_t r = 0; r < n; ++r) members[cluster_of[r]].push_back(r);   // ascending ids
@@ -164,6 +252,7 @@ inline SidePlan build_side_plan(const HostCsr &adj, const HostCsr &inc, int t_ma
       work.emplace_back(c.begin(), c.begin() + half);
     }
     members.swap(fitted);
+    if (limits) merge_clusters(adj, inc, plan.bfs_index, t_max, p_limit, q_limit, members);
     n_clusters = (int)members.size();
     for (auto &m : members) std::sort(m.begin(), m.end());
   }

@@ -82,8 +82,7 @@ constexpr int64_t FUSED_LDS_BUDGET = 160 * 1024;   // one 8-wave workgroup per C
 constexpr int64_t PACKED_WEIGHT_FLOATS = 2 * (768 + 2048) * 4;   // both sides, F_in up to 96: uint4 = 4 floats
 
 // Tile plan for input rows of f_max floats under the LDS budget: fix the footprint limits (primary / secondary rows
-// staged per tile, multiples of 16) first, then cluster with a row target that typically fills them; clusters that
-// overshoot are bisected by the planner.
+// staged per tile, multiples of 16) first; the planner then fills them (tile_plan.hpp: merge_clusters).
 bool plan_network(const uds::HostCsr &adj, const uds::HostCsr &eadj, const uds::HostCsr &inc_n, const uds::HostCsr &inc_e,
                   int f_max, uds::NetworkPlan &out, int64_t &lds) {
   // candidate (p_limit, q_limit) pairs, largest first; meta is bounded by the limits (checked after planning)
@@ -91,7 +90,7 @@ bool plan_network(const uds::HostCsr &adj, const uds::HostCsr &eadj, const uds::
   for (const auto &c : cand) {
     const int p_lim = c[0], q_lim = c[1];
     if (uds::fused_lds_bytes(p_lim, q_lim, 0, uds::FUSED_H, uds::FUSED_D, f_max, f_max) > FUSED_LDS_BUDGET) continue;
-    const int t = std::max(8, std::min(p_lim * 4 / 5, q_lim * 3 / 5));
+    const int t = std::min(p_lim, 4 * uds::FUSED_WAVES * uds::FUSED_U);        // own rows: P3 covers a tile in one trip
     out = uds::build_network_plan(adj, eadj, inc_n, inc_e, t, t, p_lim, q_lim);
     lds = uds::fused_lds_bytes(out.p_cap, out.q_cap, out.meta_cap, uds::FUSED_H, uds::FUSED_D, f_max, f_max);
     if (lds <= FUSED_LDS_BUDGET && out.p_cap <= 4 * uds::FUSED_WAVES * uds::FUSED_U) return true;   // P3 covers a tile in one trip
@@ -632,9 +631,20 @@ int uds_spatial_layer_forward(const uds_network_t *net, const uds_spatial_params
 #endif
     // one workgroup per CU: ~5 rounds of 256 workgroups keep the tail short, while a workgroup stays on its tile
     // for as many snapshots as that allows (metadata, weights and the DMA pipeline are set up once per workgroup)
-    int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>(S, (1280 + a.n_tiles - 1) / a.n_tiles));
-    int64_t chunk = (S + n_chunks - 1) / n_chunks;
-    n_chunks = (S + chunk - 1) / chunk;
+    // Snapshots are cut into chunks; one workgroup = (tile, chunk).  All workgroups take about the same time
+    // (setup ~1.5 snapshots' worth + its snapshots), one per CU at a time, so the launch lasts ~ceil(grid / 256) rounds:
+    // pick the chunk length that minimises rounds * (setup + chunk).
+    int64_t chunk = S, best = INT64_MAX;
+    for (int64_t c = 1; c <= S; ++c) {
+      const int64_t n_c = (S + c - 1) / c;
+      const int64_t rounds = (n_c * a.n_tiles + 255) / 256;
+      const int64_t cost = rounds * (3 + 2 * c);          // in half snapshots
+      if (cost < best || (cost == best && c < chunk)) {
+        best = cost;
+        chunk = c;
+      }
+    }
+    int64_t n_chunks = (S + chunk - 1) / chunk;
     a.chunk = (int)chunk;
     const int grid = (int)(n_chunks * a.n_tiles);
     const int64_t lds_need = uds::fused_lds_bytes(a.p_cap, a.q_cap, a.meta_cap, uds::FUSED_H, uds::FUSED_D, (int)std::max(fx, fe),

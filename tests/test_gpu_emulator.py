@@ -181,6 +181,4 @@ def test_save_load_and_not_built(dev, networks, tmp_path):
     y1, e1 = other.predict_tf(f(X), f(Bd), f(a), f(Ex))
     assert torch.equal(y0, y1) and torch.equal(e0, e1)
     with pytest.raises(NotImplementedError):
-        emul.fit_eval()
-    with pytest.raises(NotImplementedError):
         U.Emulator('GAT', False, 'GRU', args)
