@@ -144,6 +144,27 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // wait until all but the n youngest vector-memory operations of this wave are done (n = the output stores it
 // issued last: CDNA4 counts stores in vmcnt too, and the DMA pieces are older than they are)
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+
+#ifndef UDS_P3_SLOTS
+#define UDS_P3_SLOTS 2
+#endif
+constexpr int P3_SLOTS = UDS_P3_SLOTS;      // neighbour slots per P3 step (reads in flight per row group)
+
+// value of lane K of this lane's 16-lane row (v_mov_b32_dpp row_newbcast:K), K compile-time
+template <int K>
+__device__ __forceinline__ int row16_bcast(int v) {
+  static_assert(K >= 0 && K < 16, "lane inside a 16-lane row");
+  return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xf, 0xf, true);      // every lane is written: no `old` value to set up
+}
+
 __device__ __forceinline__ void wait_all_but(int n) {
   switch (n) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -229,20 +250,12 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
   float *s_self = reinterpret_cast<float *>(smem + a.meta_cap);
   float *s_nbr = s_self + a.p_cap;
   float *attn = s_nbr + a.p_cap;                 // a_self[64] | a_nbr[64]
-  float *scratch = attn + 2 * FUSED_D + FUSED_H; // P3: per wave U x 64 (weight, neighbour) pairs = 2 KiB
-  float *sec = scratch + NW * U * 64 * 2;
+  float *sec = attn + 2 * FUSED_D + FUSED_H;
   float *hx = sec + a.q_cap * SEC_STRIDE;
   float *stage_s = hx + a.p_cap * FUSED_D;       // (q_cap/16) blocks x KT_S x 2 pieces x 1 KiB, fragment order
   float *stage_p = stage_s + a.q_cap * FS;       // (p_cap/16) blocks x KT_X x 2 pieces x 1 KiB
 
   for (int i = tid; i < meta_len; i += NT) meta[i] = a.pool[pool_off + i];
-  // weights: one copy global -> LDS (the stage is still free), then every lane picks its fragments
-  {
-    constexpr int NS = KT_S * MB_S * 2 * 64, NB = KT_B * MB_B * 2 * 64;
-    uint4 *wst = reinterpret_cast<uint4 *>(stage_s);
-    for (int i = tid; i < NS; i += NT) wst[i] = S_.w_small[i];
-    for (int i = tid; i < NB; i += NT) wst[NS + i] = S_.w_big[i];
-  }
   __syncthreads();
   const int32_t *prim_ids = meta;
   const int32_t *sec_ids = prim_ids + n_prim;
@@ -251,37 +264,8 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
   int32_t *inc_w = const_cast<int32_t *>(inc_loc) + n_inc;
   const int32_t *adj_ptr = inc_w + n_inc;
   const int32_t *adj_loc = adj_ptr + n_own + 1;
-  for (int i = tid; i < n_inc; i += NT) reinterpret_cast<float *>(inc_w)[i] = S_.ne_val[inc_w[i]];
   const float *inc_val = reinterpret_cast<const float *>(inc_w);
-
-  bf16x8 wsh[KT_S][MB_S], wsl[KT_S][MB_S], wbh[KT_B][MB_B], wbl[KT_B][MB_B];
-  {
-    const uint4 *wst = reinterpret_cast<const uint4 *>(stage_s);
-    constexpr int NS = KT_S * MB_S * 2 * 64;
-#pragma unroll
-    for (int t = 0; t < KT_S; ++t)
-#pragma unroll
-      for (int m = 0; m < MB_S; ++m) {
-        wsh[t][m] = __builtin_bit_cast(bf16x8, wst[((t * MB_S + m) * 2 + 0) * 64 + lane]);
-        wsl[t][m] = __builtin_bit_cast(bf16x8, wst[((t * MB_S + m) * 2 + 1) * 64 + lane]);
-      }
-#pragma unroll
-    for (int t = 0; t < KT_B; ++t)
-#pragma unroll
-      for (int m = 0; m < MB_B; ++m) {
-        wbh[t][m] = __builtin_bit_cast(bf16x8, wst[NS + ((t * MB_B + m) * 2 + 0) * 64 + lane]);
-        wbl[t][m] = __builtin_bit_cast(bf16x8, wst[NS + ((t * MB_B + m) * 2 + 1) * 64 + lane]);
-      }
-  }
-  if (tid < FUSED_D) {   // attention vectors and the small GEMM's bias live in LDS (read once per 16-row block)
-    attn[tid] = S_.a_self[tid];
-    attn[FUSED_D + tid] = S_.a_nbr[tid];
-    if (tid < FUSED_H) attn[2 * FUSED_D + tid] = S_.b_small ? S_.b_small[tid] : 0.f;
-  }
   const int c16 = lane & 15, rs = lane >> 4;     // P3 mapping: 16 lanes x float4 per output row, 4 rows per group
-  f32x4 bo = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (S_.b_out) bo = *reinterpret_cast<const f32x4 *>(S_.b_out + 4 * c16);
-  __syncthreads();   // weights are in registers: the stage may now be overwritten by the DMA
 
   // LDS-DMA of one 16-row block in fragment order: piece (t, i) of lane (r16, qd) = floats 32t + 16i + 4qd .. +3
   // of row r16 of the block.  The destination is wave-uniform (base + lane * 16 B is implicit).  Row offsets do not
@@ -327,8 +311,37 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
     for (int blk = wave; blk * 16 < n_sec; blk += NW) dma_sec(blk, s_begin);
     for (int blk = wave; blk * 16 < n_prim; blk += NW) dma_prim(blk, s_begin);
   }
+  // everything below overlaps with the first snapshot's DMA
+  for (int i = tid; i < n_inc; i += NT) reinterpret_cast<float *>(inc_w)[i] = S_.ne_val[inc_w[i]];
+
+  if (tid < FUSED_D) {   // attention vectors and the small GEMM's bias live in LDS (read once per 16-row block)
+    attn[tid] = S_.a_self[tid];
+    attn[FUSED_D + tid] = S_.a_nbr[tid];
+    if (tid < FUSED_H) attn[2 * FUSED_D + tid] = S_.b_small ? S_.b_small[tid] : 0.f;
+  }
+  f32x4 bo = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (S_.b_out) bo = *reinterpret_cast<const f32x4 *>(S_.b_out + 4 * c16);
+
+  // weight fragments straight from global memory into registers (every wave reads the same 22-45 KB: L2 / L1 hits after
+  // the first), issued AFTER the first snapshot's DMA so both latencies overlap
+  bf16x8 wsh[KT_S][MB_S], wsl[KT_S][MB_S], wbh[KT_B][MB_B], wbl[KT_B][MB_B];
+#pragma unroll
+  for (int t = 0; t < KT_S; ++t)
+#pragma unroll
+    for (int m = 0; m < MB_S; ++m) {
+      wsh[t][m] = __builtin_bit_cast(bf16x8, S_.w_small[((t * MB_S + m) * 2 + 0) * 64 + lane]);
+      wsl[t][m] = __builtin_bit_cast(bf16x8, S_.w_small[((t * MB_S + m) * 2 + 1) * 64 + lane]);
+    }
+#pragma unroll
+  for (int t = 0; t < KT_B; ++t)
+#pragma unroll
+    for (int m = 0; m < MB_B; ++m) {
+      wbh[t][m] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + m) * 2 + 0) * 64 + lane]);
+      wbl[t][m] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + m) * 2 + 1) * 64 + lane]);
+    }
+  __syncthreads();   // NodeEdge values, attention vectors and bias are in LDS
   int n_st = 0;   // output-store instructions this wave issued in the previous P3 (still in flight, younger than the DMA)
-  UDS_STAMP(0);   // setup: metadata, weights, first DMA issue
+  UDS_STAMP(0);   // setup: metadata, first DMA issue, weights
 
   for (int s = s_begin; s < s_end; ++s) {
     wait_all_but(n_st);    // this wave's stage slots for snapshot s have landed
@@ -500,58 +513,56 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
           const float sc = leaky02(ss[u] + s_nbr[jn[u]]);
           lg[u] = c16 < deg[u] ? sc : -INFINITY;
         }
-        float2 *scr = reinterpret_cast<float2 *>(scratch) + wave * (U * 64);   // (weight, neighbour) per (u, lane)
+        int joff[U];      // byte offset of the neighbour's hx row with its swizzle key in bits 4-6: j*256 + (j&7)*16
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const float mx = row16_max(lg[u]);
           const float ex = __builtin_amdgcn_exp2f((lg[u] - mx) * 1.44269504088896340736f);
           wgt[u] = c16 < deg[u] ? ex : 0.f;     // rows past the tile have degree 0: every weight 0, the NaN of -inf - -inf dropped
           den[u] = row16_sum(wgt[u]);
-          // neighbour stored as the byte offset of its hx row with the swizzle key in the low bits: j*256 + (j&7)*16
-          scr[u * 64 + lane] = make_float2(wgt[u], __int_as_float(jn[u] * (FUSED_D * 4) + ((jn[u] & 7) << 4)));
+          joff[u] = jn[u] * (FUSED_D * 4) + ((jn[u] & 7) << 4);
         }
-        // Two neighbours per trip and row group: one 16-B broadcast read fetches (w_k, j_k, w_k+1, j_k+1) for the 16
-        // lanes of a group, two row reads follow.  Groups whose longest list is exhausted are skipped (wave-uniform).
-        // Slots beyond a row's degree hold weight 0 and row 0.
-        const float4 *pair = reinterpret_cast<const float4 *>(scr) + (lane >> 4) * 8;
+        // Lane c of a 16-lane row group holds (weight, offset) of neighbour c.  Neighbour K reaches the row's other
+        // lanes by a DPP row broadcast (v_mov_b32_dpp row_newbcast:K): no LDS round trip for the pairs.  The XOR with
+        // the lane's own chunk offset (c16 << 4) applies the hx swizzle: bits 4-6 key ^ chunk, bits >= 8 the row.
+        // Two neighbour slots per step and row group, all reads of a step in flight together; groups whose longest
+        // list is exhausted drop out (wave-uniform).  Slots beyond a row's degree hold weight 0 and row 0.
         const char *hxb = reinterpret_cast<const char *>(hx);
         const int cx = c16 << 4;
-        // Straight-line trips over the first A groups (no branches inside a trip, so all its LDS reads are in flight
-        // together); A shrinks as the shorter groups run out: e[u] = longest list among groups u..U-1.
-        auto trip = [&](auto A_, int k) {
-          constexpr int A = decltype(A_)::value;
+        auto step = [&](auto K_, auto A_) {
+          constexpr int K = decltype(K_)::value, A = decltype(A_)::value, W = P3_SLOTS;
+          f32x4 hh[A][W];
 #pragma unroll
-          for (int u0 = 0; u0 < A; u0 += 2) {       // two groups at a time: 2 pair reads, then 4 row reads in flight
-            constexpr int Z = 0;
-            const int n = (A - u0) < 2 ? (A - u0) : 2;
-            float4 wj[2];
-            f32x4 h0[2], h1[2];
+          for (int u = 0; u < A; ++u)
+            static_for<W>([&](auto i_) {
+              constexpr int i = decltype(i_)::value;
+              hh[u][i] = *reinterpret_cast<const f32x4 *>(hxb + (row16_bcast<K + i>(joff[u]) ^ cx));
+            });
 #pragma unroll
-            for (int v = 0; v < 2; ++v)
-              if (v < n) wj[v] = pair[(u0 + v) * 32 + (k >> 1)];
+          for (int u = 0; u < A; ++u)
+            static_for<W>([&](auto i_) {
+              constexpr int i = decltype(i_)::value;
+              const float w = __int_as_float(row16_bcast<K + i>(__float_as_int(wgt[u])));
 #pragma unroll
-            for (int v = 0; v < 2; ++v)
-              if (v < n) {
-                const int j0 = __float_as_int(wj[v].y), j1 = __float_as_int(wj[v].w);
-                h0[v] = *reinterpret_cast<const f32x4 *>(hxb + ((cx ^ (j0 & 0x70)) + (j0 & ~0xff)));
-                h1[v] = *reinterpret_cast<const f32x4 *>(hxb + ((cx ^ (j1 & 0x70)) + (j1 & ~0xff)));
-              }
-#pragma unroll
-            for (int v = 0; v < 2; ++v)
-              if (v < n) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                  acc[u0 + v][q] = fmaf(wj[v].z, h1[v][q], fmaf(wj[v].x, h0[v][q], acc[u0 + v][q]));
-              }
-            (void)Z;
-          }
+              for (int q = 0; q < 4; ++q) acc[u][q] = fmaf(w, hh[u][i][q], acc[u][q]);
+            });
         };
         const int e3 = dmax[3], e2 = max(e3, dmax[2]), e1 = max(e2, dmax[1]), e0 = max(e1, dmax[0]);
-        int k = 0;
-        for (; k < e3; k += 2) trip(std::integral_constant<int, 4>{}, k);
-        for (; k < e2; k += 2) trip(std::integral_constant<int, 3>{}, k);
-        for (; k < e1; k += 2) trip(std::integral_constant<int, 2>{}, k);
-        for (; k < e0; k += 2) trip(std::integral_constant<int, 1>{}, k);
+        auto steps = [&](auto K_) {      // slots K .. K+W-1: as many groups as still have neighbours there
+          constexpr int K = decltype(K_)::value;
+          if (K < e3) step(K_, std::integral_constant<int, 4>{});
+          else if (K < e2) step(K_, std::integral_constant<int, 3>{});
+          else if (K < e1) step(K_, std::integral_constant<int, 2>{});
+          else step(K_, std::integral_constant<int, 1>{});
+        };
+        bool more = e0 > 0;
+        static_for<16 / P3_SLOTS>([&](auto t_) {
+          constexpr int K = decltype(t_)::value * P3_SLOTS;
+          if (more) {
+            steps(std::integral_constant<int, K>{});
+            more = e0 > K + P3_SLOTS;
+          }
+        });
       } else {   // some row has more than 16 neighbours: every lane walks its row's whole list
 #pragma unroll
         for (int u = 0; u < U; ++u) {

@@ -343,8 +343,7 @@ inline SidePlan build_side_plan(const HostCsr &adj, const HostCsr &inc, int t_ma
 inline int64_t fused_lds_bytes(int p_cap, int q_cap, int meta_cap, int h, int d, int fp, int fs) {
   const int64_t weights = 16 * 64 * 2 * ((int64_t)(fs / 32) * (h / 16) + (int64_t)((fp + h) / 32) * (d / 16));
   const int64_t stage = std::max<int64_t>(4 * ((int64_t)q_cap * fs + (int64_t)p_cap * fp), weights);
-  const int64_t scratch = 8 * 4 * 64 * 2;   // P3: 8 waves x 4 row groups x 64 (weight, neighbour) pairs (floats)
-  return 4 * ((int64_t)meta_cap + 2 * p_cap + 2 * d + h + scratch + (int64_t)q_cap * (h + 4) + (int64_t)p_cap * d) + stage;
+  return 4 * ((int64_t)meta_cap + 2 * p_cap + 2 * d + h + (int64_t)q_cap * (h + 4) + (int64_t)p_cap * d) + stage;
 }
 
 // Both sides of a network merged into one tile list ordered by locality key, so that the node tile and

@@ -86,7 +86,7 @@ constexpr int64_t PACKED_WEIGHT_FLOATS = 2 * (768 + 2048) * 4;   // both sides, 
 bool plan_network(const uds::HostCsr &adj, const uds::HostCsr &eadj, const uds::HostCsr &inc_n, const uds::HostCsr &inc_e,
                   int f_max, uds::NetworkPlan &out, int64_t &lds) {
   // candidate (p_limit, q_limit) pairs, largest first; meta is bounded by the limits (checked after planning)
-  const int cand[][2] = {{128, 176}, {112, 160}, {96, 144}, {80, 128}, {64, 96}, {48, 64}, {32, 48}, {16, 32}};
+  const int cand[][2] = {{128, 208}, {128, 192}, {128, 176}, {112, 160}, {96, 144}, {80, 128}, {64, 96}, {48, 64}, {32, 48}, {16, 32}};
   for (const auto &c : cand) {
     const int p_lim = c[0], q_lim = c[1];
     if (uds::fused_lds_bytes(p_lim, q_lim, 0, uds::FUSED_H, uds::FUSED_D, f_max, f_max) > FUSED_LDS_BUDGET) continue;

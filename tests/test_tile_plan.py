@@ -71,19 +71,23 @@ def test_plan_with_isolated_rows_and_self_loop_link():
 
 
 def test_headline_plan_fits_the_cu_lds():
-    """The plan uds_network_create builds for 64-float rows: footprint limits (128 primary / 176 secondary rows)
-    are enforced by bisecting outlier clusters, halos stay a modest fraction, LDS <= 160 KiB (one 8-wave workgroup per CU)."""
+    """The plan uds_network_create builds for 64-float rows (own rows <= 128, footprint limits 128 primary / 208
+    secondary rows): the agglomeration fills the limits (few, full tiles), halos stay a modest fraction, LDS <= 160 KiB
+    (one 8-wave workgroup per CU)."""
     g = U.DrainageGraph.from_edges(U.synthetic_drainage_network(10000, 12000, 0))
-    hdr, pool, caps = _lib.tile_plan(g, 102, 102, 128, 176)
-    check_plan(g, hdr, pool, caps, 102, 102)
-    assert caps['p_cap'] <= 128 and caps['q_cap'] <= 176
+    hdr, pool, caps = _lib.tile_plan(g, 128, 128, 128, 208)
+    check_plan(g, hdr, pool, caps, 128, 128)
+    assert caps['p_cap'] <= 128 and caps['q_cap'] <= 208
     for side, n in ((0, g.n_node), (1, g.n_edge)):
         h = hdr[hdr[:, 6] == side]
         assert h[:, 0].sum() == n
-        assert h[:, 1].sum() <= 1.5 * n                    # prim rows (own + halo) per side
-    # LDS of the fused kernel at F = 64: meta + scalars + P3 scratch + sec rows + hx rows + DMA stage of raw rows
-    lds = 4 * (160 + 4096 + caps["meta_cap"] + 2 * caps["p_cap"] + caps['q_cap'] * 36 + caps['p_cap'] * 64) + \
+        assert h[:, 1].sum() <= 1.25 * n                   # prim rows (own + halo) per side
+        assert h[:, 0].mean() >= 100                       # tiles are filled: a half-empty tile costs a workgroup the same time
+        assert np.ceil(h[:, 1] / 16).mean() >= 7.5         # ~8 sixteen-row blocks for the 8 waves
+    assert len(hdr) <= 215
+    # LDS of the fused kernel at F = 64: meta + scalars + sec rows + hx rows + DMA stage of raw rows
+    lds = 4 * (160 + caps["meta_cap"] + 2 * caps["p_cap"] + caps['q_cap'] * 36 + caps['p_cap'] * 64) + \
         256 * (caps['q_cap'] + caps['p_cap'])
     assert lds <= 160 * 1024
-    a, b, c = _lib.tile_plan(g, 102, 102, 128, 176)
+    a, b, c = _lib.tile_plan(g, 128, 128, 128, 208)
     assert np.array_equal(a, hdr) and np.array_equal(b, pool)   # deterministic
