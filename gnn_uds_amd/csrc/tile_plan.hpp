@@ -343,7 +343,8 @@ inline SidePlan build_side_plan(const HostCsr &adj, const HostCsr &inc, int t_ma
 inline int64_t fused_lds_bytes(int p_cap, int q_cap, int meta_cap, int h, int d, int fp, int fs) {
   const int64_t weights = 16 * 64 * 2 * ((int64_t)(fs / 32) * (h / 16) + (int64_t)((fp + h) / 32) * (d / 16));
   const int64_t stage = std::max<int64_t>(4 * ((int64_t)q_cap * fs + (int64_t)p_cap * fp), weights);
-  return 4 * ((int64_t)meta_cap + 2 * p_cap + 2 * d + h + (int64_t)q_cap * (h + 4) + (int64_t)p_cap * d) + stage;
+  const int64_t cold = (fp > 64 ? (d / 16) * 2 * 1024 : 0) + (fs > 64 ? (h / 16) * 2 * 1024 : 0);   // LDS-resident third k-step
+  return 4 * ((int64_t)meta_cap + 2 * p_cap + 2 * d + h + (int64_t)q_cap * (h + 4) + (int64_t)p_cap * d) + cold + stage;
 }
 
 // Both sides of a network merged into one tile list ordered by locality key, so that the node tile and

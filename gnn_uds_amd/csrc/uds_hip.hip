@@ -629,34 +629,37 @@ int uds_spatial_layer_forward(const uds_network_t *net, const uds_spatial_params
 #ifdef UDS_PHASE_TIMING
     a.dbg = reinterpret_cast<unsigned long long *>(ws + PACKED_WEIGHT_FLOATS);   // diagnostic build: stamps go to the (otherwise unused) workspace
 #endif
-    // one workgroup per CU: ~5 rounds of 256 workgroups keep the tail short, while a workgroup stays on its tile
-    // for as many snapshots as that allows (metadata, weights and the DMA pipeline are set up once per workgroup)
-    // Snapshots are cut into chunks; one workgroup = (tile, chunk).  All workgroups take about the same time
-    // (setup ~1.5 snapshots' worth + its snapshots), one per CU at a time, so the launch lasts ~ceil(grid / 256) rounds:
-    // pick the chunk length that minimises rounds * (setup + chunk).
-    int64_t chunk = S, best = INT64_MAX;
-    for (int64_t c = 1; c <= S; ++c) {
-      const int64_t n_c = (S + c - 1) / c;
-      const int64_t rounds = (n_c * a.n_tiles + 255) / 256;
-      const int64_t cost = rounds * (3 + 2 * c);          // in half snapshots
-      if (cost < best || (cost == best && c < chunk)) {
-        best = cost;
-        chunk = c;
+    // Snapshots are cut into chunks; one workgroup = (tile, chunk).  All working workgroups take about the same time
+    // (setup ~1.5 snapshots' worth + its snapshots), one per CU at a time, so a launch lasts ~ceil(working / 256) rounds:
+    // pick the chunk length that minimises rounds * (setup + chunk).  (Metadata, weights and the DMA pipeline are set
+    // up once per workgroup, so long chunks are cheap; a launch for one side only skips the other side's tiles at once.)
+    auto set_chunk = [&](int64_t working_tiles) {
+      int64_t chunk = S, best = INT64_MAX;
+      for (int64_t c = 1; c <= S; ++c) {
+        const int64_t n_c = (S + c - 1) / c;
+        const int64_t rounds = (n_c * working_tiles + 255) / 256;
+        const int64_t cost = rounds * (3 + 2 * c);          // in half snapshots
+        if (cost < best || (cost == best && c < chunk)) {
+          best = cost;
+          chunk = c;
+        }
       }
-    }
-    int64_t n_chunks = (S + chunk - 1) / chunk;
-    a.chunk = (int)chunk;
-    const int grid = (int)(n_chunks * a.n_tiles);
+      a.chunk = (int)chunk;
+      return (int)(((S + chunk - 1) / chunk) * a.n_tiles);
+    };
     const int64_t lds_need = uds::fused_lds_bytes(a.p_cap, a.q_cap, a.meta_cap, uds::FUSED_H, uds::FUSED_D, (int)std::max(fx, fe),
                                                   (int)std::max(fx, fe));
     if (fx == fe) {
       a.side_mask = 3;
+      const int grid = set_chunk(a.n_tiles);
       he = (fx == 64) ? launch_fused<64, 64>(a, grid, lds_need, st) : launch_fused<96, 96>(a, grid, lds_need, st);
     } else {   // node tiles: FP = fx, FS = fe; link tiles: FP = fe, FS = fx -> one launch per side
       a.side_mask = 1;
+      int grid = set_chunk(sl.plan.side[0].n_tiles);
       he = (fx == 64) ? launch_fused<64, 96>(a, grid, lds_need, st) : launch_fused<96, 64>(a, grid, lds_need, st);
       if (he == hipSuccess) {
         a.side_mask = 2;
+        grid = set_chunk(sl.plan.side[1].n_tiles);
         he = (fe == 64) ? launch_fused<64, 96>(a, grid, lds_need, st) : launch_fused<96, 64>(a, grid, lds_need, st);
       }
     }
