@@ -153,6 +153,12 @@ __device__ __forceinline__ void static_for(F &&f) {
   }
 }
 
+#ifdef UDS_SMALL_IN_LDS
+constexpr bool SMALL_IN_LDS = true;     // the fusion-MLP weights (32 VGPRs) live in LDS, read per 16-row block
+#else
+constexpr bool SMALL_IN_LDS = false;
+#endif
+
 #ifndef UDS_P3_SLOTS
 #define UDS_P3_SLOTS 2
 #endif
@@ -252,11 +258,12 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
   float *attn = s_nbr + a.p_cap;                 // a_self[64] | a_nbr[64]
   // 96-wide inputs: the weight fragments of the third 32-wide k-step stay in LDS ("cold": read per 16-row block) so
   // that the register-resident set is the same as for 64-wide inputs (no spills)
-  constexpr bool COLD_X = FP > 64, COLD_S = FS > 64;
-  constexpr int T_COLD_X = KT_X - 1, T_COLD_S = KT_S - 1;
+  constexpr bool COLD_X = FP > 64, COLD_S = FS > 64 || SMALL_IN_LDS;
+  constexpr int T_COLD_X = KT_X - 1, T_COLD_S = SMALL_IN_LDS ? 0 : KT_S - 1;     // first k-step that lives in LDS
+  constexpr int N_COLD_S = (KT_S - T_COLD_S) * MB_S * 2 * 64;
   uint4 *cold_b = reinterpret_cast<uint4 *>(attn + 2 * FUSED_D + FUSED_H);     // MB_B x 2 fragments x 64 lanes
-  uint4 *cold_s = cold_b + (COLD_X ? MB_B * 2 * 64 : 0);                        // MB_S x 2 fragments x 64 lanes
-  float *sec = reinterpret_cast<float *>(cold_s + (COLD_S ? MB_S * 2 * 64 : 0));
+  uint4 *cold_s = cold_b + (COLD_X ? MB_B * 2 * 64 : 0);                        // (KT_S - T_COLD_S) x MB_S x 2 fragments x 64 lanes
+  float *sec = reinterpret_cast<float *>(cold_s + (COLD_S ? N_COLD_S : 0));
   float *hx = sec + a.q_cap * SEC_STRIDE;
   float *stage_s = hx + a.p_cap * FUSED_D;       // (q_cap/16) blocks x KT_S x 2 pieces x 1 KiB, fragment order
   float *stage_p = stage_s + a.q_cap * FS;       // (p_cap/16) blocks x KT_X x 2 pieces x 1 KiB
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
   for (int t = 0; t < KT_S; ++t)
 #pragma unroll
     for (int m = 0; m < MB_S; ++m) {
-      if (COLD_S && t == T_COLD_S) continue;
+      if (COLD_S && t >= T_COLD_S) continue;
       wsh[t][m] = __builtin_bit_cast(bf16x8, S_.w_small[((t * MB_S + m) * 2 + 0) * 64 + lane]);
       wsl[t][m] = __builtin_bit_cast(bf16x8, S_.w_small[((t * MB_S + m) * 2 + 1) * 64 + lane]);
     }
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
   if (COLD_X)
     for (int i = tid; i < MB_B * 2 * 64; i += NT) cold_b[i] = S_.w_big[T_COLD_X * MB_B * 2 * 64 + i];
   if (COLD_S)
-    for (int i = tid; i < MB_S * 2 * 64; i += NT) cold_s[i] = S_.w_small[T_COLD_S * MB_S * 2 * 64 + i];
+    for (int i = tid; i < N_COLD_S; i += NT) cold_s[i] = S_.w_small[T_COLD_S * MB_S * 2 * 64 + i];
   __syncthreads();   // NodeEdge values, attention vectors and bias are in LDS
   int n_st = 0;   // output-store instructions this wave issued in the previous P3 (still in flight, younger than the DMA)
   UDS_STAMP(0);   // setup: metadata, first DMA issue, weights
@@ -376,9 +383,9 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
       for (int t = 0; t < KT_S; ++t)
 #pragma unroll
         for (int m = 0; m < MB_S; ++m) {
-          if (COLD_S && t == T_COLD_S)
-            acc[m] = mfma3(__builtin_bit_cast(bf16x8, cold_s[(m * 2 + 0) * 64 + lane]), __builtin_bit_cast(bf16x8, cold_s[(m * 2 + 1) * 64 + lane]),
-                           dh[t], dl[t], acc[m]);
+          if (COLD_S && t >= T_COLD_S)
+            acc[m] = mfma3(__builtin_bit_cast(bf16x8, cold_s[(((t - T_COLD_S) * MB_S + m) * 2 + 0) * 64 + lane]),
+                           __builtin_bit_cast(bf16x8, cold_s[(((t - T_COLD_S) * MB_S + m) * 2 + 1) * 64 + lane]), dh[t], dl[t], acc[m]);
           else
             acc[m] = mfma3(wsh[t][m], wsl[t][m], dh[t], dl[t], acc[m]);
         }

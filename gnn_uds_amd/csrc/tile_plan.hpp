@@ -35,7 +35,7 @@ struct SidePlan {
   std::vector<int32_t> hdr;                // n_tiles * TILE_HDR_INTS
   std::vector<int32_t> pool;               // per tile: prim[n_prim] sec[n_sec] inc_ptr[n_prim+1] inc_loc[n_inc]
                                            //           inc_w[n_inc] adj_ptr[n_own+1] adj_loc[n_adj]
-  std::vector<int32_t> key;                // locality key per tile (min BFS index of a node it touches)
+  std::vector<int32_t> key;                // locality key per tile (median BFS index of the nodes it touches)
   std::vector<int32_t> bfs_index;          // BFS visiting index of every primary row
 };
 
@@ -316,13 +316,20 @@ inline SidePlan build_side_plan(const HostCsr &adj, const HostCsr &inc, int t_ma
     const int32_t meta_len = (int32_t)plan.pool.size() - off;
     while (plan.pool.size() % 4) plan.pool.push_back(0);   // keep every tile's block 16-B aligned
 
-    int32_t key = INT32_MAX;
+    // locality key = MEDIAN node BFS index the tile touches (for links: of their end nodes): node tiles and link tiles of
+    // the same area sort next to each other, whatever shape the agglomeration gave them
+    std::vector<int32_t> ks;
     for (int32_t r : own) {
       if (node_bfs) {
-        for (int32_t p = inc.rowptr[r]; p < inc.rowptr[r + 1]; ++p) key = std::min(key, (*node_bfs)[inc.col[p]]);
+        for (int32_t p = inc.rowptr[r]; p < inc.rowptr[r + 1]; ++p) ks.push_back((*node_bfs)[inc.col[p]]);
       } else {
-        key = std::min(key, plan.bfs_index[r]);
+        ks.push_back(plan.bfs_index[r]);
       }
+    }
+    int32_t key = INT32_MAX;
+    if (!ks.empty()) {
+      std::nth_element(ks.begin(), ks.begin() + ks.size() / 2, ks.end());
+      key = ks[ks.size() / 2];
     }
     plan.key.push_back(key);
     const int32_t h[TILE_HDR_INTS] = {(int32_t)own.size(), (int32_t)prim.size(), (int32_t)sec.size(), (int32_t)inc_loc.size(),
@@ -343,7 +350,11 @@ inline SidePlan build_side_plan(const HostCsr &adj, const HostCsr &inc, int t_ma
 inline int64_t fused_lds_bytes(int p_cap, int q_cap, int meta_cap, int h, int d, int fp, int fs) {
   const int64_t weights = 16 * 64 * 2 * ((int64_t)(fs / 32) * (h / 16) + (int64_t)((fp + h) / 32) * (d / 16));
   const int64_t stage = std::max<int64_t>(4 * ((int64_t)q_cap * fs + (int64_t)p_cap * fp), weights);
+#ifdef UDS_SMALL_IN_LDS
+  const int64_t cold = (fp > 64 ? (d / 16) * 2 * 1024 : 0) + (int64_t)(fs / 32) * (h / 16) * 2 * 1024;
+#else
   const int64_t cold = (fp > 64 ? (d / 16) * 2 * 1024 : 0) + (fs > 64 ? (h / 16) * 2 * 1024 : 0);   // LDS-resident third k-step
+#endif
   return 4 * ((int64_t)meta_cap + 2 * p_cap + 2 * d + h + (int64_t)q_cap * (h + 4) + (int64_t)p_cap * d) + cold + stage;
 }
 
