@@ -12,5 +12,6 @@ from .layers import (Dense, GATConv, GCNConv, MixedGAT, NodeEdge,     # noqa: F4
                      SpatialBlock, SpatialLayer)
 
 from .emulator import Conv1D, Emulator                                # noqa: F401,E402
+from . import inp                                                     # noqa: F401,E402
 
 __version__ = '0.1.0'

@@ -501,6 +501,102 @@ class Emulator(nn.Module):
         out = [node_loss.detach()] + ([fl_loss.detach()] if self.if_flood and fl_loss is not None else []) + [edge_loss.detach()]
         return out
 
+    # ------------------------------------------------------------------ Keras checkpoints (:814-852, SURVEY.md Appendix B)
+    def keras_layer_map(self):
+        """[(keras layer name, module, [(keras weight name, parameter name), ...])] in the creation order of
+        `build_network` (emulator.py:166-341): the auto-numbered names `save_weights('model.h5')` stores the weights
+        under (`dense`, `dense_1`, ..., `node_edge_k`, `mixed_gat_k` / `gcn_conv_k`, `conv1d_k`, `dense_resx`)."""
+        count = {}
+
+        def name(base):
+            k = count.get(base, 0)
+            count[base] = k + 1
+            return base if k == 0 else '%s_%d' % (base, k)
+
+        dense_w = [('kernel', 'kernel'), ('bias', 'bias')]
+        ne_w = [('weight', 'weight'), ('bias', 'bias')]
+        gat_w = [('kernel', 'kernel'), ('attn_kernel_self', 'attn_kernel_self'), ('attn_kernel_neigh', 'attn_kernel_neighs'), ('bias', 'bias')]
+        out = [(name('dense'), self.embed_x, dense_w), (name('dense'), self.embed_b, dense_w), (name('dense'), self.embed_e, dense_w)]
+        if self.act:
+            out.append((name('dense'), self.embed_ae, dense_w))
+
+        def spatial(block):
+            for ly in block.layers:
+                out.append((name('dense'), ly.dense_xe, dense_w))
+                out.append((name('dense'), ly.dense_ex, dense_w))
+                out.append((name('node_edge'), ly.node_edge_n, ne_w))
+                out.append((name('node_edge'), ly.node_edge_e, ne_w))
+                if ly.conv == 'GAT':
+                    out.append((name('mixed_gat'), ly.gat_x, gat_w))
+                    out.append((name('mixed_gat'), ly.gat_e, gat_w))
+                else:
+                    out.append((name('gcn_conv'), ly.gcn_x, dense_w))
+                    out.append((name('gcn_conv'), ly.gcn_e, dense_w))
+
+        def temporal(mods):
+            for m in mods:
+                out.append((name('conv1d'), m, dense_w))
+
+        spatial(self.block1)
+        temporal(self.tem1_x)
+        temporal(self.tem1_e)
+        spatial(self.block2)
+        temporal(self.tem2_x)
+        temporal(self.tem2_e)
+        out.append(('dense_resx', self.res_x, dense_w))
+        out.append((name('dense'), self.res_e, dense_w))
+        out.append((name('dense'), self.out, dense_w))
+        for m in self.flood:
+            out.append((name('dense'), m, dense_w))
+        if self.if_flood:
+            out.append((name('dense'), self.flood_out, dense_w))
+        out.append((name('dense'), self.e_out_layer, dense_w))
+        return out
+
+    def load_keras_weights(self, weights):
+        """Weights of a trained reference model, keyed the way Keras stores them in `model.h5`:
+        `weights['<layer>/<weight>:0']` or `weights['<layer>/<layer>/<weight>:0']` (the HDF5 group path) or
+        `weights['<layer>'] = [arrays in the layer's own order]`, values array-like.  h5py is not part of this image: read
+        the file where TensorFlow / h5py exist (`{n: f[n][()] ...}` -> `np.savez`) and pass the arrays here.  Shapes are
+        checked; NodeEdge parameters created with sparse=True take the dense (R, M) arrays on their support."""
+        weights = dict(weights)
+        missing = []
+        with torch.no_grad():
+            for lname, mod, pairs in self.keras_layer_map():
+                for idx, (kname, pname) in enumerate(pairs):
+                    arr = None
+                    for key in ('%s/%s:0' % (lname, kname), '%s/%s/%s:0' % (lname, lname, kname), '%s/%s' % (lname, kname)):
+                        if key in weights:
+                            arr = weights[key]
+                            break
+                    if arr is None and lname in weights and not hasattr(weights[lname], 'shape'):
+                        arr = weights[lname][idx]
+                    if arr is None:
+                        missing.append('%s/%s' % (lname, kname))
+                        continue
+                    p = getattr(mod, pname)
+                    t = torch.as_tensor(np.asarray(arr), dtype=torch.float32)
+                    if getattr(mod, 'sparse', False) and t.dim() == 2:        # NodeEdge with one parameter per support entry
+                        t = t.reshape(-1)[mod._flat.cpu()]
+                    if pname == 'kernel' and t.dim() == 2 and p.dim() == 3:   # GCNConv (F, C) vs GATConv (F, 1, C)
+                        t = t.reshape(p.shape)
+                    if tuple(t.shape) != tuple(p.shape):
+                        raise ValueError('%s/%s: checkpoint shape %r, model expects %r' % (lname, kname, tuple(t.shape), tuple(p.shape)))
+                    p.copy_(t.to(p.device))
+        if missing:
+            raise KeyError('weights not found in the checkpoint: %s' % ', '.join(missing))
+        return self
+
+    def export_keras_weights(self):
+        """{'<layer>/<weight>:0': ndarray} under the Keras names (inverse of load_keras_weights; dense NodeEdge only)."""
+        out = {}
+        for lname, mod, pairs in self.keras_layer_map():
+            if getattr(mod, 'sparse', False):
+                raise NotImplementedError('NodeEdge(sparse=True) has no dense (R, M) parameters to export')
+            for kname, pname in pairs:
+                out['%s/%s:0' % (lname, kname)] = getattr(mod, pname).detach().cpu().numpy().copy()
+        return out
+
     # ------------------------------------------------------------------ checkpoints (:814-852)
     def save(self, model_dir=None):
         model_dir = model_dir if model_dir is not None else self.model_dir

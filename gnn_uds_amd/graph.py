@@ -369,6 +369,12 @@ class DrainageGraph:
                    dict(directed=directed, order=order, length=length))
 
     @classmethod
+    def from_inp(cls, path):
+        """The network of a SWMM `.inp` file (node / link order of the reference, `base.py:335-365`)."""
+        from .inp import load_network
+        return load_network(path).graph
+
+    @classmethod
     def from_dense(cls, adj, edge_adj, node_edge, edges=None):
         """From the reference's dense `args.adj`, `args.edge_adj`, `args.node_edge`
         (`emulator.py:79,83,88`): filters are (m>0) with the diagonal forced (`:143-145`)."""

@@ -1,0 +1,60 @@
+"""Keras checkpoint name map (Emulator.keras_layer_map / load_keras_weights, SURVEY.md Appendix B + 8f rank 1): host
+logic only, CPU parameters -- creation-order names, shape checks, round trip through the Keras-keyed dict."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gnn_uds_amd as U
+from tests.util import emulator_args
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _emul(**over):
+    with open(os.path.join(ROOT, 'tests', 'golden', 'networks.json')) as fh:
+        net = json.load(fh)['astlingen']
+    args = emulator_args(np.array(net['edges']), net['n_node'], **over)
+    return U.Emulator(args.conv, args.resnet, args.recurrent, args, generator=torch.Generator().manual_seed(3))
+
+
+def test_creation_order_names():
+    names = [n for n, _, _ in _emul(n_sp_layer=2, n_tp_layer=2, if_flood=3).keras_layer_map()]
+    assert names[:4] == ['dense', 'dense_1', 'dense_2', 'dense_3']                       # X, B, E, AE embeddings (emulator.py:198-212)
+    assert names[4:10] == ['dense_4', 'dense_5', 'node_edge', 'node_edge_1', 'mixed_gat', 'mixed_gat_1']
+    assert names[10:16] == ['dense_6', 'dense_7', 'node_edge_2', 'node_edge_3', 'mixed_gat_2', 'mixed_gat_3']
+    assert names[16:20] == ['conv1d', 'conv1d_1', 'conv1d_2', 'conv1d_3']                # n_tp for x, then n_tp for e
+    assert names[20:26] == ['dense_8', 'dense_9', 'node_edge_4', 'node_edge_5', 'mixed_gat_4', 'mixed_gat_5']
+    assert names[32:36] == ['conv1d_4', 'conv1d_5', 'conv1d_6', 'conv1d_7']
+    assert names[36:] == ['dense_resx', 'dense_12', 'dense_13', 'dense_14', 'dense_15', 'dense_16', 'dense_17', 'dense_18']
+    no_act = [n for n, _, _ in _emul(act=False, if_flood=0, n_sp_layer=1, n_tp_layer=1).keras_layer_map()]
+    # embeddings X, B, E (no AE), one spatial layer, 1+1 conv, spatial, 1+1 conv, dense_resx, e-res, out, e_out
+    assert no_act == ['dense', 'dense_1', 'dense_2', 'dense_3', 'dense_4', 'node_edge', 'node_edge_1', 'mixed_gat', 'mixed_gat_1',
+                      'conv1d', 'conv1d_1', 'dense_5', 'dense_6', 'node_edge_2', 'node_edge_3', 'mixed_gat_2', 'mixed_gat_3',
+                      'conv1d_2', 'conv1d_3', 'dense_resx', 'dense_7', 'dense_8', 'dense_9']
+
+
+def test_round_trip_and_shape_check():
+    a, b = _emul(), _emul()
+    for p in b.parameters():
+        p.data.zero_()
+    w = a.export_keras_weights()
+    assert w['mixed_gat/kernel:0'].shape == (96, 1, 64) and w['node_edge/weight:0'].shape == (a.n_node, a.n_edge)
+    assert w['conv1d/kernel:0'].shape == (3, 64, 64) and w['dense_resx/bias:0'].shape == (64,)
+    b.load_keras_weights(w)
+    for (n1, p1), (n2, p2) in zip(a.named_parameters(), b.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2)
+    # HDF5 group-path keys and per-layer lists are accepted too
+    h5 = {k.split('/')[0] + '/' + k: v for k, v in w.items()}
+    c = _emul()
+    c.load_keras_weights(h5)
+    assert torch.equal(c.block2.layers[0].gat_e.attn_kernel_neighs, a.block2.layers[0].gat_e.attn_kernel_neighs)
+    bad = dict(w)
+    bad['dense_1/kernel:0'] = np.zeros((2, 32), dtype=np.float32)
+    with pytest.raises(ValueError):
+        _emul().load_keras_weights(bad)
+    del bad['dense_1/kernel:0']
+    with pytest.raises(KeyError):
+        _emul().load_keras_weights(bad)
