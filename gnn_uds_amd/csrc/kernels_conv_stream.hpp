@@ -1,0 +1,209 @@
+// Causal dilated Conv1D(kernel 3) as a TIME-STREAMING kernel on the matrix cores (gfx950): every input row is read
+// from HBM once, instead of once per tap (keras Conv1D(H, 3, padding='causal', dilation_rate=D) on (B,T,R,F) rows,
+// emulator.py:155-157,244-257,299-310).
+//
+// A wave owns 16 consecutive rows r of one batch element and walks the T time steps in order.  Step t DMAs the block
+// x[t] (4 KB, fragment order) into its LDS ring, splits it once (bf16 hi + lo) and multiplies it by all three taps:
+//   out[t] += x[t] W_2,   out[t+D] += x[t] W_1,   out[t+2D] += x[t] W_0
+// (a causal window seen from the input side: zero padding needs no code, contributions past T are dropped).  The
+// 2D+1 output blocks in progress live in a register ring of accumulators; out[t] is complete after step t: bias,
+// activation, transposed through a small LDS tile, stored as whole 128-B lines.  The time loop is unrolled 2D+1 times
+// so every ring index is a compile-time register.  dir = -1 walks time backwards: with transposed taps that is the
+// input gradient of the causal layer.  Weights (48 KB pre-split) are staged once per workgroup in LDS and read per
+// k-step; the ring keeps PREF time steps of DMA in flight; the slot a step has just consumed doubles as its store tile.
+// The activation is a template parameter: a run-time switch per output element tripled the kernel's time.
+//
+// HBM-bound: 4 (F + H) bytes per row.  Numerics: the split-bf16 3-product scheme of the other MFMA kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels_rowgemm.hpp"
+
+namespace uds {
+
+struct ConvStreamArgs {
+  const float *x, *bias;
+  const uint4 *packed;        // k_pack_weight_frags layout of the (3*64, 64) kernel: k-step kt = 2*tap + half
+  float *out;
+  int B, T, R, act, dir;      // dir = +1 causal (forward), -1 look-ahead (input gradient)
+  int n_blocks;               // ceil(R / 16)
+  int n_seg, seg_len;         // the T steps are cut into n_seg segments of seg_len steps (each re-reads a 2D-step halo)
+};
+
+#ifndef UDS_CS_WAVES
+#define UDS_CS_WAVES 8
+#endif
+#ifndef UDS_CS_PREF
+#define UDS_CS_PREF 2
+#endif
+constexpr int CS_WAVES = UDS_CS_WAVES, CS_PREF = UDS_CS_PREF, CS_RING = CS_PREF + 1;      // one workgroup per CU (two waves per SIMD): 48 KB weights + waves x ring
+
+template <int D, int ACT>
+__global__ __launch_bounds__(CS_WAVES * 64, 2) void k_conv3_stream(ConvStreamArgs a) {
+  constexpr int F = 64, MB = 4, KT = 6, NSET = 2 * D + 1, LD = 36;
+  extern __shared__ __attribute__((aligned(16))) float smem_cs[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, qd = lane >> 4;
+  uint4 *wlds = reinterpret_cast<uint4 *>(smem_cs);                       // KT * MB * 2 fragments x 64 lanes
+  float *bias_s = smem_cs + KT * MB * 2 * 64 * 4;
+  float *ring = bias_s + 64 + wave * (CS_RING * 1024);
+  for (int i = tid; i < KT * MB * 2 * 64; i += CS_WAVES * 64) wlds[i] = a.packed[i];
+  if (tid < 64) bias_s[tid] = a.bias ? a.bias[tid] : 0.f;
+  __syncthreads();
+
+  const int unit = blockIdx.x * CS_WAVES + wave;          // (time segment, batch element, 16-row block)
+  if (unit >= a.n_seg * a.B * a.n_blocks) return;
+  const int seg = unit / (a.B * a.n_blocks), bn = unit - seg * (a.B * a.n_blocks);
+  const int b = bn / a.n_blocks, nb = bn - b * a.n_blocks;
+  const int s0 = seg * a.seg_len, s1 = min(a.T, s0 + a.seg_len);       // logical steps whose outputs this wave writes
+  const int t_first = max(0, s0 - 2 * D);                                // ... after the halo steps that feed them
+  const int n_valid = min(16, a.R - nb * 16);
+  const int64_t row0 = (int64_t)b * a.T * a.R + nb * 16;   // row of time step 0
+  const float *src_lane = a.x + (row0 + min(r16, n_valid - 1)) * F + 4 * qd;
+  const int64_t t_stride = (int64_t)a.R * F;
+  const unsigned my_lds = __builtin_amdgcn_readfirstlane(lds_addr(ring));
+  auto tmem = [&](int t) { return a.dir > 0 ? t : a.T - 1 - t; };         // memory time index of logical step t
+  auto issue = [&](int t, int slot) {                                     // past the end: dummy re-fetch of the last step
+    const float *s = src_lane + (int64_t)tmem(min(t, s1 - 1)) * t_stride;
+    const float *pc[4] = {s, s + 16, s + 32, s + 48};
+    glds16_run<4>(pc, my_lds + (unsigned)slot * 4096);
+  };
+#pragma unroll
+  for (int q = 0; q < CS_PREF; ++q) issue(t_first + q, q);
+
+  f32x4 acc[NSET][MB];
+#pragma unroll
+  for (int s = 0; s < NSET; ++s)
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[s][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int slot = 0;            // ring slot of the step consumed next
+
+  auto mult = [&](int tap, f32x4 (&dst)[MB], const bf16x8 (&dh)[2], const bf16x8 (&dl)[2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kt = 2 * tap + h;
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, wlds[((kt * MB + m) * 2 + 0) * 64 + lane]);
+        const bf16x8 wl = __builtin_bit_cast(bf16x8, wlds[((kt * MB + m) * 2 + 1) * 64 + lane]);
+        dst[m] = mfma3(wh, wl, dh[h], dl[h], dst[m]);
+      }
+    }
+  };
+
+  for (int t0 = t_first; t0 < s1; t0 += NSET) {
+    static_for<NSET>([&](auto u_) {
+      constexpr int U = decltype(u_)::value;
+      constexpr int CUR = U, MID = (U + D) % NSET, FAR = (U + 2 * D) % NSET;
+      const int t = t0 + U;
+      if (t < s1) {
+        int rs = slot + CS_PREF;
+        rs = rs >= CS_RING ? rs - CS_RING : rs;
+        issue(t + CS_PREF, rs);
+        // x[t] landed once everything older than its 4 pieces is done: younger = 4 PREF pieces + 4 stores per finished step
+        const int st = min(max(t - s0, 0), CS_PREF);
+        bool waited = false;
+        static_for<CS_PREF>([&](auto k_) {
+          constexpr int K = decltype(k_)::value;
+          if (st == K) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * CS_PREF + 4 * K) : "memory");
+            waited = true;
+          }
+        });
+        if (!waited) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * CS_PREF) : "memory");
+        const float4 *sl = reinterpret_cast<const float4 *>(ring + slot * 1024) + lane;
+        const float4 v0 = sl[0], v1 = sl[64], v2 = sl[128], v3 = sl[192];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slot consumed before a later trip refills it
+        float *tile = ring + slot * 1024;                      // ... and free until the next step's DMA: it doubles as the store tile
+        slot = slot + 1 == CS_RING ? 0 : slot + 1;
+        bf16x8 dh[2], dl[2];
+        split8(v0, v1, dh[0], dl[0]);
+        split8(v2, v3, dh[1], dl[1]);
+        mult(2, acc[CUR], dh, dl);
+        mult(1, acc[MID], dh, dl);
+        mult(0, acc[FAR], dh, dl);
+        // out[t] is complete: bias, activation, 16 x 64 block through the tile in two 32-column halves -> 4 stores
+        // (halo steps only feed later outputs: their own block is dropped)
+        const int64_t orow = row0 + (int64_t)tmem(t) * a.R;
+        if (t < s0) {
+#pragma unroll
+          for (int m = 0; m < MB; ++m) acc[CUR][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm) {
+            const int m = 2 * g + mm;
+            const f32x4 bb = *reinterpret_cast<const f32x4 *>(bias_s + 16 * m + 4 * qd);
+            f32x4 o = acc[CUR][m];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fused_act<ACT>(o[j] + bb[j], a.act);      // relu compiled in, others decided at run time
+            *reinterpret_cast<f32x4 *>(tile + r16 * LD + 16 * mm + 4 * qd) = o;
+            acc[CUR][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int rr = min(i * 8 + (lane >> 3), n_valid - 1), cc = 4 * (lane & 7);    // rows past the block repeat the last valid row
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(tile + rr * LD + cc);
+            *reinterpret_cast<f32x4 *>(a.out + (orow + rr) * 64 + 32 * g + cc) = v;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the dummy pieces land before the LDS is released
+}
+
+inline int64_t conv_stream_lds_bytes() {
+  return (int64_t)6 * 4 * 2 * 1024 + 256 + CS_WAVES * CS_RING * 4096;
+}
+
+template <int D, int ACT>
+inline hipError_t launch_conv_stream_a(const ConvStreamArgs &a, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3_stream<D, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int units = a.n_seg * a.B * a.n_blocks;
+  hipLaunchKernelGGL((k_conv3_stream<D, ACT>), dim3((unsigned)((units + CS_WAVES - 1) / CS_WAVES)), dim3(CS_WAVES * 64),
+                     (size_t)conv_stream_lds_bytes(), st, a);
+  return hipGetLastError();
+}
+
+template <int D>
+inline hipError_t launch_conv_stream_t(const ConvStreamArgs &a, hipStream_t st) {
+  if (a.act == 1) return launch_conv_stream_a<D, 1>(a, st);     // relu
+  if (a.act == 0) return launch_conv_stream_a<D, 0>(a, st);     // linear (the input-gradient pass)
+  return launch_conv_stream_a<D, -1>(a, st);
+}
+
+// taps = 3, F = 64, f_out = 64, |dil| in {1, 2, 4}: the shapes of every temporal layer of a d = H = 64 emulator
+inline bool conv_stream_supported(int taps, int F, int fo, int dil) {
+  const int d = dil < 0 ? -dil : dil;
+  return taps == 3 && F == 64 && fo == 64 && (d == 1 || d == 2 || d == 4);
+}
+
+inline hipError_t launch_conv_stream(ConvStreamArgs a, int dil, hipStream_t st) {
+  const int d = dil < 0 ? -dil : dil;
+  // enough independent streams for ONE resident round (256 CUs x CS_WAVES waves), but segments long enough that the
+  // 2D-step halo each one re-reads stays small
+  const int streams = a.B * a.n_blocks;
+  int n_seg = (256 * CS_WAVES) / streams;                 // round down: everything resident in ONE round
+  n_seg = std::max(1, std::min(n_seg, a.T / (4 * d)));      // a segment re-reads 2d halo steps: keep that <= 50 %
+  a.seg_len = (a.T + n_seg - 1) / n_seg;
+  a.n_seg = (a.T + a.seg_len - 1) / a.seg_len;
+  switch (d) {
+    case 1: return launch_conv_stream_t<1>(a, st);
+    case 2: return launch_conv_stream_t<2>(a, st);
+    default: return launch_conv_stream_t<4>(a, st);
+  }
+}
+
+}  // namespace uds

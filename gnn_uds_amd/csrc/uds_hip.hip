@@ -12,12 +12,15 @@
 #include <vector>
 
 #include "../../include/uds_hip.h"
+#include <cstdlib>
+
 #include "kernels_dense.hpp"
 #include "kernels_sparse.hpp"
 #include "kernels_backward.hpp"
 #include "kernels_fused.hpp"
 #include "kernels_rowgemm.hpp"
 #include "kernels_wgrad.hpp"
+#include "kernels_conv_stream.hpp"
 #include "tile_plan.hpp"
 
 namespace {
@@ -288,6 +291,14 @@ int uds_rowgemm_forward(const float *x, int64_t B, int64_t T, int64_t R, int64_t
               "uds_rowgemm_forward: K=%lld x f_out=%lld weights do not fit the LDS", (long long)(taps * F), (long long)f_out);
   UDS_REQUIRE(B * T * R < INT32_MAX, "uds_rowgemm_forward: %lld rows exceed the int32 row index", (long long)(B * T * R));
   if (B == 0) return UDS_OK;
+  const int64_t n_blocks = (R + 15) / 16;
+  if (uds::conv_stream_supported((int)taps, (int)F, (int)f_out, (int)dil) && B * n_blocks >= 256 && !std::getenv("UDS_NO_CONV_STREAM")) {
+    // enough (batch element, 16-row block) streams to fill the CUs: read every row once instead of once per tap
+    uds::ConvStreamArgs ca{x, bias, reinterpret_cast<const uint4 *>(packed), out, (int)B, (int)T, (int)R, act, dil > 0 ? 1 : -1, (int)n_blocks, 1, (int)T};
+    hipError_t ec = uds::launch_conv_stream(ca, (int)dil, static_cast<hipStream_t>(stream));
+    if (ec != hipSuccess) return fail(UDS_EHIP, "uds_rowgemm_forward: streaming conv launch -> %s", hipGetErrorString(ec));
+    return UDS_OK;
+  }
   uds::RowGemmArgs a{x, bias, reinterpret_cast<const uint4 *>(packed), out, B * T * R, (int)F, (int)taps, (int)dil, (int)T, (int)R,
                      (int)f_out, act, 0};
   hipError_t e = uds::launch_rowgemm(a, static_cast<hipStream_t>(stream));

@@ -45,7 +45,11 @@ def test_conv1d_causal(dev, B, T, R, F, H, dil, act):
                                                     (1, 1, 1000, 64, 64, 1, 1, 'linear'), (1, 1, 333, 32, 1, 1, 1, 'sigmoid'), (2, 3, 40, 64, 3, 1, 1, 'tanh'),
                                                     (1, 1, 97, 64, 32, 1, 1, 'relu'),
                                                     # slabs wide enough for the XCD-aware row mapping (R >= 4096), ragged XCD ranges
-                                                    (1, 6, 4133, 64, 64, 3, 2, 'relu'), (2, 3, 4096, 32, 32, 3, 1, 'linear')])
+                                                    (1, 6, 4133, 64, 64, 3, 2, 'relu'), (2, 3, 4096, 32, 32, 3, 1, 'linear'),
+                                                    # time-streaming Conv1D (taps 3, 64 -> 64, >= 256 sixteen-row streams): every dilation,
+                                                    # T not a multiple of the 2D+1 ring, several time segments, a ragged last block
+                                                    (1, 13, 4100, 64, 64, 3, 1, 'relu'), (1, 29, 4100, 64, 64, 3, 4, 'tanh'), (2, 60, 2050, 64, 64, 3, 2, 'relu'),
+                                                    (1, 60, 4099, 64, 64, 3, 4, 'linear'), (1, 2, 4096, 64, 64, 3, 4, 'relu')])
 def test_rowgemm_mfma_dense_and_conv(dev, B, T, R, F, H, taps, dil, act):
     """Matrix-core Dense / causal Conv1D (split-bf16, 3 products): tolerance 2e-4 * max(1, max|ref|)."""
     g = torch.Generator().manual_seed(T + R)
