@@ -5,6 +5,8 @@
 // one fmaf per product, i.e. the same arithmetic as a k-ordered fp32 dot product.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <stdint.h>
 
 #include "../../include/uds_hip.h"
@@ -30,6 +32,22 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case UDS_ACT_HARD_SIGMOID: return fminf(fmaxf(0.2f * v + 0.5f, 0.0f), 1.0f);
     default: return v;
   }
+}
+
+// The activation code is wave-uniform.  A `switch` per output ELEMENT compiles to chains of scalar branches around the
+// inlined tanh / exp bodies (it made the streaming Conv1D 1.7x slower), so kernels call their epilogue through
+// with_act(): one branch per epilogue, the common cases (relu, linear) compiled in.
+template <int ACT>
+__device__ __forceinline__ float act_ct(float v, int act_rt) {
+  if constexpr (ACT == UDS_ACT_RELU) return fmaxf(v, 0.0f);
+  else if constexpr (ACT == UDS_ACT_LINEAR) return v;
+  else return apply_act(v, act_rt);
+}
+template <class F>
+__device__ __forceinline__ void with_act(int act, F &&f) {
+  if (act == UDS_ACT_RELU) f(std::integral_constant<int, UDS_ACT_RELU>{});
+  else if (act == UDS_ACT_LINEAR) f(std::integral_constant<int, UDS_ACT_LINEAR>{});
+  else f(std::integral_constant<int, -1>{});
 }
 
 // CG = number of 4-wide column groups (power of two, <= 64).  RT row-threads x TM rows each.
@@ -128,8 +146,10 @@ __global__ __launch_bounds__(256) void k_dense_act(DenseArgs a) {
     }
     if (grow < a.rows) {
       float o[4];
+      with_act(a.act, [&](auto act_) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = apply_act(acc[i][j] + b4[j], a.act);
+        for (int j = 0; j < 4; ++j) o[j] = act_ct<decltype(act_)::value>(acc[i][j] + b4[j], a.act);
+      });
       if ((a.fo & 3) == 0) {
         if (c0 < a.fo) *reinterpret_cast<float4 *>(&a.out[grow * a.fo + c0]) = make_float4(o[0], o[1], o[2], o[3]);
       } else {

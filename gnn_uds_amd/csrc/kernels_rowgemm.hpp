@@ -188,6 +188,8 @@ __global__ __launch_bounds__(512, 2) void k_rowgemm_mfma(RowGemmArgs a) {
       }
     }
 
+    with_act(a.act, [&](auto act_) {
+    constexpr int ACT_ = decltype(act_)::value;
     // ---- epilogue: bias + activation, whole-row stores ----
     if (a.fo == 16 * MB && MB >= 2) {
       // turn each 16 x 32 accumulator pair through the wave's tile so that one store instruction writes 8 rows x 128 B
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void k_rowgemm_mfma(RowGemmArgs a) {
             const f32x4 bb = *reinterpret_cast<const f32x4 *>(bias_s + 16 * m + 4 * qd);
             f32x4 o = acc[b][m];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = apply_act(o[j] + bb[j], a.act);
+            for (int j = 0; j < 4; ++j) o[j] = act_ct<ACT_>(o[j] + bb[j], a.act);
             *reinterpret_cast<f32x4 *>(tile + r16 * LD + 16 * mm + 4 * qd) = o;
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -226,17 +228,18 @@ __global__ __launch_bounds__(512, 2) void k_rowgemm_mfma(RowGemmArgs a) {
           if ((a.fo & 3) == 0) {
             if (c0 < a.fo) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) o[j] = apply_act(o[j] + bias_s[c0 + j], a.act);
+              for (int j = 0; j < 4; ++j) o[j] = act_ct<ACT_>(o[j] + bias_s[c0 + j], a.act);
               *reinterpret_cast<f32x4 *>(a.out + r * a.fo + c0) = o;
             }
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              if (c0 + j < a.fo) a.out[r * a.fo + c0 + j] = apply_act(o[j] + bias_s[c0 + j], a.act);
+              if (c0 + j < a.fo) a.out[r * a.fo + c0 + j] = act_ct<ACT_>(o[j] + bias_s[c0 + j], a.act);
           }
         }
       }
     }
+    });
     base = base_n;
     nv = nv_n;
 #pragma unroll

@@ -42,10 +42,13 @@ __global__ __launch_bounds__(256) void k_csr_spmm(SpmmArgs a) {
     const float4 b = reinterpret_cast<const float4 *>(a.bias)[c];
     acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
   }
-  acc.x = apply_act(acc.x, a.act);
-  acc.y = apply_act(acc.y, a.act);
-  acc.z = apply_act(acc.z, a.act);
-  acc.w = apply_act(acc.w, a.act);
+  with_act(a.act, [&](auto act_) {
+    constexpr int A = decltype(act_)::value;
+    acc.x = act_ct<A>(acc.x, a.act);
+    acc.y = act_ct<A>(acc.y, a.act);
+    acc.z = act_ct<A>(acc.z, a.act);
+    acc.w = act_ct<A>(acc.w, a.act);
+  });
   reinterpret_cast<float4 *>(a.out)[((int64_t)s * a.n_rows + i) * a.f4 + c] = acc;
 }
 
@@ -95,10 +98,13 @@ __global__ __launch_bounds__(256) void k_gat_aggregate(GatArgs a) {
   float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.bias) b = reinterpret_cast<const float4 *>(a.bias)[c];
   float4 o;
-  o.x = apply_act(fmaf(acc.x, inv, b.x), a.act);
-  o.y = apply_act(fmaf(acc.y, inv, b.y), a.act);
-  o.z = apply_act(fmaf(acc.z, inv, b.z), a.act);
-  o.w = apply_act(fmaf(acc.w, inv, b.w), a.act);
+  with_act(a.act, [&](auto act_) {
+    constexpr int A = decltype(act_)::value;
+    o.x = act_ct<A>(fmaf(acc.x, inv, b.x), a.act);
+    o.y = act_ct<A>(fmaf(acc.y, inv, b.y), a.act);
+    o.z = act_ct<A>(fmaf(acc.z, inv, b.z), a.act);
+    o.w = act_ct<A>(fmaf(acc.w, inv, b.w), a.act);
+  });
   reinterpret_cast<float4 *>(a.out)[((int64_t)s * a.n + i) * a.d4 + c] = o;
 }
 
@@ -125,17 +131,20 @@ __global__ __launch_bounds__(256) void k_cumsum_res_act(CumsumArgs a) {
   float4 *o4 = reinterpret_cast<float4 *>(a.out) + b * a.T * per_b + rc;
   float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.res) r = reinterpret_cast<const float4 *>(a.res)[b * per_b + rc];
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s = 0; s < a.T; ++s) {
-    const float4 v = x4[(int64_t)s * per_b];
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    float4 o;
-    o.x = apply_act(acc.x + r.x, a.act);
-    o.y = apply_act(acc.y + r.y, a.act);
-    o.z = apply_act(acc.z + r.z, a.act);
-    o.w = apply_act(acc.w + r.w, a.act);
-    o4[(int64_t)s * per_b] = o;
-  }
+  with_act(a.act, [&](auto act_) {
+    constexpr int A = decltype(act_)::value;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < a.T; ++s) {
+      const float4 v = x4[(int64_t)s * per_b];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      float4 o;
+      o.x = act_ct<A>(acc.x + r.x, a.act);
+      o.y = act_ct<A>(acc.y + r.y, a.act);
+      o.z = act_ct<A>(acc.z + r.z, a.act);
+      o.w = act_ct<A>(acc.w + r.w, a.act);
+      o4[(int64_t)s * per_b] = o;
+    }
+  });
 }
 
 inline hipError_t launch_cumsum(const CumsumArgs &a, hipStream_t st) {
