@@ -68,15 +68,16 @@ struct uds_tile_plan {
 // One tile plan per input width class: the DMA stage holds raw rows, so wider rows need smaller tiles.
 struct uds_plan_slot {
   bool ok = false;                // a tile plan that fits the LDS budget exists
-  int f_max = 0;                  // widest input row (floats) the plan was sized for
+  int fp = 0, fs = 0;             // primary / secondary row widths (floats) of the kernel variant the plan was sized for
   uds::NetworkPlan plan;
   int32_t *d_hdr = nullptr, *d_pool = nullptr;
+  int32_t *d_hdr_side[2] = {nullptr, nullptr};   // headers of one side's tiles only (same pool): single-side launches
   int64_t lds_bytes = 0;
 };
 
 struct uds_network {
   const uds_csr *adj = nullptr, *edge_adj = nullptr, *inc_n = nullptr, *inc_e = nullptr;
-  uds_plan_slot slot[2];          // [0]: rows of 64 floats, [1]: rows of 96 floats
+  uds_plan_slot slot[4];          // one per kernel variant <FP, FS>: [0] <64,64>, [1] <64,96>, [2] <96,64>, [3] <96,96>
 };
 
 namespace {
@@ -84,18 +85,22 @@ namespace {
 constexpr int64_t FUSED_LDS_BUDGET = 160 * 1024;   // one 8-wave workgroup per CU owns the whole 160 KiB LDS
 constexpr int64_t PACKED_WEIGHT_FLOATS = 2 * (768 + 2048) * 4;   // both sides, F_in up to 96: uint4 = 4 floats
 
-// Tile plan for input rows of f_max floats under the LDS budget: fix the footprint limits (primary / secondary rows
-// staged per tile, multiples of 16) first; the planner then fills them (tile_plan.hpp: merge_clusters).
+inline int slot_index(int fp, int fs) { return (fp > 64 ? 2 : 0) + (fs > 64 ? 1 : 0); }
+
+// Tile plan for the kernel variant <fp, fs> (primary / secondary input rows of fp / fs floats: they set the size of the
+// DMA stage) under the LDS budget: fix the footprint limits (primary / secondary rows staged per tile, multiples of 16)
+// first; the planner then fills them (tile_plan.hpp: merge_clusters).
 bool plan_network(const uds::HostCsr &adj, const uds::HostCsr &eadj, const uds::HostCsr &inc_n, const uds::HostCsr &inc_e,
-                  int f_max, uds::NetworkPlan &out, int64_t &lds) {
+                  int fp, int fs, uds::NetworkPlan &out, int64_t &lds) {
   // candidate (p_limit, q_limit) pairs, largest first; meta is bounded by the limits (checked after planning)
-  const int cand[][2] = {{128, 208}, {128, 192}, {128, 176}, {112, 160}, {96, 144}, {80, 128}, {64, 96}, {48, 64}, {32, 48}, {16, 32}};
+  const int cand[][2] = {{128, 208}, {128, 192}, {128, 176}, {128, 160}, {128, 144}, {112, 160}, {112, 144}, {96, 144}, {96, 128},
+                         {80, 128}, {64, 96}, {48, 64}, {32, 48}, {16, 32}};
   for (const auto &c : cand) {
     const int p_lim = c[0], q_lim = c[1];
-    if (uds::fused_lds_bytes(p_lim, q_lim, 0, uds::FUSED_H, uds::FUSED_D, f_max, f_max) > FUSED_LDS_BUDGET) continue;
+    if (uds::fused_lds_bytes(p_lim, q_lim, 0, uds::FUSED_H, uds::FUSED_D, fp, fs) > FUSED_LDS_BUDGET) continue;
     const int t = std::min(p_lim, 4 * uds::FUSED_WAVES * uds::FUSED_U);        // own rows: P3 covers a tile in one trip
     out = uds::build_network_plan(adj, eadj, inc_n, inc_e, t, t, p_lim, q_lim);
-    lds = uds::fused_lds_bytes(out.p_cap, out.q_cap, out.meta_cap, uds::FUSED_H, uds::FUSED_D, f_max, f_max);
+    lds = uds::fused_lds_bytes(out.p_cap, out.q_cap, out.meta_cap, uds::FUSED_H, uds::FUSED_D, fp, fs);
     if (lds <= FUSED_LDS_BUDGET && out.p_cap <= 4 * uds::FUSED_WAVES * uds::FUSED_U) return true;   // P3 covers a tile in one trip
   }
   return false;
@@ -465,12 +470,13 @@ int uds_network_create(const uds_csr_t *adj, const uds_csr_t *edge_adj, const ud
   n->edge_adj = edge_adj;
   n->inc_n = inc_n;
   n->inc_e = inc_e;
-  // tile plans for the fused kernel, one per input-width class
-  const int widths[2] = {64, 96};
-  for (int k = 0; k < 2 && N > 0 && E > 0; ++k) {
-    uds_plan_slot &sl = n->slot[k];
-    sl.f_max = widths[k];
-    if (!plan_network(adj->host, edge_adj->host, inc_n->host, inc_e->host, widths[k], sl.plan, sl.lds_bytes)) continue;
+  // tile plans for the fused kernel, one per kernel variant (the first layer of block 2 has 96-wide node rows)
+  const int variants[4][2] = {{64, 64}, {64, 96}, {96, 64}, {96, 96}};
+  for (int k = 0; k < 4 && N > 0 && E > 0; ++k) {
+    uds_plan_slot &sl = n->slot[slot_index(variants[k][0], variants[k][1])];
+    sl.fp = variants[k][0];
+    sl.fs = variants[k][1];
+    if (!plan_network(adj->host, edge_adj->host, inc_n->host, inc_e->host, sl.fp, sl.fs, sl.plan, sl.lds_bytes)) continue;
     hipError_t e;
     if ((e = hipMalloc(&sl.d_hdr, sizeof(int32_t) * sl.plan.hdr.size())) != hipSuccess ||
         (e = hipMalloc(&sl.d_pool, sizeof(int32_t) * sl.plan.pool.size())) != hipSuccess ||
@@ -478,6 +484,17 @@ int uds_network_create(const uds_csr_t *adj, const uds_csr_t *edge_adj, const ud
         (e = hipMemcpy(sl.d_pool, sl.plan.pool.data(), sizeof(int32_t) * sl.plan.pool.size(), hipMemcpyHostToDevice)) != hipSuccess) {
       uds_network_destroy(n);
       return fail(UDS_ENOMEM, "uds_network_create: tile plan upload -> %s", hipGetErrorString(e));
+    }
+    for (int side = 0; side < 2; ++side) {   // compact per-side header lists, in the merged (locality) order
+      std::vector<int32_t> hs;
+      for (int t = 0; t < sl.plan.n_tiles; ++t)
+        if (sl.plan.hdr[(size_t)t * uds::TILE_HDR_INTS + 6] == side)
+          hs.insert(hs.end(), sl.plan.hdr.begin() + (size_t)t * uds::TILE_HDR_INTS, sl.plan.hdr.begin() + (size_t)(t + 1) * uds::TILE_HDR_INTS);
+      if ((e = hipMalloc(&sl.d_hdr_side[side], sizeof(int32_t) * std::max<size_t>(hs.size(), 1))) != hipSuccess ||
+          (!hs.empty() && (e = hipMemcpy(sl.d_hdr_side[side], hs.data(), sizeof(int32_t) * hs.size(), hipMemcpyHostToDevice)) != hipSuccess)) {
+        uds_network_destroy(n);
+        return fail(UDS_ENOMEM, "uds_network_create: tile plan upload -> %s", hipGetErrorString(e));
+      }
     }
     sl.ok = true;
   }
@@ -490,6 +507,8 @@ int uds_network_destroy(uds_network_t *net) {
   for (uds_plan_slot &sl : net->slot) {
     hipFree(sl.d_hdr);
     hipFree(sl.d_pool);
+    hipFree(sl.d_hdr_side[0]);
+    hipFree(sl.d_hdr_side[1]);
   }
   delete net;
   return UDS_OK;
@@ -498,7 +517,7 @@ int uds_network_destroy(uds_network_t *net) {
 int uds_network_plan_info(const uds_network_t *net, int32_t *info8) {
   UDS_REQUIRE(net && info8, "uds_network_plan_info: NULL argument");
   const uds_plan_slot &sl = net->slot[0];   // the plan for 64-float rows (d = 64 layers)
-  info8[0] = (sl.ok ? 1 : 0) | (net->slot[1].ok ? 2 : 0);
+  info8[0] = (sl.ok ? 1 : 0) | ((net->slot[1].ok && net->slot[2].ok && net->slot[3].ok) ? 2 : 0);
   info8[1] = sl.plan.side[0].n_tiles;
   info8[2] = sl.plan.side[1].n_tiles;
   info8[3] = sl.plan.p_cap;
@@ -606,12 +625,14 @@ int uds_spatial_layer_forward(const uds_network_t *net, const uds_spatial_params
   if (S == 0) return UDS_OK;
 
   const bool shape_ok = h == uds::FUSED_H && d == uds::FUSED_D && (fx == 64 || fx == 96) && (fe == 64 || fe == 96);
-  const uds_plan_slot &sl = net->slot[(fx > 64 || fe > 64) ? 1 : 0];
+  // node tiles run the variant <fx, fe>, link tiles <fe, fx>: one launch when they coincide, else one per side
+  const uds_plan_slot &sl = net->slot[slot_index((int)fx, (int)fe)];
+  const uds_plan_slot &sl_link = net->slot[slot_index((int)fe, (int)fx)];
   if (flags & UDS_FLAG_REQUIRE_FUSED)
-    UDS_REQUIRE(sl.ok && shape_ok && !(flags & UDS_FLAG_EXACT_FP32),
+    UDS_REQUIRE(sl.ok && sl_link.ok && shape_ok && !(flags & UDS_FLAG_EXACT_FP32),
                 "uds_spatial_layer_forward: fused kernel unavailable (plan %d, fx=%lld fe=%lld h=%lld d=%lld)", (int)sl.ok,
                 (long long)fx, (long long)fe, (long long)h, (long long)d);
-  if (sl.ok && shape_ok && !(flags & UDS_FLAG_EXACT_FP32)) {
+  if (sl.ok && sl_link.ok && shape_ok && !(flags & UDS_FLAG_EXACT_FP32)) {
     UDS_REQUIRE(aligned16(p->xe_b) && aligned16(p->ex_b) && aligned16(p->gx_as) && aligned16(p->gx_an) && aligned16(p->gx_b) &&
                     aligned16(p->ge_as) && aligned16(p->ge_an) && aligned16(p->ge_b),
                 "uds_spatial_layer_forward: bias / attention vectors must be 16-byte aligned");
@@ -628,13 +649,18 @@ int uds_spatial_layer_forward(const uds_network_t *net, const uds_spatial_params
     uds::FusedArgs a;
     a.side[0] = uds::FusedSide{x, e, out_x, w_small_n, w_big_n, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
     a.side[1] = uds::FusedSide{e, x, out_e, w_small_e, w_big_e, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};
-    a.hdr = sl.d_hdr;
-    a.pool = sl.d_pool;
-    a.n_tiles = sl.plan.n_tiles;
+    int64_t lds_need = 0;
+    auto use_plan = [&](const uds_plan_slot &u, int side) {     // side < 0: both sides (merged tile list), else that side's tiles only
+      a.hdr = side < 0 ? u.d_hdr : u.d_hdr_side[side];
+      a.pool = u.d_pool;
+      a.n_tiles = side < 0 ? u.plan.n_tiles : u.plan.side[side].n_tiles;
+      a.p_cap = u.plan.p_cap;
+      a.q_cap = u.plan.q_cap;
+      a.meta_cap = u.plan.meta_cap;
+      lds_need = u.lds_bytes;
+    };
+    use_plan(sl, -1);
     a.S = (int)S;
-    a.p_cap = sl.plan.p_cap;
-    a.q_cap = sl.plan.q_cap;
-    a.meta_cap = sl.plan.meta_cap;
     a.act = act;
     a.dbg = nullptr;
 #ifdef UDS_PHASE_TIMING
@@ -658,19 +684,19 @@ int uds_spatial_layer_forward(const uds_network_t *net, const uds_spatial_params
       a.chunk = (int)chunk;
       return (int)(((S + chunk - 1) / chunk) * a.n_tiles);
     };
-    const int64_t lds_need = uds::fused_lds_bytes(a.p_cap, a.q_cap, a.meta_cap, uds::FUSED_H, uds::FUSED_D, (int)std::max(fx, fe),
-                                                  (int)std::max(fx, fe));
     if (fx == fe) {
       a.side_mask = 3;
       const int grid = set_chunk(a.n_tiles);
       he = (fx == 64) ? launch_fused<64, 64>(a, grid, lds_need, st) : launch_fused<96, 96>(a, grid, lds_need, st);
     } else {   // node tiles: FP = fx, FS = fe; link tiles: FP = fe, FS = fx -> one launch per side
       a.side_mask = 1;
-      int grid = set_chunk(sl.plan.side[0].n_tiles);
+      use_plan(sl, 0);      // workgroups go round-robin to the XCDs: a grid of working tiles only keeps the XCDs level
+      int grid = set_chunk(a.n_tiles);
       he = (fx == 64) ? launch_fused<64, 96>(a, grid, lds_need, st) : launch_fused<96, 64>(a, grid, lds_need, st);
       if (he == hipSuccess) {
         a.side_mask = 2;
-        grid = set_chunk(sl.plan.side[1].n_tiles);
+        use_plan(sl_link, 1);
+        grid = set_chunk(a.n_tiles);
         he = (fe == 64) ? launch_fused<64, 96>(a, grid, lds_need, st) : launch_fused<96, 64>(a, grid, lds_need, st);
       }
     }

@@ -10,8 +10,9 @@ from gnn_uds_amd import _lib
 dev = torch.device('cuda', 0)
 g = U.DrainageGraph.from_edges(U.synthetic_drainage_network(10000, 12000, 0))
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-layer = U.SpatialLayer(g, 64, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1)).to(dev)
-x, e = torch.rand(S, 10000, 64, device=dev), torch.rand(S, 12000, 64, device=dev)
+FX, FE = int(os.environ.get('FX', 64)), int(os.environ.get('FE', 64))
+layer = U.SpatialLayer(g, 64, 'relu', fx=FX, fe=FE, sparse_params=True, generator=torch.Generator().manual_seed(1)).to(dev)
+x, e = torch.rand(S, 10000, FX, device=dev), torch.rand(S, 12000, FE, device=dev)
 lib = _lib.load()
 net = layer.network()
 info = net.plan_info()
@@ -24,7 +25,7 @@ ws = torch.zeros(lib.uds_spatial_workspace_floats(net.ptr, S, 32, 64), device=de
 ox, oe = torch.empty(S, 10000, 64, device=dev), torch.empty(S, 12000, 64, device=dev)
 for _ in range(3):
     ws.zero_()
-    rc = lib.uds_spatial_layer_forward(net.ptr, ctypes.byref(sp), x.data_ptr(), 64, e.data_ptr(), 64, S, 32, 64, 1, 0, ws.data_ptr(), ox.data_ptr(), oe.data_ptr(), None)
+    rc = lib.uds_spatial_layer_forward(net.ptr, ctypes.byref(sp), x.data_ptr(), FX, e.data_ptr(), FE, S, 32, 64, 1, 0, ws.data_ptr(), ox.data_ptr(), oe.data_ptr(), None)
     assert rc == 0
 torch.cuda.synchronize()
 n_tiles = info['node_tiles'] + info['link_tiles']
