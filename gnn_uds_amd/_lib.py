@@ -62,6 +62,8 @@ SYMBOLS = {
     'uds_spatial_pack_weights': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr]),
     'uds_spatial_layer_forward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
                                            _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
+    'uds_spatial_layer_forward_split': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64,
+                                                 _c_i64, _c_i64, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
 }
 
 
@@ -486,9 +488,11 @@ def spatial_pack_weights(p, fx, fe, h, d):
     return out
 
 
-def spatial_layer_forward(net, p, x, e, h, d, act='relu', flags=0):
+def spatial_layer_forward(net, p, x, e, h, d, act='relu', flags=0, xb=None, eb=None):
     """One spatial-block loop body (`emulator.py:225-230`).  p: dict of the 14 tensors of
-    uds_spatial_params_t.  x:(S,N,fx), e:(S,E,fe) -> (S,N,d), (S,E,d).  flags: FLAG_* of the C ABI."""
+    uds_spatial_params_t.  x:(S,N,fx), e:(S,E,fe) -> (S,N,d), (S,E,d).  flags: FLAG_* of the C ABI.
+    xb (S,N,32) / eb (S,E,32): extra columns appended to a 64-wide x / e without materialising the concatenation
+    (uds_spatial_layer_forward_split; fused kernel only)."""
     lib = load()
     S, N, fx = x.shape
     _, E, fe = e.shape
@@ -503,6 +507,16 @@ def spatial_layer_forward(net, p, x, e, h, d, act='relu', flags=0):
     ws = torch.empty(lib.uds_spatial_workspace_floats(net.ptr, S, h, d), device=x.device, dtype=torch.float32)
     out_x = torch.empty((S, N, d), device=x.device, dtype=torch.float32)
     out_e = torch.empty((S, E, d), device=x.device, dtype=torch.float32)
+    if xb is not None or eb is not None:
+        for t, ref, name in ((xb, x, 'xb'), (eb, e, 'eb')):
+            if t is not None and tuple(t.shape[:2]) != tuple(ref.shape[:2]):
+                raise UdsError('%s %r does not match %r' % (name, tuple(t.shape), tuple(ref.shape)))
+        _check(lib.uds_spatial_layer_forward_split(net.ptr, ctypes.byref(sp), _dev(x, 'x'), fx, _dev(xb, 'xb', True),
+                                                   0 if xb is None else xb.shape[-1], _dev(e, 'e'), fe, _dev(eb, 'eb', True),
+                                                   0 if eb is None else eb.shape[-1], S, h, d, ACT[act], int(flags),
+                                                   _dev(ws, 'workspace'), _dev(out_x, 'out_x'), _dev(out_e, 'out_e'), _stream()),
+               'uds_spatial_layer_forward_split')
+        return out_x, out_e
     _check(lib.uds_spatial_layer_forward(net.ptr, ctypes.byref(sp), _dev(x, 'x'), fx, _dev(e, 'e'), fe, S, h, d, ACT[act],
                                          int(flags), _dev(ws, 'workspace'), _dev(out_x, 'out_x'), _dev(out_e, 'out_e'), _stream()),
            'uds_spatial_layer_forward')

@@ -45,6 +45,10 @@ constexpr int SEC_STRIDE = FUSED_H + 4; // floats; 144-B rows make the 16-B frag
 
 struct FusedSide {
   const float *prim_in, *sec_in;
+  // 96-wide rows may come in two pieces, [64 floats | 32 floats] from two tensors (the reference concatenates the
+  // boundary embedding to x before block 2, emulator.py:260): *_in then holds the first 64 columns (row stride 64) and
+  // *_in2 the last 32 (row stride 32); nullptr = one tensor with row stride 96.
+  const float *prim_in2, *sec_in2;
   float *out;
   const uint4 *w_small, *w_big;   // packed bf16 hi/lo fragments (k_pack_weight_frags)
   const float *b_small, *a_self, *a_nbr, *b_out, *ne_val;
@@ -283,26 +287,41 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
   // LDS-DMA of one 16-row block in fragment order: piece (t, i) of lane (r16, qd) = floats 32t + 16i + 4qd .. +3
   // of row r16 of the block.  The destination is wave-uniform (base + lane * 16 B is implicit).  Row offsets do not
   // change from snapshot to snapshot, so a wave keeps those of its first two P1 blocks and first P2 block in registers.
-  auto sec_off = [&](int blk) { return sec_ids[min(blk * 16 + r16, n_sec - 1)] * FS + 4 * qd; };       // < 2^31 floats
-  auto prim_off = [&](int blk) { return prim_ids[min(blk * 16 + r16, n_prim - 1)] * FP + 4 * qd; };
-  const int soff0 = wave * 16 < n_sec ? sec_off(wave) : 0, soff1 = (wave + NW) * 16 < n_sec ? sec_off(wave + NW) : 0;
-  const int poff0 = wave * 16 < n_prim ? prim_off(wave) : 0;
+  auto sec_row = [&](int blk) { return sec_ids[min(blk * 16 + r16, n_sec - 1)]; };      // row * width < 2^31 floats
+  auto prim_row = [&](int blk) { return prim_ids[min(blk * 16 + r16, n_prim - 1)]; };
+  const int srow0 = wave * 16 < n_sec ? sec_row(wave) : 0, srow1 = (wave + NW) * 16 < n_sec ? sec_row(wave + NW) : 0;
+  const int prow0 = wave * 16 < n_prim ? prim_row(wave) : 0;
+  const bool sec_split = FS == 96 && S_.sec_in2 != nullptr, prim_split = FP == 96 && S_.prim_in2 != nullptr;
   auto dma_sec = [&](int blk, int s) {
-    const int off = blk == wave ? soff0 : (blk == wave + NW ? soff1 : sec_off(blk));
-    const float *src = S_.sec_in + (int64_t)s * S_.n_sec_glob * FS + off;
+    const int row = blk == wave ? srow0 : (blk == wave + NW ? srow1 : sec_row(blk));
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(stage_s) + (unsigned)blk * (KT_S * 2 * 1024));
     const float *pc[2 * KT_S];
+    if (sec_split) {
+      const float *sa = S_.sec_in + ((int64_t)s * S_.n_sec_glob + row) * 64 + 4 * qd;
+      const float *sb = S_.sec_in2 + ((int64_t)s * S_.n_sec_glob + row) * 32 + 4 * qd;
 #pragma unroll
-    for (int i = 0; i < 2 * KT_S; ++i) pc[i] = src + 16 * i;      // piece (t, i) = floats 32t + 16i = 16 * (2t + i)
+      for (int i = 0; i < 2 * KT_S; ++i) pc[i] = i < 4 ? sa + 16 * i : sb + 16 * (i - 4);
+    } else {
+      const float *src = S_.sec_in + ((int64_t)s * S_.n_sec_glob + row) * FS + 4 * qd;
+#pragma unroll
+      for (int i = 0; i < 2 * KT_S; ++i) pc[i] = src + 16 * i;      // piece (t, i) = floats 32t + 16i = 16 * (2t + i)
+    }
     glds16_run<2 * KT_S>(pc, dst);
   };
   auto dma_prim = [&](int blk, int s) {
-    const int off = blk == wave ? poff0 : prim_off(blk);
-    const float *src = S_.prim_in + (int64_t)s * S_.n_prim_glob * FP + off;
+    const int row = blk == wave ? prow0 : prim_row(blk);
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(stage_p) + (unsigned)blk * (KT_X * 2 * 1024));
     const float *pc[2 * KT_X];
+    if (prim_split) {
+      const float *sa = S_.prim_in + ((int64_t)s * S_.n_prim_glob + row) * 64 + 4 * qd;
+      const float *sb = S_.prim_in2 + ((int64_t)s * S_.n_prim_glob + row) * 32 + 4 * qd;
 #pragma unroll
-    for (int i = 0; i < 2 * KT_X; ++i) pc[i] = src + 16 * i;
+      for (int i = 0; i < 2 * KT_X; ++i) pc[i] = i < 4 ? sa + 16 * i : sb + 16 * (i - 4);
+    } else {
+      const float *src = S_.prim_in + ((int64_t)s * S_.n_prim_glob + row) * FP + 4 * qd;
+#pragma unroll
+      for (int i = 0; i < 2 * KT_X; ++i) pc[i] = src + 16 * i;
+    }
     glds16_run<2 * KT_X>(pc, dst);
   };
 

@@ -610,7 +610,21 @@ int uds_spatial_pack_weights(const uds_spatial_params_t *p, int64_t fx, int64_t 
 int uds_spatial_layer_forward(const uds_network_t *net, const uds_spatial_params_t *p, const float *x, int64_t fx,
                               const float *e, int64_t fe, int64_t S, int64_t h, int64_t d, int act, int flags, float *ws,
                               float *out_x, float *out_e, uds_stream_t stream) {
+  return uds_spatial_layer_forward_split(net, p, x, fx, nullptr, 0, e, fe, nullptr, 0, S, h, d, act, flags, ws, out_x, out_e, stream);
+}
+
+int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_params_t *p, const float *x, int64_t fxa,
+                                    const float *xb, int64_t fxb, const float *e, int64_t fea, const float *eb, int64_t feb,
+                                    int64_t S, int64_t h, int64_t d, int act, int flags, float *ws, float *out_x, float *out_e,
+                                    uds_stream_t stream) {
   UDS_REQUIRE(net && p && x && e && ws && out_x && out_e, "uds_spatial_layer_forward: NULL argument");
+  UDS_REQUIRE((xb != nullptr) == (fxb > 0) && (eb != nullptr) == (feb > 0), "uds_spatial_layer_forward_split: xb/fxb or eb/feb disagree");
+  UDS_REQUIRE((!xb || (fxa == 64 && fxb == 32)) && (!eb || (fea == 64 && feb == 32)),
+              "uds_spatial_layer_forward_split: a split input must be 64 + 32 columns (got %lld+%lld, %lld+%lld)", (long long)fxa,
+              (long long)fxb, (long long)fea, (long long)feb);
+  UDS_REQUIRE(aligned16(xb) && aligned16(eb), "uds_spatial_layer_forward_split: xb/eb must be 16-byte aligned");
+  const int64_t fx = fxa + fxb, fe = fea + feb;
+  if (xb || eb) flags |= UDS_FLAG_REQUIRE_FUSED;     // only the fused kernel reads split rows
   UDS_REQUIRE(p->xe_k && p->ex_k && p->ne_n_val && p->ne_e_val && p->gx_k && p->gx_as && p->gx_an && p->ge_k &&
                   p->ge_as && p->ge_an,
               "uds_spatial_layer_forward: NULL parameter tensor");
@@ -647,8 +661,8 @@ int uds_spatial_layer_forward(const uds_network_t *net, const uds_spatial_params
     }
     const uint4 *w_small_n = wq, *w_big_n = wq + 768, *w_small_e = wq + 768 + 2048, *w_big_e = wq + 2 * 768 + 2048;
     uds::FusedArgs a;
-    a.side[0] = uds::FusedSide{x, e, out_x, w_small_n, w_big_n, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
-    a.side[1] = uds::FusedSide{e, x, out_e, w_small_e, w_big_e, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};
+    a.side[0] = uds::FusedSide{x, e, xb, eb, out_x, w_small_n, w_big_n, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
+    a.side[1] = uds::FusedSide{e, x, eb, xb, out_e, w_small_e, w_big_e, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};
     int64_t lds_need = 0;
     auto use_plan = [&](const uds_plan_slot &u, int side) {     // side < 0: both sides (merged tile list), else that side's tiles only
       a.hdr = side < 0 ? u.d_hdr : u.d_hdr_side[side];

@@ -210,9 +210,10 @@ class Emulator(nn.Module):
         b = self.embed_b(c(B))
         ae = self.embed_ae(c(AE)) if self.act else None
 
-        def spatial(block, x, e):
+        def spatial(block, x, e, xb=None, eb=None):
             T = x.shape[1]
-            xs, es = block(x.reshape(nb * T, self.n_node, -1), e.reshape(nb * T, self.n_edge, -1))
+            r = lambda t, n: None if t is None else t.reshape(nb * T, n, -1)
+            xs, es = block(r(x, self.n_node), r(e, self.n_edge), r(xb, self.n_node), r(eb, self.n_edge))
             return xs.reshape(nb, T, self.n_node, -1), es.reshape(nb, T, self.n_edge, -1)
 
         x, e = spatial(self.block1, x, e)
@@ -221,10 +222,8 @@ class Emulator(nn.Module):
         for ly in self.tem1_e:
             e = ly(e)
         x, e = x[:, -self.seq_out:], e[:, -self.seq_out:]             # :249,256
-        x = torch.cat([x, b], dim=-1)                                 # :260
-        if self.act:
-            e = torch.cat([e, ae], dim=-1)                            # :262
-        x, e = spatial(self.block2, c(x), c(e))
+        # concat([x, b]) / concat([e, ae]) (:260-262) are not materialised: the first layer of block 2 reads both pieces
+        x, e = spatial(self.block2, c(x), c(e), b, ae if self.act else None)
         for ly in self.tem2_x:
             x = ly(x)
         for ly in self.tem2_e:

@@ -383,9 +383,24 @@ class SpatialLayer(nn.Module):
                 p['ne_%s_w' % tag], p['ne_%s_b' % tag] = c(ne.weight), c(ne.bias)
         return p
 
-    def forward(self, x, e):
+    def forward(self, x, e, xb=None, eb=None):
+        """xb / eb: 32 extra columns appended to a 64-wide x / e (`concat([x, b])`, emulator.py:260-262) -- read in place
+        by the fused kernel; every other path concatenates."""
+        fused_split = (xb is not None or eb is not None) and self.conv == 'GAT' and self.precision == 'bf16x3' and \
+            self.h == 32 and self.d == 64 and x.shape[-1] + (0 if xb is None else xb.shape[-1]) in (64, 96) and \
+            e.shape[-1] + (0 if eb is None else eb.shape[-1]) in (64, 96) and (xb is None or (x.shape[-1], xb.shape[-1]) == (64, 32)) and \
+            (eb is None or (e.shape[-1], eb.shape[-1]) == (64, 32)) and not _ag.grad_on(x, e, xb, eb, *self.parameters()) and \
+            self.node_edge_n.support_values()[1] is None and self.node_edge_e.support_values()[1] is None
+        if not fused_split:
+            if xb is not None:
+                x = torch.cat([x, xb], dim=-1)
+            if eb is not None:
+                e = torch.cat([e, eb], dim=-1)
+            xb = eb = None
         xs, lead_x = _flatten_snapshots(x)
         es, lead_e = _flatten_snapshots(e)
+        xbs = None if xb is None else _flatten_snapshots(xb)[0]
+        ebs = None if eb is None else _flatten_snapshots(eb)[0]
         if self.conv == 'GCN':     # a_hat @ ([x | agg] W) + b: unfused composition of the Dense / NodeEdge / spmm kernels
             if _ag.grad_on(xs, es, *self.parameters()):
                 raise NotImplementedError('training through the GCN spatial layer is not built (GAT is)')
@@ -409,11 +424,12 @@ class SpatialLayer(nn.Module):
                      gx_b=self.gat_x.bias,
                      ge_k=self.gat_e.kernel, ge_as=self.gat_e.attn_kernel_self, ge_an=self.gat_e.attn_kernel_neighs,
                      ge_b=self.gat_e.bias)
-            fx, fe = xs.shape[-1], es.shape[-1]
+            fx = xs.shape[-1] + (0 if xbs is None else xbs.shape[-1])
+            fe = es.shape[-1] + (0 if ebs is None else ebs.shape[-1])
             if self.precision == 'bf16x3' and self.h == 32 and self.d == 64 and fx in (64, 96) and fe in (64, 96):
                 p['packed'] = self._packed_weights(p, fx, fe)       # split once per parameter update, not per call
             ox, oe = _lib.spatial_layer_forward(self.network(), p, xs, es, self.h, self.d, self.activation,
-                                                _lib.PRECISION_FLAGS[self.precision])
+                                                _lib.PRECISION_FLAGS[self.precision], xb=xbs, eb=ebs)
         else:   # trained dense NodeEdge bias: unfused composition with the dense remainder GEMM
             net = self.network()
             x_e, e_x = self.dense_xe(es), self.dense_ex(xs)
@@ -435,9 +451,10 @@ class SpatialBlock(nn.Module):
         self.layers = nn.ModuleList(layers)
         self.graph = graph
 
-    def forward(self, x, e):
+    def forward(self, x, e, xb=None, eb=None):
+        """xb / eb: extra input columns of the FIRST layer (`concat([x, b])` before block 2, emulator.py:260-262)."""
         net = self.layers[0].network() if self.layers[0].conv == 'GAT' else None
-        for layer in self.layers:
+        for i, layer in enumerate(self.layers):
             layer._net = net
-            x, e = layer(x, e)
+            x, e = layer(x, e, xb, eb) if i == 0 else layer(x, e)
         return x, e

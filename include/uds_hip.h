@@ -221,6 +221,15 @@ int uds_spatial_layer_forward(const uds_network_t *net, const uds_spatial_params
                               int64_t h, int64_t d, int act, int flags, float *workspace,
                               float *out_x, float *out_e, uds_stream_t stream);
 
+/* The same layer with 96-wide inputs given as TWO tensors each: x = [xa (S,N,64) | xb (S,N,32)], e likewise (xb / eb
+ * NULL with fxb / feb 0 = a single tensor).  The reference concatenates the boundary / action embeddings to the
+ * temporal outputs before block 2 (emulator.py:260-262); here the concatenation is never materialised: the kernel
+ * fetches a row's two pieces from the two tensors.  Fused kernel only (h = 32, d = 64). */
+int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_params_t *params, const float *xa,
+                                    int64_t fxa, const float *xb, int64_t fxb, const float *ea, int64_t fea,
+                                    const float *eb, int64_t feb, int64_t S, int64_t h, int64_t d, int act, int flags,
+                                    float *workspace, float *out_x, float *out_e, uds_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

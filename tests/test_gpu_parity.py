@@ -202,6 +202,27 @@ def test_spatial_layer_c2_size_vs_sparse_oracle(dev, precision, fx, fe):
     layer = load_spatial_layer(U.SpatialLayer(gph, d, 'relu', fx=fx, fe=fe, sparse_params=True, precision=precision), p, dev)
     ox, oe = layer(x.float().to(dev), e.float().to(dev))
     close(ox, rx, PREC_TOL[precision]); close(oe, re, PREC_TOL[precision])
+    # 96-wide inputs given as [64 | 32] from two tensors (uds_spatial_layer_forward_split; `concat([x, b])` of
+    # emulator.py:260-262 never materialised): bit-identical to the concatenated call
+    xd, ed = x.float().to(dev), e.float().to(dev)
+    xa, xb = (xd[..., :64].contiguous(), xd[..., 64:].contiguous()) if fx == 96 else (xd, None)
+    ea, eb = (ed[..., :64].contiguous(), ed[..., 64:].contiguous()) if fe == 96 else (ed, None)
+    if xb is not None or eb is not None:
+        sx, se = layer(xa, ea, xb, eb)
+        assert torch.equal(sx, ox) and torch.equal(se, oe)
+
+
+def test_split_input_needs_the_fused_kernel(dev):
+    gph = U.DrainageGraph.from_edges(U.synthetic_drainage_network(300, 360, 0))
+    layer = U.SpatialLayer(gph, 64, 'relu', fx=96, sparse_params=True, generator=torch.Generator().manual_seed(1)).to(dev)
+    x, xb, e = torch.rand(2, 300, 64, device=dev), torch.rand(2, 300, 32, device=dev), torch.rand(2, 360, 64, device=dev)
+    vn, _ = layer.node_edge_n.support_values(); ve, _ = layer.node_edge_e.support_values()
+    p = {k: (v.to(dev) if v is not None else None) for k, v in layer.export_params().items() if not k.startswith('ne_')}
+    p.update(ne_n_val=vn, ne_e_val=ve)
+    with pytest.raises(_lib.UdsError):      # exact-fp32 (unfused) path + split rows: refused, not silently concatenated
+        _lib.spatial_layer_forward(layer.network(), p, x, e, 32, 64, 'relu', _lib.PRECISION_FLAGS['fp32'], xb=xb)
+    with pytest.raises(_lib.UdsError):      # a split must be 64 + 32 columns
+        _lib.spatial_layer_forward(layer.network(), p, x, e, 32, 64, 'relu', 0, xb=torch.rand(2, 300, 16, device=dev))
 
 
 def test_fused_kernel_is_required_and_used(dev):
