@@ -299,7 +299,7 @@ def main():
         bytes_gs = algorithmic_bytes_per_graph_step(g, d, d)
         achieved = (L * S * bytes_gs) / (dev_ms * 1e-3) / 1e9
         out = {
-            'metric': 'graph-steps/sec (forward rollout), |V|=10k |E|=12k d=64', 'value': gsteps / wall,
+            'metric': 'graph-steps/sec (forward rollout), |V|=%gk |E|=%gk d=%d' % (args.nodes / 1000, args.links / 1000, d), 'value': gsteps / wall,
             'unit': 'graph-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.precision == 'fp32' else 'f32 storage/accumulate, GEMM operands as bf16 hi+lo split (3 MFMA products)',

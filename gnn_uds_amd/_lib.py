@@ -40,11 +40,14 @@ SYMBOLS = {
     'uds_rowgemm_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
     'uds_rowgemm_pack': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
     'uds_rowgemm_forward': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
+    'uds_rowgemm_forward_cat': (_c_int, [_c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int,
+                                         _c_ptr, _c_i64, _c_i64, _c_ptr]),
     'uds_cumsum_act': (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_flow_balance': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'uds_gat_workspace_floats': (_c_i64, [_c_i64, _c_i64, _c_i64]),
     'uds_gat_forward': (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                  _c_int, _c_ptr, _c_ptr, _c_ptr]),
+    'uds_gat_aggregate': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_gat_backward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr,
                                   _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'uds_csr_sddmm': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
@@ -333,6 +336,28 @@ def rowgemm_forward(x, packed, bias, f_out, act='linear', taps=1, dilation=1):
     return out
 
 
+def rowgemm_cat(x, x2, packed, bias, f_out, act='linear', out=None, col0=0):
+    """Matrix-core Dense on rows [x | x2] (x2 None: x alone) written to columns [col0, col0 + f_out) of `out`
+    (..., ldo) -- allocated (..., f_out) when None.  No concatenation copies (uds_rowgemm_forward_cat)."""
+    lib = load()
+    F1 = x.shape[-1]
+    F2 = 0 if x2 is None else x2.shape[-1]
+    rows = x.numel() // F1
+    if x2 is not None and x2.numel() // F2 != rows:
+        raise UdsError('rowgemm_cat: x %r and x2 %r have different row counts' % (tuple(x.shape), tuple(x2.shape)))
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-1]) + (f_out,), device=x.device, dtype=torch.float32)
+    ldo = out.shape[-1]
+    if out.numel() // ldo != rows:
+        raise UdsError('rowgemm_cat: out %r does not have %d rows' % (tuple(out.shape), rows))
+    if rows == 0:
+        _dev(x, 'x')
+        return out
+    _check(lib.uds_rowgemm_forward_cat(_dev(x, 'x'), F1, _dev(x2, 'x2', True), F2, 1, 1, rows, packed.data_ptr(), _dev(bias, 'bias', True),
+                                       1, 1, f_out, ACT[act], _dev(out, 'out'), ldo, col0, _stream()), 'uds_rowgemm_forward_cat')
+    return out
+
+
 def cumsum_act(x, res=None, act='linear'):
     """act(cumsum over axis 1 of x (B,T,R,F) + res (B,1,R,F))."""
     lib = load()
@@ -404,6 +429,22 @@ def gat_forward(handle, xa, kernel, a_self, a_nbr, bias=None, act='relu', xb=Non
     if return_workspace:
         m = S * n
         return out, (ws[:m * d].view(S, n, d), ws[m * d:m * d + m].view(S, n), ws[m * d + m:m * d + 2 * m].view(S, n))
+    return out
+
+
+def gat_aggregate(handle, hx, s_self, s_nbr, bias=None, act='relu'):
+    """Attention softmax + neighbour sum of a GATConv from precomputed hx (S,n,d), s_self / s_nbr (S,n)."""
+    lib = load()
+    S, n, d = hx.shape
+    if n != handle.n_rows or tuple(s_self.shape) != (S, n) or tuple(s_nbr.shape) != (S, n):
+        raise UdsError('gat_aggregate: hx %r, s_self %r, s_nbr %r do not match a %d-row pattern' %
+                       (tuple(hx.shape), tuple(s_self.shape), tuple(s_nbr.shape), handle.n_rows))
+    out = torch.empty_like(hx)
+    if out.numel() == 0:
+        _dev(hx, 'hx')
+        return out
+    _check(lib.uds_gat_aggregate(handle.ptr, _dev(hx, 'hx'), _dev(s_self, 's_self'), _dev(s_nbr, 's_nbr'), _dev(bias, 'bias', True), S, d,
+                                 ACT[act], _dev(out, 'out'), _stream()), 'uds_gat_aggregate')
     return out
 
 

@@ -24,6 +24,10 @@ struct RowGemmArgs {
   int64_t rows;
   int F, taps, dil, T, t_rows, fo, act;   // A row = taps x F floats, K = taps * F (multiple of 32)
   int seg;                  // seg > 0: XCD-aware mapping (see k_rowgemm_mfma), else consecutive wave-tiles
+  // Dense only (taps = 1): the row may be the concatenation [x (F1 floats) | x2 (F - F1 floats)] of two tensors, and the
+  // output may be a column block of a wider matrix (row stride ldo floats, first column col0)
+  const float *x2 = nullptr;
+  int F1 = 0, ldo = 0, col0 = 0;
 };
 
 // Pack with zero padding of the output features up to mb*16 (heads have 1..3 outputs).
@@ -137,6 +141,7 @@ __global__ __launch_bounds__(512, 2) void k_rowgemm_mfma(RowGemmArgs a) {
     const int shift = (a.taps - 1 - j) * a.dil;
     const bool live = tx - shift >= 0 && tx - shift < a.T;
     const float *src = a.x + (int64_t)(rw - (live ? shift * a.t_rows : 0)) * a.F + f0 + 4 * qd;
+    if (a.x2) src = k0 < a.F1 ? a.x + (int64_t)rw * a.F1 + k0 + 4 * qd : a.x2 + (int64_t)rw * (a.F - a.F1) + (k0 - a.F1) + 4 * qd;
     glds16_pair(src, src + 16, my_lds + (unsigned)slot * 2048);
   };
 
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void k_rowgemm_mfma(RowGemmArgs a) {
           for (int i = 0; i < 2; ++i) {
             const int rr = i * 8 + (lane >> 3), cc = 4 * (lane & 7);
             const f32x4 v = *reinterpret_cast<const f32x4 *>(tile + rr * LD + cc);
-            if (b * 16 + rr < nv) *reinterpret_cast<f32x4 *>(a.out + (int64_t)(base + b * 16 + rr) * a.fo + 32 * g + cc) = v;
+            if (b * 16 + rr < nv) *reinterpret_cast<f32x4 *>(a.out + (int64_t)(base + b * 16 + rr) * a.ldo + a.col0 + 32 * g + cc) = v;
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -229,12 +234,12 @@ __global__ __launch_bounds__(512, 2) void k_rowgemm_mfma(RowGemmArgs a) {
             if (c0 < a.fo) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) o[j] = act_ct<ACT_>(o[j] + bias_s[c0 + j], a.act);
-              *reinterpret_cast<f32x4 *>(a.out + r * a.fo + c0) = o;
+              *reinterpret_cast<f32x4 *>(a.out + r * a.ldo + a.col0 + c0) = o;
             }
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              if (c0 + j < a.fo) a.out[r * a.fo + c0 + j] = act_ct<ACT_>(o[j] + bias_s[c0 + j], a.act);
+              if (c0 + j < a.fo) a.out[r * a.ldo + a.col0 + c0 + j] = act_ct<ACT_>(o[j] + bias_s[c0 + j], a.act);
           }
         }
       }

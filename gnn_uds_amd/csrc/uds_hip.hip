@@ -286,6 +286,19 @@ int uds_rowgemm_pack(const float *W, int64_t k_total, int64_t f_out, void *packe
 
 int uds_rowgemm_forward(const float *x, int64_t B, int64_t T, int64_t R, int64_t F, const void *packed, const float *bias,
                         int64_t taps, int64_t dil, int64_t f_out, int act, float *out, uds_stream_t stream) {
+  return uds_rowgemm_forward_cat(x, F, nullptr, 0, B, T, R, packed, bias, taps, dil, f_out, act, out, f_out, 0, stream);
+}
+
+int uds_rowgemm_forward_cat(const float *x, int64_t F1, const float *x2, int64_t F2, int64_t B, int64_t T, int64_t R, const void *packed,
+                            const float *bias, int64_t taps, int64_t dil, int64_t f_out, int act, float *out, int64_t ldo, int64_t col0,
+                            uds_stream_t stream) {
+  const int64_t F = F1 + F2;
+  UDS_REQUIRE((x2 != nullptr) == (F2 > 0), "uds_rowgemm_forward_cat: x2 / F2 disagree");
+  UDS_REQUIRE(!x2 || (taps == 1 && F1 % 32 == 0 && F2 % 32 == 0 && aligned16(x2)),
+              "uds_rowgemm_forward_cat: a two-tensor row needs taps = 1 and both widths multiples of 32");
+  UDS_REQUIRE(ldo >= col0 + f_out && col0 >= 0 && (ldo == f_out || (ldo % 4 == 0 && col0 % 4 == 0)),
+              "uds_rowgemm_forward_cat: output block [%lld, %lld) does not fit rows of %lld floats (4-float aligned)", (long long)col0,
+              (long long)(col0 + f_out), (long long)ldo);
   UDS_REQUIRE(x && packed && out, "uds_rowgemm_forward: NULL x/packed/out");
   UDS_REQUIRE(B >= 0 && T > 0 && R > 0 && F > 0 && F % 32 == 0 && taps > 0 && taps <= 16 && dil != 0 && f_out > 0 && f_out <= 64,
               "uds_rowgemm_forward: needs F %% 32 == 0, f_out <= 64 (B=%lld T=%lld R=%lld F=%lld taps=%lld f_out=%lld)", (long long)B,
@@ -297,7 +310,8 @@ int uds_rowgemm_forward(const float *x, int64_t B, int64_t T, int64_t R, int64_t
   UDS_REQUIRE(B * T * R < INT32_MAX, "uds_rowgemm_forward: %lld rows exceed the int32 row index", (long long)(B * T * R));
   if (B == 0) return UDS_OK;
   const int64_t n_blocks = (R + 15) / 16;
-  if (uds::conv_stream_supported((int)taps, (int)F, (int)f_out, (int)dil) && B * n_blocks >= 256 && !std::getenv("UDS_NO_CONV_STREAM")) {
+  if (uds::conv_stream_supported((int)taps, (int)F, (int)f_out, (int)dil) && B * n_blocks >= 256 && ldo == f_out &&
+      !std::getenv("UDS_NO_CONV_STREAM")) {
     // enough (batch element, 16-row block) streams to fill the CUs: read every row once instead of once per tap
     uds::ConvStreamArgs ca{x, bias, reinterpret_cast<const uint4 *>(packed), out, (int)B, (int)T, (int)R, act, dil > 0 ? 1 : -1, (int)n_blocks, 1, (int)T};
     hipError_t ec = uds::launch_conv_stream(ca, (int)dil, static_cast<hipStream_t>(stream));
@@ -305,7 +319,7 @@ int uds_rowgemm_forward(const float *x, int64_t B, int64_t T, int64_t R, int64_t
     return UDS_OK;
   }
   uds::RowGemmArgs a{x, bias, reinterpret_cast<const uint4 *>(packed), out, B * T * R, (int)F, (int)taps, (int)dil, (int)T, (int)R,
-                     (int)f_out, act, 0};
+                     (int)f_out, act, 0, x2, (int)F1, (int)ldo, (int)col0};
   hipError_t e = uds::launch_rowgemm(a, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(UDS_EHIP, "uds_rowgemm_forward: launch -> %s", hipGetErrorString(e));
   return UDS_OK;
@@ -373,6 +387,21 @@ int uds_gat_forward(const uds_csr_t *g, const float *xa, int64_t fa, const float
   uds::GatArgs a{g->d_rowptr, g->d_col, g->d_order, hx, s_self, s_nbr, bias, out, (int)n, (int)(d / 4), act, (int)S};
   hipError_t e = uds::launch_gat_aggregate(a, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(UDS_EHIP, "uds_gat_forward: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
+int uds_gat_aggregate(const uds_csr_t *g, const float *hx, const float *s_self, const float *s_nbr, const float *bias, int64_t S,
+                      int64_t d, int act, float *out, uds_stream_t stream) {
+  UDS_REQUIRE(g && hx && s_self && s_nbr && out, "uds_gat_aggregate: NULL argument");
+  UDS_REQUIRE(g->n_rows == g->n_cols, "uds_gat_aggregate: pattern must be square");
+  UDS_REQUIRE(d > 0 && d % 4 == 0 && d <= 256, "uds_gat_aggregate: d=%lld must be a multiple of 4, at most 256", (long long)d);
+  UDS_REQUIRE(S >= 0 && S <= 65535, "uds_gat_aggregate: S=%lld outside [0,65535]", (long long)S);
+  UDS_REQUIRE(act >= UDS_ACT_LINEAR && act <= UDS_ACT_HARD_SIGMOID, "uds_gat_aggregate: unknown activation %d", act);
+  UDS_REQUIRE(aligned16(hx) && aligned16(out) && aligned16(bias), "uds_gat_aggregate: hx/out/bias must be 16-byte aligned");
+  if (S == 0 || g->n_rows == 0) return UDS_OK;
+  uds::GatArgs a{g->d_rowptr, g->d_col, g->d_order, hx, s_self, s_nbr, bias, out, (int)g->n_rows, (int)(d / 4), act, (int)S};
+  hipError_t e = uds::launch_gat_aggregate(a, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_gat_aggregate: launch -> %s", hipGetErrorString(e));
   return UDS_OK;
 }
 

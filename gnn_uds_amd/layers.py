@@ -165,6 +165,28 @@ class GATConv(nn.Module):
             out = _ag.GatFn.apply(xs, xbs, self.kernel, self.attn_kernel_self, self.attn_kernel_neighs, self.bias,
                                   self.activation, h, self.precision)
             return out.reshape(lead + out.shape[-2:])
+        fin = xs.shape[-1] + (0 if xbs is None else xbs.shape[-1])
+        if self.precision == 'bf16x3' and fin % 32 == 0 and self.channels % 16 == 0 and xs.shape[0] * xs.shape[1] >= 4096:
+            # wide layers (d = 128, the reference's default): the linear part on the matrix cores (split-bf16 row GEMM, 64
+            # columns per launch), the attention projections as two matrix-vector products, then the CSR aggregation kernel
+            w2 = self.kernel.reshape(fin, self.channels)
+            key = (self.kernel._version, self.attn_kernel_self._version, self.attn_kernel_neighs._version, self.kernel.data_ptr())
+            if getattr(self, '_wide', None) is None or self._wide[0] != key:
+                # per parameter version: the kernel's 64-column blocks and the two attention projections W a_self, W a_nbr
+                # (s = hx a = z (W a): one more narrow row GEMM instead of a 600k-row matrix-vector product)
+                cols = [_lib.rowgemm_pack(w2[:, c0:c0 + 64].contiguous()) for c0 in range(0, self.channels, 64)]
+                wa = torch.stack([w2 @ self.attn_kernel_self.reshape(-1), w2 @ self.attn_kernel_neighs.reshape(-1)], dim=1)
+                self._wide = (key, cols, _lib.rowgemm_pack(wa.contiguous()))
+            _, cols, wa_packed = self._wide
+            if not all(_lib.rowgemm_supported(fin, 32, min(64, self.channels - 64 * i)) for i in range(len(cols))):
+                raise _lib.UdsError('GATConv: %d -> %d does not fit the matrix-core row GEMM' % (fin, self.channels))
+            hx = torch.empty(xs.shape[:-1] + (self.channels,), device=xs.device, dtype=torch.float32)
+            for i, pk in enumerate(cols):
+                _lib.rowgemm_cat(xs, xbs, pk, None, min(64, self.channels - 64 * i), 'linear', out=hx, col0=64 * i)
+            s2 = _lib.rowgemm_cat(xs, xbs, wa_packed, None, 2, 'linear')
+            s_self, s_nbr = s2[..., 0].contiguous(), s2[..., 1].contiguous()
+            out = _lib.gat_aggregate(h, hx, s_self, s_nbr, self.bias, self.activation)
+            return out.reshape(lead + out.shape[-2:])
         out = _lib.gat_forward(h, xs, self.kernel, self.attn_kernel_self, self.attn_kernel_neighs, self.bias,
                                self.activation, xbs)
         return out.reshape(lead + out.shape[-2:])
@@ -428,6 +450,15 @@ class SpatialLayer(nn.Module):
             fe = es.shape[-1] + (0 if ebs is None else ebs.shape[-1])
             if self.precision == 'bf16x3' and self.h == 32 and self.d == 64 and fx in (64, 96) and fe in (64, 96):
                 p['packed'] = self._packed_weights(p, fx, fe)       # split once per parameter update, not per call
+            if 'packed' not in p and self.precision == 'bf16x3' and fx % 32 == 0 and fe % 32 == 0 and self.h % 16 == 0 and self.d % 16 == 0 \
+                    and xs.shape[0] * xs.shape[1] >= 4096:
+                # no fused kernel for this shape (d = 128: the reference's default embed_size): unfused composition with
+                # the dense parts on the matrix cores instead of the exact-fp32 FMA kernels
+                net = self.network()
+                x_e, e_x = self.dense_xe(es), self.dense_ex(xs)
+                ox = self.gat_x([xs, net.adj], xb=self.node_edge_n(x_e))
+                oe = self.gat_e([es, net.edge_adj], xb=self.node_edge_e(e_x))
+                return ox.reshape(lead_x + ox.shape[-2:]), oe.reshape(lead_e + oe.shape[-2:])
             ox, oe = _lib.spatial_layer_forward(self.network(), p, xs, es, self.h, self.d, self.activation,
                                                 _lib.PRECISION_FLAGS[self.precision], xb=xbs, eb=ebs)
         else:   # trained dense NodeEdge bias: unfused composition with the dense remainder GEMM

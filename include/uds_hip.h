@@ -103,6 +103,14 @@ int uds_rowgemm_forward(const float *x, int64_t B, int64_t T, int64_t R, int64_t
                         const float *bias, int64_t taps, int64_t dil, int64_t f_out, int act, float *out,
                         uds_stream_t stream);
 
+/* uds_rowgemm_forward whose input row is the concatenation [x (F1) | x2 (F2)] of two tensors (x2 NULL, F2 = 0: one
+ * tensor; two tensors need taps = 1) and whose f_out outputs go to columns [col0, col0 + f_out) of rows of `ldo`
+ * floats: a 128-wide layer is two calls on the two column halves of its kernel, no concatenation copies
+ * (`concat([x, NodeEdge(x_e)])` -> GATConv kernel, emulator.py:227-230 at embed_size = 128). */
+int uds_rowgemm_forward_cat(const float *x, int64_t F1, const float *x2, int64_t F2, int64_t B, int64_t T, int64_t R,
+                            const void *packed, const float *bias, int64_t taps, int64_t dil, int64_t f_out, int act,
+                            float *out, int64_t ldo, int64_t col0, uds_stream_t stream);
+
 /* out[b,t,r,:] = act(cumsum_t(x)[b,t,r,:] + res[b,0,r,:]); x, out (B,T,R,F), res (B,1,R,F) or NULL; F % 4 == 0.
  * The resnet head of the emulator.                                          emulator.py:313-320 */
 int uds_cumsum_act(const float *x, const float *res, int64_t B, int64_t T, int64_t R, int64_t F, int act,
@@ -127,6 +135,13 @@ int uds_gat_forward(const uds_csr_t *graph, const float *xa, int64_t fa, const f
                     int64_t fb, int64_t S, const float *W, const float *a_self,
                     const float *a_nbr, const float *bias, int64_t d, int act, float *workspace,
                     float *out, uds_stream_t stream);
+
+/* The attention / aggregation half of uds_gat_forward on its own: hx (S,n,d) = the transformed features, s_self / s_nbr
+ * (S,n) = their projections on the two attention kernels, however the caller computed them (e.g. with the matrix-core
+ * row GEMM for wide layers: d = 128 is the reference's default embed_size).
+ *   out_i = act( sum_j softmax_j(leaky_relu_0.2(s_self_i + s_nbr_j)) hx_j + bias ),  j in row i of `graph`. */
+int uds_gat_aggregate(const uds_csr_t *graph, const float *hx, const float *s_self, const float *s_nbr,
+                      const float *bias, int64_t S, int64_t d, int act, float *out, uds_stream_t stream);
 
 /* ---- reverse mode of the sparse operators (the GradientTape of fit_eval, emulator.py:457-484) ---------- */
 

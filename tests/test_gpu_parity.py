@@ -212,6 +212,25 @@ def test_spatial_layer_c2_size_vs_sparse_oracle(dev, precision, fx, fe):
         assert torch.equal(sx, ox) and torch.equal(se, oe)
 
 
+def test_wide_layer_d128_matrix_core_unfused_path(dev):
+    """d = 128 (the reference's default embed_size, utils/config.yaml): no fused kernel; with precision='bf16x3' the dense
+    parts run on the matrix-core row GEMM + uds_gat_aggregate.  Tolerance 2e-4 * max(1, max|ref|) as for the fused layer."""
+    gph = U.DrainageGraph.from_edges(U.synthetic_drainage_network(2000, 2500, 0))
+    d, S = 128, 3
+    p = spatial_params(2000, 2500, d, d, d, seed=5, dense_ne=False, nnz_n=gph.inc_n.nnz, nnz_e=gph.inc_e.nnz)
+    g = torch.Generator().manual_seed(6)
+    x, e = rnd(g, S, 2000, d), rnd(g, S, 2500, d)
+    rx, re = OS.spatial_layer_csr(x, e, p, (gph.adj.rowptr, gph.adj.col), (gph.edge_adj.rowptr, gph.edge_adj.col),
+                                  (gph.inc_n.rowptr, gph.inc_n.col), (gph.inc_e.rowptr, gph.inc_e.col))
+    for precision in ('bf16x3', 'fp32'):
+        layer = load_spatial_layer(U.SpatialLayer(gph, d, 'relu', sparse_params=True, precision=precision), p, dev)
+        ox, oe = layer(x.float().to(dev), e.float().to(dev))
+        close(ox, rx, PREC_TOL[precision]); close(oe, re, PREC_TOL[precision])
+    hx, ss, sn = rnd(g, S, 2000, d).float().to(dev), rnd(g, S, 2000).float().to(dev), rnd(g, S, 2000).float().to(dev)
+    with pytest.raises(_lib.UdsError):
+        _lib.gat_aggregate(_lib.CsrHandle(gph.adj), hx, ss[:, :5].contiguous(), sn)
+
+
 def test_split_input_needs_the_fused_kernel(dev):
     gph = U.DrainageGraph.from_edges(U.synthetic_drainage_network(300, 360, 0))
     layer = U.SpatialLayer(gph, 64, 'relu', fx=96, sparse_params=True, generator=torch.Generator().manual_seed(1)).to(dev)
