@@ -55,6 +55,7 @@ SYMBOLS = {
     'uds_wgrad': (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'uds_network_create': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, ctypes.POINTER(_c_ptr)]),
     'uds_network_destroy': (_c_int, [_c_ptr]),
+    'uds_network_prepare': (_c_int, [_c_ptr, _c_i64, _c_i64]),
     'uds_network_plan_info': (_c_int, [_c_ptr, _c_ptr]),
     'uds_tile_plan_create': (_c_int, [_c_ptr] * 8 + [_c_i64, _c_i64] + [ctypes.c_int32] * 4 + [ctypes.POINTER(_c_ptr)]),
     'uds_tile_plan_destroy': (_c_int, [_c_ptr]),
@@ -209,10 +210,18 @@ class NetworkHandle:
         _check(lib.uds_network_create(self.adj.ptr, self.edge_adj.ptr, self.inc_n.ptr, self.inc_e.ptr, ctypes.byref(h)),
                'uds_network_create')
         self._h = h
+        self._prepared = {(64, 64)}
 
     @property
     def ptr(self):
         return self._h
+
+    def prepare(self, fx, fe):
+        """Build the tile plans a layer with input widths (fx, fe) needs (no-op for 64/64 and once built)."""
+        key = (int(fx), int(fe))
+        if key not in self._prepared:
+            _check(load().uds_network_prepare(self._h, key[0], key[1]), 'uds_network_prepare')
+            self._prepared.add(key)
 
     def plan_info(self):
         """Tile plan of the fused kernel: dict(fused, node_tiles, link_tiles, p_cap, q_cap, meta_cap, lds_bytes, ...)."""

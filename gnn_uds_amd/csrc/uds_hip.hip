@@ -67,6 +67,7 @@ struct uds_tile_plan {
 
 // One tile plan per input width class: the DMA stage holds raw rows, so wider rows need smaller tiles.
 struct uds_plan_slot {
+  bool built = false;             // planning was attempted
   bool ok = false;                // a tile plan that fits the LDS budget exists
   int fp = 0, fs = 0;             // primary / secondary row widths (floats) of the kernel variant the plan was sized for
   uds::NetworkPlan plan;
@@ -482,6 +483,42 @@ int uds_wgrad(const float *a, const float *g, int64_t B, int64_t T, int64_t R, i
   return UDS_OK;
 }
 
+// Build (once) and upload the tile plan of kernel variant <fp, fs>.  A plan that does not fit the LDS leaves the slot
+// !ok (the layer then runs unfused); only an allocation / copy failure is an error.
+static int build_slot(uds_network *n, int fp, int fs) {
+  uds_plan_slot &sl = n->slot[slot_index(fp, fs)];
+  if (sl.built) return UDS_OK;
+  sl.built = true;
+  sl.fp = fp;
+  sl.fs = fs;
+  if (!plan_network(n->adj->host, n->edge_adj->host, n->inc_n->host, n->inc_e->host, fp, fs, sl.plan, sl.lds_bytes)) return UDS_OK;
+  hipError_t e;
+  if ((e = hipMalloc(&sl.d_hdr, sizeof(int32_t) * sl.plan.hdr.size())) != hipSuccess ||
+      (e = hipMalloc(&sl.d_pool, sizeof(int32_t) * sl.plan.pool.size())) != hipSuccess ||
+      (e = hipMemcpy(sl.d_hdr, sl.plan.hdr.data(), sizeof(int32_t) * sl.plan.hdr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(sl.d_pool, sl.plan.pool.data(), sizeof(int32_t) * sl.plan.pool.size(), hipMemcpyHostToDevice)) != hipSuccess)
+    return fail(UDS_ENOMEM, "tile plan upload -> %s", hipGetErrorString(e));
+  for (int side = 0; side < 2; ++side) {   // compact per-side header lists, in the merged (locality) order
+    std::vector<int32_t> hs;
+    for (int t = 0; t < sl.plan.n_tiles; ++t)
+      if (sl.plan.hdr[(size_t)t * uds::TILE_HDR_INTS + 6] == side)
+        hs.insert(hs.end(), sl.plan.hdr.begin() + (size_t)t * uds::TILE_HDR_INTS, sl.plan.hdr.begin() + (size_t)(t + 1) * uds::TILE_HDR_INTS);
+    if ((e = hipMalloc(&sl.d_hdr_side[side], sizeof(int32_t) * std::max<size_t>(hs.size(), 1))) != hipSuccess ||
+        (!hs.empty() && (e = hipMemcpy(sl.d_hdr_side[side], hs.data(), sizeof(int32_t) * hs.size(), hipMemcpyHostToDevice)) != hipSuccess))
+      return fail(UDS_ENOMEM, "tile plan upload -> %s", hipGetErrorString(e));
+  }
+  sl.ok = true;
+  return UDS_OK;
+}
+
+int uds_network_prepare(uds_network_t *net, int64_t fx, int64_t fe) {
+  UDS_REQUIRE(net != nullptr, "uds_network_prepare: NULL network");
+  if (!((fx == 64 || fx == 96) && (fe == 64 || fe == 96)) || net->adj->n_rows == 0 || net->edge_adj->n_rows == 0) return UDS_OK;
+  int rc = build_slot(net, (int)fx, (int)fe);            // node tiles run <fx, fe>
+  if (rc == UDS_OK) rc = build_slot(net, (int)fe, (int)fx);   // link tiles <fe, fx>
+  return rc;
+}
+
 int uds_network_create(const uds_csr_t *adj, const uds_csr_t *edge_adj, const uds_csr_t *inc_n, const uds_csr_t *inc_e,
                        uds_network_t **out) {
   UDS_REQUIRE(out != nullptr, "uds_network_create: out is NULL");
@@ -499,33 +536,13 @@ int uds_network_create(const uds_csr_t *adj, const uds_csr_t *edge_adj, const ud
   n->edge_adj = edge_adj;
   n->inc_n = inc_n;
   n->inc_e = inc_e;
-  // tile plans for the fused kernel, one per kernel variant (the first layer of block 2 has 96-wide node rows)
-  const int variants[4][2] = {{64, 64}, {64, 96}, {96, 64}, {96, 96}};
-  for (int k = 0; k < 4 && N > 0 && E > 0; ++k) {
-    uds_plan_slot &sl = n->slot[slot_index(variants[k][0], variants[k][1])];
-    sl.fp = variants[k][0];
-    sl.fs = variants[k][1];
-    if (!plan_network(adj->host, edge_adj->host, inc_n->host, inc_e->host, sl.fp, sl.fs, sl.plan, sl.lds_bytes)) continue;
-    hipError_t e;
-    if ((e = hipMalloc(&sl.d_hdr, sizeof(int32_t) * sl.plan.hdr.size())) != hipSuccess ||
-        (e = hipMalloc(&sl.d_pool, sizeof(int32_t) * sl.plan.pool.size())) != hipSuccess ||
-        (e = hipMemcpy(sl.d_hdr, sl.plan.hdr.data(), sizeof(int32_t) * sl.plan.hdr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(sl.d_pool, sl.plan.pool.data(), sizeof(int32_t) * sl.plan.pool.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+  // the tile plan of the 64-wide kernel variant is built now; 96-wide variants on request (uds_network_prepare)
+  if (N > 0 && E > 0) {
+    int rc = build_slot(n, 64, 64);
+    if (rc != UDS_OK) {
       uds_network_destroy(n);
-      return fail(UDS_ENOMEM, "uds_network_create: tile plan upload -> %s", hipGetErrorString(e));
+      return rc;
     }
-    for (int side = 0; side < 2; ++side) {   // compact per-side header lists, in the merged (locality) order
-      std::vector<int32_t> hs;
-      for (int t = 0; t < sl.plan.n_tiles; ++t)
-        if (sl.plan.hdr[(size_t)t * uds::TILE_HDR_INTS + 6] == side)
-          hs.insert(hs.end(), sl.plan.hdr.begin() + (size_t)t * uds::TILE_HDR_INTS, sl.plan.hdr.begin() + (size_t)(t + 1) * uds::TILE_HDR_INTS);
-      if ((e = hipMalloc(&sl.d_hdr_side[side], sizeof(int32_t) * std::max<size_t>(hs.size(), 1))) != hipSuccess ||
-          (!hs.empty() && (e = hipMemcpy(sl.d_hdr_side[side], hs.data(), sizeof(int32_t) * hs.size(), hipMemcpyHostToDevice)) != hipSuccess)) {
-        uds_network_destroy(n);
-        return fail(UDS_ENOMEM, "uds_network_create: tile plan upload -> %s", hipGetErrorString(e));
-      }
-    }
-    sl.ok = true;
   }
   *out = n;
   return UDS_OK;
@@ -546,7 +563,7 @@ int uds_network_destroy(uds_network_t *net) {
 int uds_network_plan_info(const uds_network_t *net, int32_t *info8) {
   UDS_REQUIRE(net && info8, "uds_network_plan_info: NULL argument");
   const uds_plan_slot &sl = net->slot[0];   // the plan for 64-float rows (d = 64 layers)
-  info8[0] = (sl.ok ? 1 : 0) | ((net->slot[1].ok && net->slot[2].ok && net->slot[3].ok) ? 2 : 0);
+  info8[0] = (sl.ok ? 1 : 0) | ((net->slot[1].ok && net->slot[2].ok) ? 2 : 0) | (net->slot[3].ok ? 4 : 0);
   info8[1] = sl.plan.side[0].n_tiles;
   info8[2] = sl.plan.side[1].n_tiles;
   info8[3] = sl.plan.p_cap;

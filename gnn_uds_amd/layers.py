@@ -450,6 +450,7 @@ class SpatialLayer(nn.Module):
             fe = es.shape[-1] + (0 if ebs is None else ebs.shape[-1])
             if self.precision == 'bf16x3' and self.h == 32 and self.d == 64 and fx in (64, 96) and fe in (64, 96):
                 p['packed'] = self._packed_weights(p, fx, fe)       # split once per parameter update, not per call
+                self.network().prepare(fx, fe)                      # tile plans of the 96-wide variants are built on first use
             if 'packed' not in p and self.precision == 'bf16x3' and fx % 32 == 0 and fe % 32 == 0 and self.h % 16 == 0 and self.d % 16 == 0 \
                     and xs.shape[0] * xs.shape[1] >= 4096:
                 # no fused kernel for this shape (d = 128: the reference's default embed_size): unfused composition with

@@ -181,6 +181,11 @@ typedef struct uds_network uds_network_t;
 int uds_network_create(const uds_csr_t *adj, const uds_csr_t *edge_adj, const uds_csr_t *inc_n,
                        const uds_csr_t *inc_e, uds_network_t **out);
 int uds_network_destroy(uds_network_t *net);
+/* uds_network_create plans the fused kernel for 64-wide node and link rows.  Layers with 96-wide inputs (the first
+ * layer of block 2: H + d/2 features, emulator.py:260-262) need their own tile plans: build them here, once, before
+ * the first forward with those widths (allocates; afterwards forwards stay allocation-free).  Without it such a layer
+ * runs the unfused kernels.  fx / fe = input widths of the node / link side. */
+int uds_network_prepare(uds_network_t *net, int64_t fx, int64_t fe);
 /* info8 = {fused plan available, node tiles, link tiles, max primary rows per tile, max secondary rows per
  * tile, max metadata ints per tile, LDS bytes per workgroup, t_node*1000 + t_link}. */
 int uds_network_plan_info(const uds_network_t *net, int32_t *info8);

@@ -15,6 +15,7 @@ layer = U.SpatialLayer(g, 64, 'relu', fx=FX, fe=FE, sparse_params=True, generato
 x, e = torch.rand(S, 10000, FX, device=dev), torch.rand(S, 12000, FE, device=dev)
 lib = _lib.load()
 net = layer.network()
+net.prepare(FX, FE)
 info = net.plan_info()
 vn, _ = layer.node_edge_n.support_values(); ve, _ = layer.node_edge_e.support_values()
 p = {k: (v.to(dev) if v is not None else None) for k, v in layer.export_params().items() if not k.startswith('ne_')}
