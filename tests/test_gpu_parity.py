@@ -43,7 +43,9 @@ def rnd(gen, *shape):
 @pytest.mark.parametrize('rows,fa,fb,fo,act', [
     (1, 8, 0, 4, 'relu'), (63, 64, 0, 32, 'relu'), (257, 64, 32, 64, 'linear'), (1000, 128, 64, 128, 'tanh'),
     (130, 5, 0, 3, 'hard_sigmoid'), (77, 32, 0, 1, 'sigmoid'), (64, 96, 0, 64, 'relu'), (300, 192, 0, 256, 'relu'),
-    (40, 64, 0, 7, 'linear')])
+    (40, 64, 0, 7, 'linear'),
+    # narrow inputs, many rows: the streaming embedding kernel (emulator.py:198-212)
+    (5000, 5, 0, 64, 'relu'), (4100, 1, 0, 32, 'relu'), (6000, 4, 0, 64, 'linear'), (4097, 8, 0, 96, 'tanh'), (4096, 2, 0, 4, 'sigmoid')])
 def test_dense_act(dev, rows, fa, fb, fo, act):
     g = torch.Generator().manual_seed(rows + fo)
     xa, k, b = rnd(g, rows, fa) - 0.5, rnd(g, fa + fb, fo) - 0.5, rnd(g, fo) - 0.5
