@@ -42,6 +42,7 @@ SYMBOLS = {
     'uds_rowgemm_forward': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_rowgemm_forward_cat': (_c_int, [_c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int,
                                          _c_ptr, _c_i64, _c_i64, _c_ptr]),
+    'uds_dense_cumsum': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr]),
     'uds_cumsum_act': (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_flow_balance': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'uds_gat_workspace_floats': (_c_i64, [_c_i64, _c_i64, _c_i64]),
@@ -364,6 +365,24 @@ def rowgemm_cat(x, x2, packed, bias, f_out, act='linear', out=None, col0=0):
         return out
     _check(lib.uds_rowgemm_forward_cat(_dev(x, 'x'), F1, _dev(x2, 'x2', True), F2, 1, 1, rows, packed.data_ptr(), _dev(bias, 'bias', True),
                                        1, 1, f_out, ACT[act], _dev(out, 'out'), ldo, col0, _stream()), 'uds_rowgemm_forward_cat')
+    return out
+
+
+def dense_cumsum(x, packed, bias=None, res=None, act='linear'):
+    """act(cumsum over axis 1 of (x @ kernel + bias) + res): x (B,T,R,64), kernel (64,64) packed by rowgemm_pack,
+    res (B,1,R,64) -- Dense + prefix sum + residual + activation in one kernel (uds_dense_cumsum)."""
+    lib = load()
+    B, T, R, F = x.shape
+    if F != 64:
+        raise UdsError('dense_cumsum: 64 -> 64 only, got %d inputs' % F)
+    if res is not None and tuple(res.shape) != (B, 1, R, 64):
+        raise UdsError('dense_cumsum: res must be %r, got %r' % ((B, 1, R, 64), tuple(res.shape)))
+    out = torch.empty((B, T, R, 64), device=x.device, dtype=torch.float32)
+    if out.numel() == 0:
+        _dev(x, 'x')
+        return out
+    _check(lib.uds_dense_cumsum(_dev(x, 'x'), B, T, R, packed.data_ptr(), _dev(bias, 'bias', True), _dev(res, 'res', True), ACT[act],
+                                _dev(out, 'out'), _stream()), 'uds_dense_cumsum')
     return out
 
 

@@ -206,4 +206,131 @@ inline hipError_t launch_conv_stream(ConvStreamArgs a, int dil, hipStream_t st) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Dense(64 -> 64) followed by the prefix sum over time, the residual and the activation in ONE pass:
+//   out[b,t,r,:] = act( sum_{t' <= t} (x[b,t',r,:] W + bias) + res[b,0,r,:] )
+// (`Dense` named dense_resx, `cumsum(x_out, axis=1) + res`, activation: emulator.py:313-320).  Same streaming scheme as
+// k_conv3_stream: a wave owns 16 rows of one batch element and walks the T steps; the running sum never leaves the MFMA
+// accumulators (x W accumulates across steps), the bias enters as (t+1) * bias, the residual block sits in registers.
+// Replaces a row GEMM + a prefix-sum kernel (2 reads + 2 writes of the tensor) by 1 read + 1 write.
+// ---------------------------------------------------------------------------------------------------------------
+struct DenseCumsumArgs {
+  const float *x, *bias, *res;      // res (B, 1, R, 64) or nullptr
+  const uint4 *packed;              // k_pack_weight_frags layout of the (64, 64) kernel
+  float *out;
+  int B, T, R, act, n_blocks;
+};
+
+constexpr int DC_WAVES = 2, DC_PREF = 4, DC_RING = DC_PREF + 1;
+
+template <int ACT>
+__global__ __launch_bounds__(DC_WAVES * 64, 2) void k_dense_cumsum_stream(DenseCumsumArgs a) {
+  constexpr int F = 64, MB = 4, KT = 2, LD = 36;
+  extern __shared__ __attribute__((aligned(16))) float smem_dc[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, qd = lane >> 4;
+  uint4 *wlds = reinterpret_cast<uint4 *>(smem_dc);
+  float *ring = smem_dc + KT * MB * 2 * 64 * 4 + wave * (DC_RING * 1024);
+  for (int i = tid; i < KT * MB * 2 * 64; i += DC_WAVES * 64) wlds[i] = a.packed[i];
+  __syncthreads();
+  const int unit = blockIdx.x * DC_WAVES + wave;
+  if (unit >= a.B * a.n_blocks) return;
+  const int b = unit / a.n_blocks, nb = unit - b * a.n_blocks;
+  const int n_valid = min(16, a.R - nb * 16);
+  const int64_t row0 = (int64_t)b * a.T * a.R + nb * 16;
+  const int my_row = min(r16, n_valid - 1);
+  const float *src_lane = a.x + (row0 + my_row) * F + 4 * qd;
+  const int64_t t_stride = (int64_t)a.R * F;
+  const unsigned my_lds = __builtin_amdgcn_readfirstlane(lds_addr(ring));
+  auto issue = [&](int t, int slot) {
+    const float *s = src_lane + (int64_t)min(t, a.T - 1) * t_stride;
+    const float *pc[4] = {s, s + 16, s + 32, s + 48};
+    glds16_run<4>(pc, my_lds + (unsigned)slot * 4096);
+  };
+#pragma unroll
+  for (int q = 0; q < DC_PREF; ++q) issue(q, q);
+  // weights, bias and the residual block in accumulator layout: lane (r16, qd) <-> out[row r16][16 m + 4 qd + j]
+  bf16x8 wh[KT][MB], wl[KT][MB];
+  f32x4 bb[MB], rr[MB], run[MB];
+#pragma unroll
+  for (int m = 0; m < MB; ++m) {
+#pragma unroll
+    for (int h = 0; h < KT; ++h) {
+      wh[h][m] = __builtin_bit_cast(bf16x8, wlds[((h * MB + m) * 2 + 0) * 64 + lane]);
+      wl[h][m] = __builtin_bit_cast(bf16x8, wlds[((h * MB + m) * 2 + 1) * 64 + lane]);
+    }
+    bb[m] = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + 16 * m + 4 * qd) : f32x4{0.f, 0.f, 0.f, 0.f};
+    rr[m] = a.res ? *reinterpret_cast<const f32x4 *>(a.res + ((int64_t)b * a.R + nb * 16 + my_row) * F + 16 * m + 4 * qd)
+                  : f32x4{0.f, 0.f, 0.f, 0.f};
+    run[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  int slot = 0;
+  for (int t = 0; t < a.T; ++t) {
+    int rs = slot + DC_PREF;
+    rs = rs >= DC_RING ? rs - DC_RING : rs;
+    issue(t + DC_PREF, rs);
+    const int st = min(t, DC_PREF);
+    bool waited = false;
+    static_for<DC_PREF>([&](auto k_) {
+      constexpr int K = decltype(k_)::value;
+      if (st == K) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * DC_PREF + 4 * K) : "memory");
+        waited = true;
+      }
+    });
+    if (!waited) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * DC_PREF) : "memory");
+    const float4 *sl = reinterpret_cast<const float4 *>(ring + slot * 1024) + lane;
+    const float4 v0 = sl[0], v1 = sl[64], v2 = sl[128], v3 = sl[192];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float *tile = ring + slot * 1024;          // the consumed slot doubles as the store tile until the next step's DMA
+    slot = slot + 1 == DC_RING ? 0 : slot + 1;
+    bf16x8 dh[2], dl[2];
+    split8(v0, v1, dh[0], dl[0]);
+    split8(v2, v3, dh[1], dl[1]);
+#pragma unroll
+    for (int h = 0; h < KT; ++h)
+#pragma unroll
+      for (int m = 0; m < MB; ++m) run[m] = mfma3(wh[h][m], wl[h][m], dh[h], dl[h], run[m]);
+    const float tb = (float)(t + 1);
+    const int64_t orow = row0 + (int64_t)t * a.R;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm) {
+        const int m = 2 * g + mm;
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fused_act<ACT>(run[m][j] + fmaf(tb, bb[m][j], rr[m][j]), a.act);
+        *reinterpret_cast<f32x4 *>(tile + r16 * LD + 16 * mm + 4 * qd) = o;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r_ = min(i * 8 + (lane >> 3), n_valid - 1), cc = 4 * (lane & 7);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(tile + r_ * LD + cc);
+        *reinterpret_cast<f32x4 *>(a.out + (orow + r_) * 64 + 32 * g + cc) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+inline int64_t dense_cumsum_lds_bytes() { return (int64_t)2 * 4 * 2 * 1024 + DC_WAVES * DC_RING * 4096; }
+
+template <int ACT>
+inline hipError_t launch_dense_cumsum_a(const DenseCumsumArgs &a, hipStream_t st) {
+  const int units = a.B * a.n_blocks;
+  hipLaunchKernelGGL((k_dense_cumsum_stream<ACT>), dim3((unsigned)((units + DC_WAVES - 1) / DC_WAVES)), dim3(DC_WAVES * 64),
+                     (size_t)dense_cumsum_lds_bytes(), st, a);
+  return hipGetLastError();
+}
+
+inline hipError_t launch_dense_cumsum(const DenseCumsumArgs &a, hipStream_t st) {
+  if (a.act == 1) return launch_dense_cumsum_a<1>(a, st);
+  if (a.act == 0) return launch_dense_cumsum_a<0>(a, st);
+  return launch_dense_cumsum_a<-1>(a, st);
+}
+
 }  // namespace uds

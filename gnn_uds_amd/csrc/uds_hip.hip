@@ -326,6 +326,21 @@ int uds_rowgemm_forward_cat(const float *x, int64_t F1, const float *x2, int64_t
   return UDS_OK;
 }
 
+int uds_dense_cumsum(const float *x, int64_t B, int64_t T, int64_t R, const void *packed, const float *bias, const float *res, int act,
+                     float *out, uds_stream_t stream) {
+  UDS_REQUIRE(x && packed && out, "uds_dense_cumsum: NULL x/packed/out");
+  UDS_REQUIRE(B >= 0 && T > 0 && R > 0, "uds_dense_cumsum: bad sizes B=%lld T=%lld R=%lld", (long long)B, (long long)T, (long long)R);
+  UDS_REQUIRE(act >= UDS_ACT_LINEAR && act <= UDS_ACT_HARD_SIGMOID, "uds_dense_cumsum: unknown activation %d", act);
+  UDS_REQUIRE(aligned16(x) && aligned16(packed) && aligned16(out) && aligned16(bias) && aligned16(res),
+              "uds_dense_cumsum: pointers must be 16-byte aligned");
+  UDS_REQUIRE(B * T * R < INT32_MAX, "uds_dense_cumsum: %lld rows exceed the int32 row index", (long long)(B * T * R));
+  if (B == 0) return UDS_OK;
+  uds::DenseCumsumArgs a{x, bias, res, reinterpret_cast<const uint4 *>(packed), out, (int)B, (int)T, (int)R, act, (int)((R + 15) / 16)};
+  hipError_t e = uds::launch_dense_cumsum(a, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_dense_cumsum: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
 int uds_cumsum_act(const float *x, const float *res, int64_t B, int64_t T, int64_t R, int64_t F, int act, float *out,
                    uds_stream_t stream) {
   UDS_REQUIRE(x && out, "uds_cumsum_act: NULL x/out");

@@ -228,14 +228,19 @@ class Emulator(nn.Module):
             x = ly(x)
         for ly in self.tem2_e:
             e = ly(e)
-        x, e = self.res_x(x), self.res_e(e)
-        if self.resnet:                                               # :315-320
-            if _ag.grad_on(x, e, x_lin_last, e_lin_last):
-                x = _ag.CumsumActFn.apply(x, x_lin_last, self.activation)
-                e = _ag.CumsumActFn.apply(e, e_lin_last, self.activation)
-            else:
-                x = _lib.cumsum_act(x, x_lin_last, self.activation)
-                e = _lib.cumsum_act(e, e_lin_last, self.activation)
+        def res_head(layer, t, lin_last):                             # :313-320
+            if not self.resnet:
+                return layer(t)
+            if (layer.precision == 'bf16x3' and layer.units == 64 and t.shape[-1] == 64 and t.shape[0] * t.shape[2] >= 4096
+                    and not _ag.grad_on(t, lin_last, layer.kernel, layer.bias)):
+                # Dense + cumsum over time + residual + activation in one streaming kernel
+                return _lib.dense_cumsum(c(t), _packed_kernel(layer, layer.kernel), layer.bias, c(lin_last), self.activation)
+            y = layer(t)
+            if _ag.grad_on(y, lin_last):
+                return _ag.CumsumActFn.apply(y, lin_last, self.activation)
+            return _lib.cumsum_act(y, lin_last, self.activation)
+
+        x, e = res_head(self.res_x, x, x_lin_last), res_head(self.res_e, e, e_lin_last)
         out = self.out(x)
         if self.if_flood:
             f = x

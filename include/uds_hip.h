@@ -111,6 +111,13 @@ int uds_rowgemm_forward_cat(const float *x, int64_t F1, const float *x2, int64_t
                             const void *packed, const float *bias, int64_t taps, int64_t dil, int64_t f_out, int act,
                             float *out, int64_t ldo, int64_t col0, uds_stream_t stream);
 
+/* keras Dense(64) (64 inputs) + prefix sum over time + residual + activation in one pass (matrix cores, split-bf16):
+ *   out[b,t,r,:] = act( sum_{t' <= t} (x[b,t',r,:] @ kernel + bias) + res[b,0,r,:] ),   x, out: (B,T,R,64), res: (B,1,R,64) or NULL.
+ * `packed` = uds_rowgemm_pack of the (64, 64) kernel.  The `dense_resx` layer and the `cumsum(x_out, axis=1) + res` that
+ * follows it (emulator.py:313-320): one read and one write of the tensor instead of two each. */
+int uds_dense_cumsum(const float *x, int64_t B, int64_t T, int64_t R, const void *packed, const float *bias,
+                     const float *res, int act, float *out, uds_stream_t stream);
+
 /* out[b,t,r,:] = act(cumsum_t(x)[b,t,r,:] + res[b,0,r,:]); x, out (B,T,R,F), res (B,1,R,F) or NULL; F % 4 == 0.
  * The resnet head of the emulator.                                          emulator.py:313-320 */
 int uds_cumsum_act(const float *x, const float *res, int64_t B, int64_t T, int64_t R, int64_t F, int act,

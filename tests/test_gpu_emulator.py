@@ -68,6 +68,22 @@ def test_rowgemm_mfma_dense_and_conv(dev, B, T, R, F, H, taps, dil, act):
           2e-4)
 
 
+@pytest.mark.parametrize('B,T,R,act,with_res', [(1, 7, 300, 'relu', True), (2, 13, 4100, 'relu', True), (1, 60, 33, 'tanh', False),
+                                                (1, 1, 16, 'linear', True)])
+def test_dense_cumsum_stream(dev, B, T, R, act, with_res):
+    """Dense(64->64) + prefix sum over time + residual + activation in one kernel (split-bf16 MFMA): tolerance
+    2e-4 * max(1, max|ref|) * sqrt(T) (the running sum accumulates T products in fp32)."""
+    g = torch.Generator().manual_seed(T + R)
+    x, k, b = rnd(g, B, T, R, 64) - 0.5, rnd(g, 64, 64) - 0.5, rnd(g, 64) - 0.5
+    res = rnd(g, B, 1, R, 64) - 0.5 if with_res else None
+    ref = torch.cumsum(x @ k + b, dim=1)
+    ref = OD.activation(act)(ref + res if with_res else ref)
+    f = lambda t: None if t is None else t.float().to(dev)
+    out = _lib.dense_cumsum(f(x), _lib.rowgemm_pack(f(k)), f(b), f(res), act)
+    close(out, ref, 2e-4 * max(1.0, T ** 0.5))
+    close(_lib.dense_cumsum(f(x), _lib.rowgemm_pack(f(k)), None, None, 'linear'), torch.cumsum(x @ k, dim=1), 2e-4 * max(1.0, T ** 0.5))
+
+
 def test_cumsum_act_and_flow_balance(dev, networks):
     g = torch.Generator().manual_seed(1)
     x, res = rnd(g, 2, 6, 9, 8) - 0.5, rnd(g, 2, 1, 9, 8) - 0.5
