@@ -438,10 +438,12 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
 #pragma unroll
       for (int t = 0; t < KT_X; ++t) split8(st[(2 * t) * 64], st[(2 * t + 1) * 64], dh[t], dl[t]);
       UDS_STAMP(8);    // P2a: stage read + split
+#ifndef UDS_LATE_PRIM_DMA
       if (s + 1 < s_end) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         dma_prim(blk, s + 1);
       }
+#endif
       UDS_STAMP(9);    // P2b: DMA issue
       const int lrow = blk * 16 + r16;
       const bool valid = lrow < n_prim;
@@ -530,6 +532,12 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
     UDS_STAMP(4);
     lds_barrier();
     UDS_STAMP(5);
+#ifdef UDS_LATE_PRIM_DMA
+    // the primary rows of the next snapshot are fetched from here: their stage slots were consumed before the barrier,
+    // and the eight waves no longer queue on the DMA path in the middle of P2
+    if (s + 1 < s_end)
+      for (int blk = wave; blk * 16 < n_prim; blk += NW) dma_prim(blk, s + 1);
+#endif
     // ---------------- P3: segmented softmax + neighbour sum -> HBM ----------------
     // 16 lanes per output row, U row groups (4*U rows) per wave in flight at once so the dependent LDS reads of
     // one group hide behind the others.  Lane c scores neighbour c (one exp per neighbour, not per lane); the row
