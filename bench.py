@@ -75,6 +75,35 @@ def rollout_forward(U, g, args, dev, reps=5):
                       'flood head' % (T, args.layers, args.layers)}
 
 
+def rollout_autoregressive(U, dev, steps=100):
+    """BASELINE.json config 2: a real-scale network (2k nodes / 2.5k conduits), d=64, 3+3 spatial layers, 100-step rainfall
+    rollout fed back step by step (seq_in 6, seq_out 1, B=1; `Emulator._model` with roll=100, emulator.py:400-438): simulated
+    steps per second of the eager loop and with every step replayed from one captured HIP graph."""
+    from types import SimpleNamespace
+    N, E = 2000, 2500
+    edges = U.synthetic_drainage_network(N, E, 0)
+    g = U.DrainageGraph.from_edges(edges)
+    a = SimpleNamespace(state_shape=(N, 4), edge_state_shape=(E, 4), seq_in=6, seq_out=1, embed_size=64, hidden_dim=64, kernel_size=3,
+                        n_sp_layer=3, n_tp_layer=2, activation='relu', if_flood=3, edge_fusion=True, edges=edges, act=False, graph=g,
+                        roll=steps, model_dir=None)
+    emul = U.Emulator('GAT', True, 'Conv1D', a, generator=torch.Generator().manual_seed(1)).to(dev)
+    rng = np.random.default_rng(0)
+    emul.set_norm(*[np.stack([0.5 + rng.random((n, c)), np.zeros((n, c))]) for n, c in ((N, 5), (N, 1), (N, 5), (N, 1), (E, 4))])
+    x, b, ex = torch.rand(1, 6, N, 5, device=dev), torch.rand(1, steps, N, 1, device=dev) * 0.1, torch.rand(1, 6, E, 4, device=dev)
+    out = {}
+    for name, fn in (('eager', lambda: emul._model(x, None, b, ex)), ('hip_graph', lambda: emul.rollout_graphed(x, None, b, ex))):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        out[name + '_steps_per_s'] = steps * 3 / (time.perf_counter() - t0)
+    out['config'] = 'C2: N=2000 E=2500 d=64, 3+3 spatial layers, seq_in=6 seq_out=1 B=1, %d autoregressive steps' % steps
+    return out
+
+
 def cpu_baseline(g, block_params, d, budget_s=12.0, S=2):
     """The oracle (sparse-CSR PyTorch-CPU restatement of the reference forward, kind 'port': the
     reference's TF path cannot run here) timed on this host's cores on a bounded sample."""
@@ -318,6 +347,7 @@ def main():
         }
         if world == 1 and args.embed == 64:
             out['rollout'] = rollout_forward(U, g, args, dev)
+            out['rollout']['autoregressive'] = rollout_autoregressive(U, dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(g, params, d)
         print(json.dumps(out))

@@ -168,6 +168,13 @@ class Emulator(nn.Module):
         self.register_buffer('_inc_sign', torch.as_tensor(self.graph.inc_n.val, dtype=torch.float32), persistent=False)
         self._inc_handle = None
         self._norms = {}
+        # host-side facts about the constant buffers (the reference tests them per call, emulator.py:688,698,630): decided once,
+        # so the forward path has no device -> host synchronisation (and can be captured into a HIP graph)
+        self._has_offset = bool(float(self.offset.max()) > 0) if self.n_edge else False
+        self._has_pump = bool(float(self.pump.min()) > 0) if self.n_edge else False
+        self._has_any_pump = bool(float(self.pump_in.sum() + self.pump_out.sum() + self.pump.sum()) > 0)
+        self._idx_cache = {}
+        self._graph = None
 
         d, h, H, L, gen = self.embed_size, self.embed_size // 2, self.hidden_dim, self.n_sp_layer, generator
         a = self.activation
@@ -275,18 +282,25 @@ class Emulator(nn.Module):
         flat = [int(i) for e in hits for i in e]
         return sorted(set(flat), key=flat.index)
 
+    def _dev_index(self, name, arr, device):
+        """An int64 index list on the device, uploaded once."""
+        key = (name, str(device))
+        if key not in self._idx_cache:
+            self._idx_cache[key] = torch.as_tensor(arr, dtype=torch.int64, device=device)
+        return self._idx_cache[key]
+
     def get_edge_action(self, a, g=True):
         out = np.zeros(self.n_edge, dtype=np.int64)
         out[self._act_edge_index()] = np.arange(1, a.shape[-1] + 1)
         table = torch.cat([torch.ones_like(a[..., :1]), a], dim=-1)
-        return table[..., torch.as_tensor(out, device=a.device)].unsqueeze(-1)
+        return table[..., self._dev_index('edge_action', out, a.device)].unsqueeze(-1)
 
     def get_action(self, a, g=True):
         out_o, out_i = np.zeros(self.n_node, dtype=np.int64), np.zeros(self.n_node, dtype=np.int64)
         out_o[self.act_edges[:, 0]] = np.arange(1, a.shape[-1] + 1)
         out_i[self.act_edges[:, 1]] = np.arange(1, a.shape[-1] + 1)
         table = torch.cat([torch.ones_like(a[..., :1]), a], dim=-1)
-        return table[..., torch.as_tensor(out_o, device=a.device)], table[..., torch.as_tensor(out_i, device=a.device)]
+        return table[..., self._dev_index('act_out', out_o, a.device)], table[..., self._dev_index('act_in', out_i, a.device)]
 
     # ------------------------------------------------------------------ post-processing (:680-770)
     def _flow_balance(self, flow):
@@ -308,13 +322,13 @@ class Emulator(nn.Module):
 
     def post_proc_tf(self, preds, a, b):
         preds, edge_preds = preds
-        if self.node_edge is None and (float(self.offset.max()) > 0 or (self.act and float(self.pump.min()) > 0)):
+        if self.node_edge is None and (self._has_offset or (self.act and self._has_pump)):
             raise NotImplementedError('offset / pump gating needs the dense incidence (`args.node_edge`), not built for CSR-only networks')
         pos = None if self.node_edge is None else self.node_edge.clamp(0, 1)
         if self.tide:
             h = preds[..., 0] * (1 - self.is_outfall) + b[..., -1]
             preds = torch.cat([h.unsqueeze(-1), preds[..., 1:]], dim=-1)
-        if float(self.offset.max()) > 0:
+        if self._has_offset:
             inoff = torch.matmul(self.normalize(preds, 'y', True)[..., 0] - self.hmin, pos)
             flow, off = edge_preds[..., -1], self.offset
             flow = (flow * (flow > 0).float() * (off > 0).float() * (inoff > off).float() + flow * (flow <= 0).float() * (off > 0).float() +
@@ -322,7 +336,7 @@ class Emulator(nn.Module):
             edge_preds = torch.cat([edge_preds[..., :-1], flow], dim=-1)
         if self.act:
             ne_ = self._norm('e', preds.device)
-            if float(self.pump.min()) > 0:
+            if self._has_pump:
                 fl = self.pump * torch.matmul((preds[..., 0] > 0.01).float(), pos)
                 fl = fl * (ne_[0, :, 2] > 1e-3).float() / ne_[0, :, 2]
                 flow = (edge_preds[..., -1] * (fl == 0).float() + fl).unsqueeze(-1)
@@ -374,7 +388,7 @@ class Emulator(nn.Module):
         ey = self.normalize(ey, 'e', True)
         ey = torch.cat([torch.minimum(ey[..., 0].clamp(min=0), self.ehmax).unsqueeze(-1), ey[..., 1:]], dim=-1)
         y = self.normalize(y, 'y', True)
-        if float(self.pump_in.sum() + self.pump_out.sum() + self.pump.sum()) > 0:       # pumped-storage depth (:630-638)
+        if self._has_any_pump:       # pumped-storage depth (:630-638)
             if self.node_edge is None:
                 raise NotImplementedError('pumped-storage depth needs the dense incidence (`args.node_edge`)')
             ps = ((self.area * torch.mv(self.node_edge.clamp(0, 1), self.pump)) > 0).float()
@@ -395,26 +409,77 @@ class Emulator(nn.Module):
             ys, eys = [], []
             for i in range(self.roll):
                 sl = slice(i * self.seq_out, (i + 1) * self.seq_out)
-                ae_i = self.get_edge_action(a[:, sl], True) if self.act else None
-                y, ey = self.forward(x[:, -self.seq_in:], b[:, sl], ex[:, -self.seq_in:], ae_i)
-                y, ey = self.post_proc_tf((y, ey), a[:, sl] if a is not None else None, b[:, sl])
+                y, ey, x, ex = self._roll_step(x, ex, a[:, sl] if a is not None else None, b[:, sl])
                 ys.append(y)
                 eys.append(ey)
-                if self.if_flood:                                   # flood bit fed back as a hard 0/1 (:417)
-                    x_new = torch.cat([y[..., :-1], (y[..., -1:] > 0.5).float(), b[:, sl]], dim=-1)
-                else:
-                    x_new = torch.cat([y, b[:, sl]], dim=-1)
-                keep = self.seq_in - self.seq_out
-                x = torch.cat([x[:, -keep:], x_new], dim=1) if keep > 0 else x_new
-                ae_new = ae_i if self.act else torch.ones(ey.shape[:-1] + (1,), device=ey.device)
-                ex_new = torch.cat([ey, ae_new], dim=-1)
-                ex = torch.cat([ex[:, -keep:], ex_new], dim=1) if keep > 0 else ex_new
             preds, edge_preds = torch.cat(ys, dim=1), torch.cat(eys, dim=1)
         else:
             if ae is None and self.act:
                 ae = self.get_edge_action(a, True)
             preds, edge_preds = self.post_proc_tf(self.forward(x, b, ex, ae), a, b)
         return preds.clamp(0, 1), edge_preds                          # :437
+
+    def _roll_step(self, x, ex, a_i, b_i):
+        """One chunk of the autoregressive rollout (emulator.py:403-423): forward on the last seq_in steps, post-processing,
+        then the window shifts by seq_out steps fed with the prediction (flood bit thresholded at 0.5)."""
+        ae_i = self.get_edge_action(a_i, True) if self.act else None
+        y, ey = self.forward(x[:, -self.seq_in:], b_i, ex[:, -self.seq_in:], ae_i)
+        y, ey = self.post_proc_tf((y, ey), a_i, b_i)
+        if self.if_flood:                                   # flood bit fed back as a hard 0/1 (:417)
+            x_new = torch.cat([y[..., :-1], (y[..., -1:] > 0.5).float(), b_i], dim=-1)
+        else:
+            x_new = torch.cat([y, b_i], dim=-1)
+        keep = self.seq_in - self.seq_out
+        x = torch.cat([x[:, -keep:], x_new], dim=1) if keep > 0 else x_new
+        ae_new = ae_i if self.act else torch.ones(ey.shape[:-1] + (1,), device=ey.device)
+        ex_new = torch.cat([ey, ae_new], dim=-1)
+        ex = torch.cat([ex[:, -keep:], ex_new], dim=1) if keep > 0 else ex_new
+        return y, ey, x, ex
+
+    def rollout_graphed(self, x, a, b, ex):
+        """`_model` with roll > 0 where every chunk replays ONE captured HIP graph (the step has ~60 small launches: with few
+        snapshots per step the eager loop is bound by launch latency).  Same arguments and result as `_model(x, a, b, ex)`;
+        the graph is re-captured when shapes change.  Parameters must not change between capture and replay (the packed
+        weight buffers are baked in): call `drop_graph()` after loading or training."""
+        if not self.roll:
+            raise ValueError('rollout_graphed needs roll > 0')
+        so = self.seq_out
+        key = (tuple(x[:, -self.seq_in:].shape), tuple(b.shape[2:]), tuple(ex[:, -self.seq_in:].shape), None if a is None else tuple(a.shape[2:]),
+               str(x.device))
+        if self._graph is None or self._graph['key'] != key:
+            G = dict(key=key, x=x[:, -self.seq_in:].clone(), ex=ex[:, -self.seq_in:].clone(), b=b[:, :so].clone(),
+                     a=None if a is None else a[:, :so].clone())
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side), torch.no_grad():          # warm-up: caches, packed weights, tile plans
+                for _ in range(2):
+                    self._roll_step(G['x'], G['ex'], G['a'], G['b'])
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            G['graph'] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(G['graph']), torch.no_grad():
+                y, ey, xn, exn = self._roll_step(G['x'], G['ex'], G['a'], G['b'])
+                G['x'].copy_(xn)
+                G['ex'].copy_(exn)
+            G['y'], G['ey'] = y, ey
+            self._graph = G
+        G = self._graph
+        with torch.no_grad():
+            G['x'].copy_(x[:, -self.seq_in:])
+            G['ex'].copy_(ex[:, -self.seq_in:])
+            ys = torch.empty((x.shape[0], self.roll * so) + tuple(G['y'].shape[2:]), device=x.device)
+            eys = torch.empty((x.shape[0], self.roll * so) + tuple(G['ey'].shape[2:]), device=x.device)
+            for i in range(self.roll):
+                sl = slice(i * so, (i + 1) * so)
+                G['b'].copy_(b[:, sl])
+                if a is not None:
+                    G['a'].copy_(a[:, sl])
+                G['graph'].replay()
+                ys[:, sl].copy_(G['y'])
+                eys[:, sl].copy_(G['ey'])
+        return ys.clamp(0, 1), eys
+
+    def drop_graph(self):
+        self._graph = None
 
     def simulate(self, states, runoff, a=None, edge_states=None):
         """emulator.py:521-564, with every sliding window of the event batched into ONE forward (the reference loops

@@ -190,6 +190,28 @@ def test_model_rollout(dev, networks):
     assert float((ey.double().cpu() - rey).abs().max()) < 5e-3
 
 
+def test_graph_captured_rollout_equals_the_eager_loop(dev, networks):
+    """`rollout_graphed`: every autoregressive chunk replays one captured HIP graph; results are bit-identical to the eager
+    `_model` loop (same kernels, same order), also when called again with new inputs and after a shape change."""
+    net = networks['astlingen']
+    edges, n = np.array(net['edges']), net['n_node']
+    for over in (dict(roll=4, seq_in=5, seq_out=1, n_sp_layer=1), dict(roll=3, seq_in=4, seq_out=2, n_sp_layer=1, act=False, if_flood=0)):
+        args = emulator_args(edges, n, **over)
+        norms = emulator_norms(args)
+        emul = load_emulator(U.Emulator(args.conv, args.resnet, args.recurrent, args), OE.init_params(args, seed=2), dev)
+        emul.set_norm(*(norms[k].numpy() for k in 'xbyre'))
+        c = OE.config(args)
+        for seed, B in ((1, 2), (2, 2), (3, 3)):
+            g = torch.Generator().manual_seed(seed)
+            f = lambda t: t.float().to(dev)
+            x, b, ex = f(rnd(g, B, c.seq_in, n, c.n_in)), f(rnd(g, B, c.seq_out * c.roll, n, c.b_in) * 0.1), f(rnd(g, B, c.seq_in, len(edges), c.e_in))
+            a = f(rnd(g, B, c.seq_out * c.roll, len(args.act_edges))) if c.act else None
+            y0, e0 = emul._model(x, a, b, ex)
+            y1, e1 = emul.rollout_graphed(x, a, b, ex)
+            assert torch.equal(y0, y1) and torch.equal(e0, e1)
+        emul.drop_graph()
+
+
 def test_save_load_and_not_built(dev, networks, tmp_path):
     args, params, emul, norms = _setup(networks, 'astlingen', dev, n_sp_layer=1)
     X, Bd, Ex, a = _inputs(args, 1)
