@@ -26,7 +26,8 @@ from torch import nn
 from . import _lib
 from .graph import DrainageGraph, csr_from_dense
 from . import autograd as _ag
-from .layers import Dense, SpatialBlock, _glorot_uniform, _packed_kernel, _param
+from .graph import csr_from_dense, edge_based_adj_csr, node_based_adj_csr
+from .layers import Dense, GraphBaseBlock, SpatialBlock, _glorot_uniform, _packed_kernel, _param
 
 
 class Conv1D(nn.Module):
@@ -132,15 +133,38 @@ class Emulator(nn.Module):
             self.conv_kind = 'GCN'
         else:
             raise NotImplementedError('conv=%r is not built (GAT and GCN are)' % (conv,))
-        if self.graph_base or self.use_adj:
-            raise NotImplementedError('graph_base > 0 and use_adj are not built')
+        if self.use_adj:
+            raise NotImplementedError('use_adj (per-step adjacency rewritten by the control action) is not built')
+        if self.graph_base not in (0, 1, 2):
+            raise ValueError('graph_base must be 0, 1 (node-based) or 2 (edge-based), got %r' % (self.graph_base,))
         if recurrent not in ('Conv1D', None, 'None', False):
             raise NotImplementedError('recurrent=%r is not built (Conv1D is what every shipped model uses)' % (recurrent,))
         if self.dropout:
             raise NotImplementedError('dropout > 0 (training-time) is not built')
 
         graph = g('graph')
-        if isinstance(graph, DrainageGraph):
+        self._base_filter = None
+        if self.graph_base:
+            # ONE graph over nodes and links (base.py:471-532); `args.adj` is then the combined (N+E) x (N+E) matrix
+            # (base.py:320-323) -- or, with `args.graph`, the pattern is rebuilt in CSR from the link list
+            self.graph = graph if isinstance(graph, DrainageGraph) else DrainageGraph.from_edges(self.edges, self.n_node)
+            node_edge = None if isinstance(graph, DrainageGraph) else np.asarray(g('node_edge'), dtype=np.float64)
+            if g('adj') is not None and not isinstance(graph, DrainageGraph):
+                adj = np.asarray(g('adj'))
+                if adj.shape != (self.n_node + self.n_edge,) * 2:
+                    raise ValueError('graph_base needs the combined (N+E, N+E) adjacency, got %r' % (adj.shape,))
+                if self.conv_kind == 'GCN':
+                    from .layers import GCNConv
+                    self._base_filter = GCNConv.preprocess(adj)
+                else:
+                    self._base_filter = csr_from_dense((adj > 0).astype(int), add_self_loops=True)
+            else:
+                if self.conv_kind != 'GAT':
+                    raise NotImplementedError('graph_base with a CSR graph is built for conv=GAT')
+                build = node_based_adj_csr if self.graph_base == 1 else edge_based_adj_csr
+                self._base_filter = build(self.edges, self.n_node, bool(g('directed', False)), int(g('order', 1)), g('length', 0))
+            self.filter = self.edge_filter = None
+        elif isinstance(graph, DrainageGraph):
             # large networks: `args.graph` (CSR, e.g. DrainageGraph.from_edges) instead of the dense (N,N) / (E,E) / (N,E)
             # matrices of `args.adj`, `args.edge_adj`, `args.node_edge`, which cannot exist at N >= 50k
             if self.conv_kind != 'GAT':
@@ -184,14 +208,24 @@ class Emulator(nn.Module):
         self.embed_e = Dense(d, 'linear', in_features=self.e_in, generator=gen)                 # :206
         self.embed_ae = Dense(h, a, in_features=1, generator=gen) if self.act else None         # :212
         sp = self.n_node * self.n_edge > (1 << 24)
-        self.block1 = SpatialBlock(self.graph, d, L, a, sparse_params=sp, generator=gen, precision=precision,
-                                   conv=self.conv_kind, filters=(self.filter, self.edge_filter))                      # :219-235
+        if self.graph_base:
+            self.block1 = GraphBaseBlock(self.n_node, self.n_edge, self._base_filter, d, L, a, generator=gen, conv=self.conv_kind,
+                                         precision=precision)                                                          # :220-223
+        else:
+            self.block1 = SpatialBlock(self.graph, d, L, a, sparse_params=sp, generator=gen, precision=precision,
+                                       conv=self.conv_kind, filters=(self.filter, self.edge_filter))                  # :219-235
         tem = lambda f: nn.ModuleList([Conv1D(H, self.kernel_size, 2 ** i, a, in_features=(f if i == 0 else H), generator=gen, precision=pr)
                                        for i in range(self.n_tp_layer)])
         self.tem1_x, self.tem1_e = tem(d), tem(d)                                               # :247,254
         fx2, fe2 = H + h, H + (h if self.act else 0)
-        self.block2 = SpatialBlock(self.graph, d, L, a, fx=fx2, fe=fe2, sparse_params=sp, generator=gen, precision=precision,
-                                   conv=self.conv_kind, filters=(self.filter, self.edge_filter))                      # :272-288
+        if self.graph_base:
+            if fx2 != fe2:
+                raise ValueError('graph_base stacks node and link rows in block 2: needs act=True (equal widths %d / %d)' % (fx2, fe2))
+            self.block2 = GraphBaseBlock(self.n_node, self.n_edge, self._base_filter, d, L, a, f_in=fx2, generator=gen,
+                                         conv=self.conv_kind, precision=precision)                                     # :273-276
+        else:
+            self.block2 = SpatialBlock(self.graph, d, L, a, fx=fx2, fe=fe2, sparse_params=sp, generator=gen, precision=precision,
+                                       conv=self.conv_kind, filters=(self.filter, self.edge_filter))                  # :272-288
         self.tem2_x, self.tem2_e = tem(d), tem(d)                                               # :302,308
         self.res_x = Dense(d, 'linear' if self.resnet else a, in_features=H, generator=gen, precision=pr)     # :313 'dense_resx'
         self.res_e = Dense(d, 'linear' if self.resnet else a, in_features=H, generator=gen, precision=pr)     # :317
@@ -590,6 +624,10 @@ class Emulator(nn.Module):
             out.append((name('dense'), self.embed_ae, dense_w))
 
         def spatial(block):
+            if self.graph_base:
+                for ly in block.layers:
+                    out.append((name('mixed_gat' if self.conv_kind == 'GAT' else 'gcn_conv'), ly, gat_w if self.conv_kind == 'GAT' else dense_w))
+                return
             for ly in block.layers:
                 out.append((name('dense'), ly.dense_xe, dense_w))
                 out.append((name('dense'), ly.dense_ex, dense_w))

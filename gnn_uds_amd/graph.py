@@ -245,6 +245,78 @@ def edge_adjacency_csr(edges, directed=False, order=1, length=0, lengths=None):
     return _csr_from_pairs(rows, cols, n_edge, n_edge)
 
 
+def node_based_adj_csr(edges, n_node=None, directed=False, order=1, length=0):
+    """Sparse `get_node_based_adj` (`base.py:471-498`, `graph_base = 1`): ONE graph over the N nodes and the E links
+    (vertex N + i = link i) with the edges (u, v), (u, link), (link, v) of every link; row n holds the depth-`order` DFS
+    ball of n, symmetrised unless `directed`."""
+    if length:
+        raise NotImplementedError('graph_base with length > 0 (Gaussian kernel over the combined graph) is not built')
+    edges = _check_edges(edges)
+    if n_node is None:
+        n_node = int(edges.max()) + 1 if edges.size else 0
+    n = n_node + edges.shape[0]
+    me = np.arange(n, dtype=np.int64)
+    if order <= 0:
+        return _csr_from_pairs(me, me, n, n)
+    g = _OrderedGraph(directed)
+    for i, (u, v) in enumerate(edges):
+        g.add_edge(int(u), int(v))
+        g.add_edge(int(u), n_node + i)
+        g.add_edge(n_node + i, int(v))
+    rows, cols = [], []
+    for r in range(n):
+        for a in g.ball(r, order):
+            rows.append(r)
+            cols.append(a)
+            if not directed:
+                rows.append(a)
+                cols.append(r)
+    return _csr_from_pairs(rows, cols, n, n)
+
+
+def edge_based_adj_csr(edges, n_node=None, directed=False, order=1, length=0):
+    """Sparse `get_edge_based_adj` (`base.py:500-532`, `graph_base = 2`): the line graph (links meeting at a node) plus
+    an edge between every link and its end nodes, over the N + E vertices; row n = depth-`order` DFS ball, NOT symmetrised
+    (as the reference)."""
+    if length:
+        raise NotImplementedError('graph_base with length > 0 (Gaussian kernel over the combined graph) is not built')
+    edges = _check_edges(edges)
+    if n_node is None:
+        n_node = int(edges.max()) + 1 if edges.size else 0
+    n = n_node + edges.shape[0]
+    me = np.arange(n, dtype=np.int64)
+    if order <= 0:
+        return _csr_from_pairs(me, me, n, n)
+    g = _OrderedGraph(directed)
+    for i, (u, v) in enumerate(edges):
+        g.add_edge(int(u), int(v), edge=n_node + i)
+    ex = _OrderedGraph(directed)
+    for v in list(g.succ):
+        if directed:
+            ins = [g.succ[a][v]['edge'] for a in g.pred[v]]
+            outs = [g.succ[v][d]['edge'] for d in g.succ[v]]
+            for p in ins:
+                for q in outs:
+                    ex.add_edge(p, q)
+            for p in ins:
+                ex.add_edge(p, v)
+            for q in outs:
+                ex.add_edge(v, q)
+        else:
+            inc = [g.succ[v][b]['edge'] for b in g.succ[v]]
+            for i in range(len(inc)):
+                for j in range(i + 1, len(inc)):
+                    ex.add_edge(inc[i], inc[j])
+            for p in inc:
+                ex.add_edge(p, v)
+    rows, cols = [], []
+    for r in range(n):
+        for a in ex.ball(r, order):
+            rows.append(r)
+            cols.append(a)
+    return _csr_from_pairs(rows, cols, n, n)
+
+
 def _dijkstra_ball(nbrs, src, cutoff):
     """{vertex: distance} for every vertex within `cutoff` of src (inclusive), as
     nx.single_source_dijkstra_path_length(G, src, weight='length', cutoff=cutoff)."""

@@ -470,6 +470,39 @@ class SpatialLayer(nn.Module):
         return ox.reshape(lead_x + ox.shape[-2:]), oe.reshape(lead_e + oe.shape[-2:])
 
 
+class GraphBaseBlock(nn.Module):
+    """The spatial block of the `graph_base` variants (`emulator.py:220-223,273-276`): ONE graph over the N nodes and the
+    E links (`get_node_based_adj` / `get_edge_based_adj`), one conv per layer over `concat([x, e], axis=-2)`, split back into
+    node and link rows.  `filt`: the combined (N+E) x (N+E) pattern as a `graph.CSR` with self loops (GAT) or the dense
+    normalised filter (GCN)."""
+
+    def __init__(self, n_node, n_edge, filt, embed_size, n_sp_layer, activation='relu', f_in=None, generator=None, conv='GAT',
+                 precision='bf16x3'):
+        super().__init__()
+        if conv not in ('GAT', 'GCN'):
+            raise NotImplementedError('conv=%r: GAT and GCN are built' % (conv,))
+        self.n_node, self.n_edge, self.filt, self.conv = int(n_node), int(n_edge), filt, conv
+        f_in = int(embed_size) if f_in is None else int(f_in)
+        mk = GATConv if conv == 'GAT' else GCNConv
+        self.layers = nn.ModuleList([mk(embed_size, activation=activation, in_channels=(f_in if i == 0 else embed_size), generator=generator)
+                                     for i in range(n_sp_layer)])
+        for ly in self.layers:
+            if conv == 'GAT':
+                ly.precision = precision
+
+    def forward(self, x, e, xb=None, eb=None):
+        if xb is not None:
+            x = torch.cat([x, xb], dim=-1)
+        if eb is not None:
+            e = torch.cat([e, eb], dim=-1)
+        if x.shape[-1] != e.shape[-1]:
+            raise _lib.UdsError('graph_base stacks node and link rows: widths %d and %d differ' % (x.shape[-1], e.shape[-1]))
+        z = torch.cat([x, e], dim=-2)
+        for ly in self.layers:
+            z = ly([z, self.filt])
+        return z[..., :self.n_node, :].contiguous(), z[..., self.n_node:, :].contiguous()
+
+
 class SpatialBlock(nn.Module):
     """`for _ in range(n_sp_layer)` (`emulator.py:219-235`): first layer takes (fx, fe) features."""
 

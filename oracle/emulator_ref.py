@@ -65,6 +65,7 @@ def config(args):
     c.conv = 'GCN' if 'GCN' in conv else 'GAT'
     c.resnet = bool(g('resnet', False))
     c.roll = int(g('roll', 0))
+    c.graph_base = int(g('graph_base', 0))                # 0: node graph + line graph; 1 / 2: one graph over nodes AND links (:220-223)
     if c.conv == 'GAT':                                   # emulator.py:143-145
         c.filter = (c.adj > 0).astype(np.float64)
         c.edge_filter = (c.edge_adj > 0).astype(np.float64)
@@ -96,6 +97,10 @@ def init_params(args, seed=1, bias_scale=0.05):
     dense = lambda fi, fo: {'kernel': _glorot(g, (fi, fo)), 'bias': bias(fo)}
 
     def spatial(fx, fe):
+        if c.graph_base:                                      # one conv over concat([x, e], axis=-2) (emulator.py:220-223,273-276)
+            assert fx == fe, 'graph_base concatenates node and link rows: equal widths needed'
+            return {'gat': {'kernel': _glorot(g, (fx, 1, d)), 'attn_kernel_self': _glorot(g, (d, 1, 1)),
+                            'attn_kernel_neighs': _glorot(g, (d, 1, 1)), 'bias': bias(d)}}
         conv = lambda f: {'kernel': _glorot(g, (f, 1, d)), 'attn_kernel_self': _glorot(g, (d, 1, 1)),
                           'attn_kernel_neighs': _glorot(g, (d, 1, 1)), 'bias': bias(d)}
         return {'dense_xe': dense(fe, h), 'dense_ex': dense(fx, h),
@@ -185,7 +190,13 @@ def forward(args, params, X, B, E, AE=None):
         T = x.shape[1]
         xs, es = x.reshape((-1,) + tuple(x.shape[2:])), e.reshape((-1,) + tuple(e.shape[2:]))
         for p in layers:
-            xs, es = _spatial_layer(xs, es, p, c, dt)
+            if c.graph_base:
+                q = p['gat']
+                z = OD.gat_conv_dense(torch.cat([xs, es], dim=-2), torch.from_numpy(c.filter).to(dt), q['kernel'], q['attn_kernel_self'],
+                                      q['attn_kernel_neighs'], q['bias'], c.activation)
+                xs, es = z[:, :c.n_node], z[:, c.n_node:]
+            else:
+                xs, es = _spatial_layer(xs, es, p, c, dt)
         return xs.reshape(nb, T, c.n_node, -1), es.reshape(nb, T, c.n_edge, -1)
 
     def temporal(x, layers, n):                                   # :244-257 / :299-310

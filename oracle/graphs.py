@@ -84,6 +84,52 @@ def edge_adjacency(edges, directed=False, length=0, order=1, lengths=None):
     return adj
 
 
+def node_based_adjacency(edges, directed=False, order=1):
+    """`get_node_based_adj` with length = 0 (`base.py:471-498`): nodes and links in one graph, vertex n_node + i = link i."""
+    edges = np.asarray(edges)
+    n_node, n_edge = int(edges.max()) + 1, edges.shape[0]
+    adj = np.zeros((n_node + n_edge, n_node + n_edge))
+    g = nx.DiGraph() if directed else nx.Graph()
+    for i, (u, v) in enumerate(edges):
+        g.add_edge(int(u), int(v))
+        g.add_edge(int(u), n_node + i)
+        g.add_edge(n_node + i, int(v))
+    for n in range(n_node + n_edge):
+        for a in (list(nx.dfs_preorder_nodes(g, n, order)) if order > 0 else [n]):
+            adj[n, a] = 1
+            if not directed:
+                adj[a, n] = 1
+    return adj
+
+
+def edge_based_adjacency(edges, directed=False, order=1):
+    """`get_edge_based_adj` with length = 0 (`base.py:500-532`)."""
+    from itertools import product
+    edges = np.asarray(edges)
+    n_node, n_edge = int(edges.max()) + 1, edges.shape[0]
+    g = nx.DiGraph() if directed else nx.Graph()
+    for i, (u, v) in enumerate(edges):
+        g.add_edge(int(u), int(v), edge=n_node + i)
+    ex = nx.DiGraph() if directed else nx.Graph()
+    for n in g.nodes():
+        pairs = product(g.in_edges(n), g.out_edges(n)) if directed else combinations(g.edges(n), 2)
+        for (a, b), (c, d) in pairs:
+            ex.add_edge(g[a][b]['edge'], g[c][d]['edge'])
+        if directed:
+            for a, b in g.in_edges(n):
+                ex.add_edge(g[a][b]['edge'], n)
+            for c, d in g.out_edges(n):
+                ex.add_edge(n, g[c][d]['edge'])
+        else:
+            for a, b in g.edges(n):
+                ex.add_edge(g[a][b]['edge'], n)
+    adj = np.zeros((n_node + n_edge, n_node + n_edge))
+    for n in range(n_node + n_edge):
+        for a in (list(nx.dfs_preorder_nodes(ex, n, order)) if order > 0 else [n]):
+            adj[n, a] = 1
+    return adj
+
+
 def node_edge_incidence(n_node, edges):
     """`get_node_edge` (`base.py:432-439`): +1 at the from-node, -1 at the to-node
     (a self-referential link nets to 0)."""

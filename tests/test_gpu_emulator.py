@@ -190,6 +190,33 @@ def test_model_rollout(dev, networks):
     assert float((ey.double().cpu() - rey).abs().max()) < 5e-3
 
 
+@pytest.mark.parametrize('graph_base', [1, 2])
+def test_graph_base_variants(dev, networks, graph_base):
+    """graph_base = 1 / 2 (`emulator.py:220-223,273-276`): one conv over the stacked node + link rows on the combined
+    graph of `get_node_based_adj` / `get_edge_based_adj`; forward parity with the oracle (exact-fp32 conv: 5e-5) from the
+    dense `args.adj` AND from the CSR builders (`args.graph`)."""
+    net = networks['astlingen']
+    edges, n = np.array(net['edges']), net['n_node']
+    args = emulator_args(edges, n, graph_base=graph_base, n_sp_layer=2)
+    params = OE.init_params(args, seed=4)
+    c = OE.config(args)
+    g = torch.Generator().manual_seed(9)
+    X, Bd, Ex = rnd(g, 2, c.seq_in, n, c.n_in), rnd(g, 2, c.seq_out, n, c.b_in), rnd(g, 2, c.seq_in, len(edges), c.e_in)
+    AE = rnd(g, 2, c.seq_out, len(edges), 1)
+    ry, re = OE.forward(args, params, X, Bd, Ex, AE)
+    f = lambda t: t.float().to(dev)
+    emul = load_emulator(U.Emulator(args.conv, args.resnet, args.recurrent, args), params, dev)
+    y, ey = emul(f(X), f(Bd), f(Ex), f(AE))
+    close(y, ry, 5e-4); close(ey, re, 5e-4)
+    args2 = emulator_args(edges, n, graph_base=graph_base, n_sp_layer=2)
+    args2.graph, args2.adj = U.DrainageGraph.from_edges(edges, n), None
+    emul2 = load_emulator(U.Emulator(args2.conv, args2.resnet, args2.recurrent, args2), params, dev)
+    y2, ey2 = emul2(f(X), f(Bd), f(Ex), f(AE))
+    assert torch.equal(y, y2) and torch.equal(ey, ey2)
+    names = [nm for nm, _, _ in emul.keras_layer_map()]
+    assert names[4:6] == ['mixed_gat', 'mixed_gat_1'] and 'node_edge' not in names
+
+
 def test_graph_captured_rollout_equals_the_eager_loop(dev, networks):
     """`rollout_graphed`: every autoregressive chunk replays one captured HIP graph; results are bit-identical to the eager
     `_model` loop (same kernels, same order), also when called again with new inputs and after a shape change."""

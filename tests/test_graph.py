@@ -133,3 +133,20 @@ def test_gaussian_length_kernel_matches_networkx(networks, name, cutoff):
             assert np.array_equal(ref > 0, csr.to_dense() > 0) and np.allclose(ref, csr.to_dense(), rtol=1e-12, atol=0)
     with pytest.raises(ValueError):
         G.adjacency_csr(e, length=cutoff)
+
+
+@pytest.mark.parametrize('name', ['astlingen', 'shunqing', 'hague', 'RedChicoSur'])
+def test_graph_base_adjacencies_match_the_networkx_oracle(networks, name):
+    """`get_node_based_adj` / `get_edge_based_adj` (base.py:471-532, graph_base 1 / 2): nodes and links in ONE graph; the CSR
+    builders equal the networkx restatement bit for bit for every direction / DFS depth."""
+    net = networks[name]
+    e = np.array(net['edges'])
+    for directed in (False, True):
+        for order in (0, 1, 2):
+            a = G.node_based_adj_csr(e, None, directed, order)
+            assert np.array_equal(a.to_dense(), OG.node_based_adjacency(e, directed, order))
+            b = G.edge_based_adj_csr(e, None, directed, order)
+            assert np.array_equal(b.to_dense(), OG.edge_based_adjacency(e, directed, order))
+            assert a.n_rows == b.n_rows == int(e.max()) + 1 + len(e)
+    with pytest.raises(NotImplementedError):
+        G.node_based_adj_csr(e, None, False, 1, length=100.0)

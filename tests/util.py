@@ -77,6 +77,9 @@ def emulator_args(edges, n_node, seed=0, **over):
              area=np.zeros(n_node), pump=np.zeros(n_edge), pump_in=np.zeros(n_node), pump_out=np.zeros(n_node),
              offset=np.zeros(n_edge), ehmax=0.3 + rng.random(n_edge), tide=False)
     a.update(over)
+    if a.get('graph_base'):                  # the reference passes the combined (N+E)^2 adjacency as `adj` (base.py:320-323)
+        build = OG.node_based_adjacency if a['graph_base'] == 1 else OG.edge_based_adjacency
+        a['adj'] = build(edges, a.get('directed', False), a.get('order', 1))
     return SimpleNamespace(**a)
 
 
@@ -100,6 +103,11 @@ def load_emulator(emul, p, device):
 
     def spatial(block, layers):
         for layer, q in zip(block.layers, layers):
+            if 'gat' in q:                      # graph_base: one conv over the stacked node + link rows
+                layer.kernel.data = f32(q['gat']['kernel'])
+                layer.attn_kernel_self.data, layer.attn_kernel_neighs.data = f32(q['gat']['attn_kernel_self']), f32(q['gat']['attn_kernel_neighs'])
+                layer.bias.data = f32(q['gat']['bias'])
+                continue
             dense(layer.dense_xe, q['dense_xe']); dense(layer.dense_ex, q['dense_ex'])
             for ne, key in ((layer.node_edge_n, 'node_edge_n'), (layer.node_edge_e, 'node_edge_e')):
                 ne.weight.data, ne.bias.data = f32(q[key]['weight']), f32(q[key]['bias'])
@@ -142,6 +150,8 @@ def emulator_param_pairs(emul, flat):
                 m = getattr(m, part).layers
             elif part.isdigit():
                 m = m[int(part)]
+            elif part == 'gat' and not hasattr(m, 'gat'):
+                pass                              # graph_base: the layer IS the conv
             else:
                 m = getattr(m, part)
         out.append((name, getattr(m, parts[-1]), t))
