@@ -379,3 +379,27 @@ def model_rollout(args, params, norms, x, a, b, ex):
         ex_new = torch.cat([ey, ae_new], dim=-1)                                                  # :422
         ex = torch.cat([ex[:, -(c.seq_in - c.seq_out):], ex_new], dim=1) if c.seq_in > c.seq_out else ex_new
     return torch.cat(ys, dim=1).clamp(0, 1), torch.cat(eys, dim=1)                               # :437
+
+
+def convnet_forward(args, params, X, E, B=None):
+    """`ConvNet.build_network` of the RL agents (agent.py:65-99): Dense embeddings, the spatial block, then Spektral's
+    GlobalAttnSumPool (softmax over the stacked node + link rows of x @ attn_kernel, weighted sum) -> (batch, conv_dim).
+    params: {'embed_x', 'embed_e', 'block': [layers as in init_params], 'pool': {'attn_kernel' (F,1)}}."""
+    c = config(args)
+    dt = X.dtype
+    a = getattr(args, 'activation', None) or 'linear'
+    if getattr(args, 'use_pred', False):
+        X = torch.cat([X, B], dim=-1)
+    x = OD.dense(X, params['embed_x']['kernel'], params['embed_x']['bias'], a)
+    e = OD.dense(E, params['embed_e']['kernel'], params['embed_e']['bias'], a)
+    for p in params['block']:
+        if c.graph_base:
+            q = p['gat']
+            z = OD.gat_conv_dense(torch.cat([x, e], dim=-2), torch.from_numpy(c.filter).to(dt), q['kernel'], q['attn_kernel_self'],
+                                  q['attn_kernel_neighs'], q['bias'], a)
+            x, e = z[:, :c.n_node], z[:, c.n_node:]
+        else:
+            x, e = _spatial_layer(x, e, p, c, dt)
+    z = torch.cat([x, e], dim=-2)
+    alpha = torch.softmax((z @ params['pool']['attn_kernel']).squeeze(-1), dim=-1)
+    return (alpha.unsqueeze(-2) @ z).squeeze(-2)

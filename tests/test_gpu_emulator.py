@@ -217,6 +217,53 @@ def test_graph_base_variants(dev, networks, graph_base):
     assert names[4:6] == ['mixed_gat', 'mixed_gat_1'] and 'node_edge' not in names
 
 
+@pytest.mark.parametrize('graph_base,use_pred', [(0, False), (0, True), (1, False)])
+def test_rl_convnet_encoder(dev, networks, graph_base, use_pred):
+    """`ConvNet` of the RL agents (agent.py:20-99): embeddings + the spatial block + GlobalAttnSumPool; batch of single
+    snapshots.  Tolerance 5e-4 * max(1, max|ref|) (fused split-bf16 layers)."""
+    from oracle import emulator_ref as ER
+    net = networks['shunqing']
+    edges, n = np.array(net['edges']), net['n_node']
+    args = emulator_args(edges, n, graph_base=graph_base, n_sp_layer=2, conv_dim=64, use_pred=use_pred, if_flood=0, activation='relu')
+    args.edge_state_shape = (len(edges), 3)
+    gen = torch.Generator().manual_seed(7)
+    d, h, n_in = 64, 32, 4 + (1 if use_pred else 0)
+    gl = lambda *s: ER._glorot(gen, s)
+    dense = lambda fi, fo: {'kernel': gl(fi, fo), 'bias': torch.randn(fo, generator=gen, dtype=torch.float64) * 0.05}
+    conv = lambda f: {'kernel': gl(f, 1, d), 'attn_kernel_self': gl(d, 1, 1), 'attn_kernel_neighs': gl(d, 1, 1),
+                      'bias': torch.randn(d, generator=gen, dtype=torch.float64) * 0.05}
+    ne = lambda r, m: {'weight': torch.randn(r, m, generator=gen, dtype=torch.float64) * 0.05, 'bias': torch.zeros(r, m, dtype=torch.float64)}
+    if graph_base:
+        layers = [{'gat': conv(d)} for _ in range(2)]
+    else:
+        layers = [{'dense_xe': dense(d, h), 'dense_ex': dense(d, h), 'node_edge_n': ne(n, len(edges)), 'node_edge_e': ne(len(edges), n),
+                   'gat_x': conv(d + h), 'gat_e': conv(d + h)} for _ in range(2)]
+    params = {'embed_x': dense(n_in, d), 'embed_e': dense(3, d), 'block': layers, 'pool': {'attn_kernel': gl(d, 1)}}
+    Bn = 6
+    X, E, Bd = rnd(gen, Bn, n, 4), rnd(gen, Bn, len(edges), 3), rnd(gen, Bn, n, 1)
+    ref = ER.convnet_forward(args, params, X, E, Bd if use_pred else None)
+    m = U.ConvNet(args, 'GAT').to(dev)
+    f32 = lambda t: t.float().to(dev).contiguous()
+    m.embed_x.kernel.data, m.embed_x.bias.data = f32(params['embed_x']['kernel']), f32(params['embed_x']['bias'])
+    m.embed_e.kernel.data, m.embed_e.bias.data = f32(params['embed_e']['kernel']), f32(params['embed_e']['bias'])
+    m.pool.attn_kernel.data = f32(params['pool']['attn_kernel'])
+    for ly, q in zip(m.block.layers, layers):
+        if graph_base:
+            ly.kernel.data, ly.bias.data = f32(q['gat']['kernel']), f32(q['gat']['bias'])
+            ly.attn_kernel_self.data, ly.attn_kernel_neighs.data = f32(q['gat']['attn_kernel_self']), f32(q['gat']['attn_kernel_neighs'])
+        else:
+            for mod, key in ((ly.dense_xe, 'dense_xe'), (ly.dense_ex, 'dense_ex')):
+                mod.kernel.data, mod.bias.data = f32(q[key]['kernel']), f32(q[key]['bias'])
+            for mod, key in ((ly.node_edge_n, 'node_edge_n'), (ly.node_edge_e, 'node_edge_e')):
+                mod.weight.data, mod.bias.data = f32(q[key]['weight']), f32(q[key]['bias'])
+            for mod, key in ((ly.gat_x, 'gat_x'), (ly.gat_e, 'gat_e')):
+                mod.kernel.data, mod.bias.data = f32(q[key]['kernel']), f32(q[key]['bias'])
+                mod.attn_kernel_self.data, mod.attn_kernel_neighs.data = f32(q[key]['attn_kernel_self']), f32(q[key]['attn_kernel_neighs'])
+    out = m(f32(X), f32(E), f32(Bd) if use_pred else None)
+    assert tuple(out.shape) == (Bn, 64)
+    close(out, ref, 5e-4)
+
+
 def test_graph_captured_rollout_equals_the_eager_loop(dev, networks):
     """`rollout_graphed`: every autoregressive chunk replays one captured HIP graph; results are bit-identical to the eager
     `_model` loop (same kernels, same order), also when called again with new inputs and after a shape change."""
