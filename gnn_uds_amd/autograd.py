@@ -162,7 +162,22 @@ class GatFn(torch.autograd.Function):
     def forward(ctx, xa, xb, kernel, a_self, a_nbr, bias, act, handle, precision):
         xa = xa.contiguous()
         xb = None if xb is None else xb.contiguous()
-        out, (hx, s_self, s_nbr) = _lib.gat_forward(handle, xa, kernel, a_self, a_nbr, bias, act, xb, return_workspace=True)
+        fin, d = xa.shape[-1] + (0 if xb is None else xb.shape[-1]), kernel.shape[-1]
+        w2 = kernel.reshape(fin, d)
+        fast = (precision == 'bf16x3' and xa.shape[-1] % 32 == 0 and (xb is None or xb.shape[-1] % 32 == 0) and d % 16 == 0 and
+                all(_lib.rowgemm_supported(fin, 32, min(64, d - c0)) for c0 in range(0, d, 64)) and xa.shape[0] * xa.shape[1] >= 4096)
+        if fast:
+            # linear part on the matrix cores: 64-column blocks of the kernel written into one hx (rows read from their two
+            # tensors), the attention projections as one narrow row GEMM with W a_self, W a_nbr, then the aggregation kernel
+            hx = torch.empty(xa.shape[:-1] + (d,), device=xa.device, dtype=torch.float32)
+            for c0 in range(0, d, 64):
+                _lib.rowgemm_cat(xa, xb, _lib.rowgemm_pack(w2[:, c0:c0 + 64].contiguous()), None, min(64, d - c0), 'linear', out=hx, col0=c0)
+            wa = torch.stack([w2 @ a_self.reshape(-1), w2 @ a_nbr.reshape(-1)], dim=1).contiguous()
+            s2 = _lib.rowgemm_cat(xa, xb, _lib.rowgemm_pack(wa), None, 2, 'linear')
+            s_self, s_nbr = s2[..., 0].contiguous(), s2[..., 1].contiguous()
+            out = _lib.gat_aggregate(handle, hx, s_self, s_nbr, bias, act)
+        else:
+            out, (hx, s_self, s_nbr) = _lib.gat_forward(handle, xa, kernel, a_self, a_nbr, bias, act, xb, return_workspace=True)
         ctx.save_for_backward(xa, xb, kernel, a_self, a_nbr, out, hx, s_self, s_nbr)
         ctx.act, ctx.handle, ctx.precision, ctx.has_bias = act, handle, precision, bias is not None
         return out
@@ -175,17 +190,19 @@ class GatFn(torch.autograd.Function):
         ht, perm = ctx.handle.transposed(g.device)
         d_hx, ds_self, ds_nbr = _lib.gat_backward(ctx.handle, ht, perm, g, hx, s_self, s_nbr, a_self.reshape(-1).contiguous(),
                                                   a_nbr.reshape(-1).contiguous())
-        hx2, dh2 = hx.reshape(-1, d), d_hx.reshape(-1, d)
         fa = xa.shape[-1]
         w2 = kernel.reshape(-1, d)
         dxa = dxb = dk = das = dan = db = None
-        if ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1]):
-            dz = rows_matmul(d_hx, w2.t(), ctx.precision)
-            dxa = dz[..., :fa] if ctx.needs_input_grad[0] else None
-            dxb = dz[..., fa:] if xb is not None and ctx.needs_input_grad[1] else None
+        # d[xa | xb] = d_hx W^T, each piece straight into its own tensor (no concatenated intermediate)
+        if ctx.needs_input_grad[0]:
+            dxa = rows_matmul(d_hx, w2[:fa].t(), ctx.precision)
+        if xb is not None and ctx.needs_input_grad[1]:
+            dxb = rows_matmul(d_hx, w2[fa:].t(), ctx.precision)
         if ctx.needs_input_grad[2]:
-            z = xa if xb is None else torch.cat([xa, xb], dim=-1)
-            dk = weight_grad(z, d_hx, ctx.precision, False)[0].reshape(kernel.shape)
+            dk = weight_grad(xa, d_hx, ctx.precision, False)[0]
+            if xb is not None:
+                dk = torch.cat([dk, weight_grad(xb, d_hx, ctx.precision, False)[0]], dim=0)
+            dk = dk.reshape(kernel.shape)
         if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
             # d a_self = sum_r ds_self[r] hx[r, :], d a_nbr likewise: one (rows, 2)^T (rows, d) reduction
             da = weight_grad(torch.stack([ds_self, ds_nbr], dim=-1), hx, ctx.precision, False)[0]
