@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libuds_hip.so')
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
 PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 3
+#define UDS_ABI_VERSION 4
 
 enum {
   UDS_OK = 0,
