@@ -14,5 +14,6 @@ from .layers import (Dense, GATConv, GCNConv, MixedGAT, NodeEdge,     # noqa: F4
 from .emulator import Conv1D, Emulator                                # noqa: F401,E402
 from . import inp                                                     # noqa: F401,E402
 from .agent import ConvNet, GlobalAttnSumPool                         # noqa: F401,E402
+from . import mpc                                                     # noqa: F401,E402
 
 __version__ = '0.1.0'

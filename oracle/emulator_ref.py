@@ -403,3 +403,42 @@ def convnet_forward(args, params, X, E, B=None):
     z = torch.cat([x, e], dim=-2)
     alpha = torch.softmax((z @ params['pool']['attn_kernel']).squeeze(-1), dim=-1)
     return (alpha.unsqueeze(-2) @ z).squeeze(-2)
+
+
+def mpc_objective(args, params, norms, y, state, runoff, edge_state, n_step, n_act, r_step, targets, gamma=None):
+    """Objective of `mpc_problem_gr.objective_fn` (mpc.py:551-598) with the astlingen objective (astlingen.py:75-99) for a
+    population y (pop, n_step*n_act): settings held r_step steps, predict chunk by chunk, weighted flooding + treatment-plant
+    inflow + inflow roughness, summed over the horizon."""
+    c = config(args)
+    pop = y.shape[0]
+    s = y.reshape(-1, n_step, n_act).repeat_interleave(r_step, dim=1)
+    T = runoff.shape[0]
+    if s.shape[1] < T:
+        s = torch.cat([s, s[:, -1:].expand(-1, T - s.shape[1], -1)], dim=1)
+    s = s[:, :T]
+    rep = lambda t: t.unsqueeze(0).expand((pop,) + tuple(t.shape))
+    st0, ro, es = rep(state), rep(runoff), rep(edge_state)
+    n_chunk = T // c.seq_out
+    if n_chunk <= 1:
+        preds, _ = predict(args, params, norms, st0, ro, s, es)
+    else:
+        st, ed, ys, perf = st0[:, -c.seq_in:], es[:, -c.seq_in:], [], None
+        for i in range(n_chunk):
+            sl = slice(i * c.seq_out, (i + 1) * c.seq_out)
+            if c.if_flood and i > 0:
+                st = torch.cat([st[..., :-1], (perf > 0).to(y.dtype), st[..., -1:]], dim=-1)
+            yy, ey = predict(args, params, norms, st, ro[:, sl], s[:, sl], ed)
+            st, perf = torch.cat([yy[..., :-2], ro[:, sl]], dim=-1), yy[..., -1:]
+            ed = torch.cat([ey, get_edge_action(c, s[:, sl])], dim=-1)
+            ys.append(yy)
+        preds = torch.cat(ys, dim=1)
+    q_w = preds[..., -1]
+    q_in = torch.cat([st0[:, -1:, :, 1], preds[..., 1]], dim=1)
+    obj = (q_w[..., targets['flood_idx']] * targets['flood_w']).sum(-1)
+    if targets.get('outflow_idx') is not None:
+        obj = obj + (q_in[:, 1:, targets['outflow_idx']] * targets['outflow_w']).sum(-1)
+    if targets.get('smooth_idx') is not None:
+        obj = obj + ((q_in[:, 1:, targets['smooth_idx']] - q_in[:, :-1, targets['smooth_idx']]).abs() * targets['smooth_w']).sum(-1)
+    if gamma is not None:
+        obj = obj * gamma
+    return obj.sum(-1)

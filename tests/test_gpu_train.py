@@ -292,3 +292,42 @@ def test_training_uses_no_cpu_fallback(dev, networks):
     with pytest.raises(_lib.UdsError):
         emul.forward(cpu_in[0].float().requires_grad_(True), cpu_in[2].float(), cpu_in[4].float(),
                      torch.ones(2, 5, emul.n_edge, 1))
+
+
+@pytest.mark.parametrize('chunks', [1, 2])
+def test_mpc_objective_and_gradient(dev, networks, chunks):
+    """`gnn_uds_amd.mpc` (mpc.py:551-612 + astlingen.py:75-99): objective of a population of control sequences and its
+    gradient with respect to the decision vector, one and two prediction chunks; against autograd over the fp64 oracle.
+    Tolerances: objective 5e-4 relative, gradient 1e-2 * max|grad| (reverse mode through ~10 split-bf16 layers and the
+    de-normalised post-processing; hard gates keep their oracle value on this input)."""
+    from gnn_uds_amd import mpc as M
+    net = networks['astlingen']
+    edges, n = np.array(net['edges']), net['n_node']
+    args = emulator_args(edges, n, seq_in=4, seq_out=2, n_sp_layer=1, if_flood=1, epsilon=0.0)
+    norms = emulator_norms(args)
+    params = OE.init_params(args, seed=3)
+    c = OE.config(args)
+    g = torch.Generator().manual_seed(11)
+    T = c.seq_out * chunks
+    state, runoff, edge_state = rnd(g, c.seq_in, n, 5), rnd(g, T, n, 1) * 0.05, rnd(g, c.seq_in, len(edges), 4)
+    state[..., 3] = (state[..., 3] > 0.8).double()
+    pop, n_step, n_act, r_step = 3, chunks, len(args.act_edges), 2
+    y = 0.2 + 0.6 * rnd(g, pop, n_step * n_act)
+    tg = dict(flood_idx=torch.tensor([3, 7, 11]), flood_w=torch.tensor([1.0, 2.0, 0.5], dtype=torch.float64),
+              outflow_idx=torch.tensor([0]), outflow_w=torch.tensor([0.3], dtype=torch.float64),
+              smooth_idx=torch.tensor([5, 9]), smooth_w=torch.tensor([0.7, 0.2], dtype=torch.float64))
+    gamma = torch.tensor([1.0, 0.9, 0.8, 0.7][:T], dtype=torch.float64)
+    yr = y.clone().requires_grad_(True)
+    ref = OE.mpc_objective(args, params, norms, yr, state, runoff, edge_state, n_step, n_act, r_step, tg, gamma)
+    (gref,) = torch.autograd.grad(ref.sum(), yr)
+    emul = load_emulator(U.Emulator(args.conv, args.resnet, args.recurrent, args), params, dev)
+    emul.set_norm(*(norms[k].numpy() for k in 'xbyre'))
+    f = lambda t: t.float().to(dev)
+    tgd = {k: (v.to(dev) if v.dtype == torch.int64 else f(v)) for k, v in tg.items()}
+    obj, grad = M.objective_and_gradient(emul, f(y), f(state), f(runoff), f(edge_state), n_step, n_act, r_step, tgd, f(gamma))
+    assert tuple(obj.shape) == (pop,) and tuple(grad.shape) == tuple(y.shape)
+    close(obj, ref.detach(), 5e-4)
+    gmax = float(gref.abs().max())
+    assert gmax > 0
+    err = float((grad.double().cpu() - gref).abs().max())
+    assert err <= 1e-2 * gmax, 'gradient err %.3e vs max|grad| %.3e' % (err, gmax)
