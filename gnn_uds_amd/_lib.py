@@ -307,10 +307,10 @@ def conv1d_causal(x, kernel, bias=None, dilation=1, act='linear'):
 
 def rowgemm_supported(k_total, f_in, f_out):
     """Shapes the matrix-core row GEMM takes: input width a multiple of 32, at most 64 outputs, and the packed weights
-    (K/32 * ceil(f_out/16) * 2 KiB) next to at least 48 KiB of per-wave DMA rings and the store tiles inside the 160 KiB LDS."""
+    (K/32 * ceil(f_out/16) * 2 KiB) next to at least 32 KiB of per-wave DMA rings and the store tiles inside the 160 KiB LDS."""
     mb = 1 if f_out <= 16 else 2 if f_out <= 32 else 4
     return (f_in % 32 == 0 and k_total % 32 == 0 and 0 < f_out <= 64
-            and (k_total // 32) * mb * 2048 + 256 + 8 * 3 * 2048 + 8 * 16 * (36 if mb >= 2 else 20) * 4 <= 160 * 1024)
+            and (k_total // 32) * mb * 2048 + 256 + 8 * 2 * 2048 + 8 * 16 * (36 if mb >= 2 else 20) * 4 <= 160 * 1024)
 
 
 def rowgemm_pack(kernel2d):

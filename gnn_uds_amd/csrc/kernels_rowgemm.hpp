@@ -260,10 +260,11 @@ inline int64_t rowgemm_lds_bytes(int K, int MB, int ring) {
   const int cg = MB >= 2 ? 2 : 1;
   return (int64_t)(K / 32) * MB * 2 * 1024 + 256 + 8 * ring * 2048 + 8 * 16 * (16 * cg + 4) * 4;
 }
-// deepest ring (5, else 3) that fits the LDS next to the weights; 0 = the weights alone are too large
+// deepest ring (5, 3, else 2) that fits the LDS next to the weights; 0 = the weights alone are too large
 inline int rowgemm_ring(int K, int MB) {
   if (rowgemm_lds_bytes(K, MB, 5) <= 160 * 1024) return 5;
   if (rowgemm_lds_bytes(K, MB, 3) <= 160 * 1024) return 3;
+  if (rowgemm_lds_bytes(K, MB, 2) <= 160 * 1024) return 2;
   return 0;
 }
 
@@ -291,7 +292,10 @@ inline hipError_t launch_rowgemm_r(const RowGemmArgs &a, hipStream_t st) {
 
 template <int MB, int NB>
 inline hipError_t launch_rowgemm_t(const RowGemmArgs &a, hipStream_t st) {
-  return rowgemm_ring(a.taps * a.F, MB) == 5 ? launch_rowgemm_r<MB, NB, 5>(a, st) : launch_rowgemm_r<MB, NB, 3>(a, st);
+  const int ring = rowgemm_ring(a.taps * a.F, MB);
+  if (ring == 5) return launch_rowgemm_r<MB, NB, 5>(a, st);
+  if (ring == 3) return launch_rowgemm_r<MB, NB, 3>(a, st);
+  return launch_rowgemm_r<MB, NB, 2>(a, st);      // e.g. the 3 x 128 -> 64 Conv1D of a d = 128 emulator: 96 KB of weights
 }
 
 inline int rowgemm_mb(int fo) { return fo <= 16 ? 1 : (fo <= 32 ? 2 : 4); }

@@ -95,6 +95,18 @@ class Dense(nn.Module):
         fi = xc.shape[-1]
         if self.precision == 'bf16x3' and _lib.rowgemm_supported(fi, fi, self.units):
             return _lib.rowgemm_forward(xc, _packed_kernel(self, self.kernel), self.bias, self.units, act)
+        if self.precision == 'bf16x3' and self.units > 64 and self.units % 16 == 0 and _lib.rowgemm_supported(fi, fi, 64) and \
+                xc.numel() // fi >= 4096:
+            # wide outputs (d = 128): 64-column blocks of the kernel, each written into its columns of one output
+            key = (self.kernel._version, self.kernel.data_ptr(), None if self.bias is None else self.bias._version)
+            if getattr(self, '_blocks', None) is None or self._blocks[0] != key:
+                self._blocks = (key, [(c0, min(64, self.units - c0), _lib.rowgemm_pack(self.kernel[:, c0:c0 + 64].contiguous()),
+                                       None if self.bias is None else self.bias[c0:c0 + 64].contiguous())
+                                      for c0 in range(0, self.units, 64)])
+            out = torch.empty(xc.shape[:-1] + (self.units,), device=xc.device, dtype=torch.float32)
+            for c0, w, pk, bb in self._blocks[1]:
+                _lib.rowgemm_cat(xc, None, pk, bb, w, act, out=out, col0=c0)
+            return out
         return _lib.dense_act(xc, self.kernel, self.bias, act)
 
 

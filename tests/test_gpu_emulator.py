@@ -49,7 +49,9 @@ def test_conv1d_causal(dev, B, T, R, F, H, dil, act):
                                                     # time-streaming Conv1D (taps 3, 64 -> 64, >= 256 sixteen-row streams): every dilation,
                                                     # T not a multiple of the 2D+1 ring, several time segments, a ragged last block
                                                     (1, 13, 4100, 64, 64, 3, 1, 'relu'), (1, 29, 4100, 64, 64, 3, 4, 'tanh'), (2, 60, 2050, 64, 64, 3, 2, 'relu'),
-                                                    (1, 60, 4099, 64, 64, 3, 4, 'linear'), (1, 2, 4096, 64, 64, 3, 4, 'relu')])
+                                                    (1, 60, 4099, 64, 64, 3, 4, 'linear'), (1, 2, 4096, 64, 64, 3, 4, 'relu'),
+                                                    # 3 x 128 -> 64 (first temporal layer of a d = 128 emulator): 96 KB of weights, ring of 2
+                                                    (1, 7, 700, 128, 64, 3, 2, 'relu'), (2, 5, 33, 128, 32, 3, 1, 'tanh')])
 def test_rowgemm_mfma_dense_and_conv(dev, B, T, R, F, H, taps, dil, act):
     """Matrix-core Dense / causal Conv1D (split-bf16, 3 products): tolerance 2e-4 * max(1, max|ref|)."""
     g = torch.Generator().manual_seed(T + R)
@@ -262,6 +264,28 @@ def test_rl_convnet_encoder(dev, networks, graph_base, use_pred):
     out = m(f32(X), f32(E), f32(Bd) if use_pred else None)
     assert tuple(out.shape) == (Bn, 64)
     close(out, ref, 5e-4)
+
+
+def test_emulator_at_the_reference_default_sizes(dev, networks):
+    """embed_size 128, hidden_dim 64, n_sp_layer 2, n_tp_layer 2, seq_in 6, seq_out 1 (utils/config.yaml): the d = 128 fused
+    kernel (block 1, later layers of block 2), the 64-column-block row GEMM for 128-wide Dense outputs, the 3 x 128 -> 64
+    Conv1D.  Whole-forward tolerance 5e-4 * max(1, max|ref|) as for d = 64; a batch large enough (rows >= 4096) to take
+    the matrix-core paths."""
+    net = networks['RedChicoSur']
+    edges, n = np.array(net['edges']), net['n_node']
+    args = emulator_args(edges, n, embed_size=128, hidden_dim=64, n_sp_layer=2, n_tp_layer=2, seq_in=6, seq_out=1)
+    params = OE.init_params(args, seed=8)
+    c = OE.config(args)
+    g = torch.Generator().manual_seed(3)
+    Bn = 12
+    X, Bd, Ex = rnd(g, Bn, c.seq_in, n, c.n_in), rnd(g, Bn, c.seq_out, n, c.b_in), rnd(g, Bn, c.seq_in, len(edges), c.e_in)
+    AE = rnd(g, Bn, c.seq_out, len(edges), 1)
+    ry, re = OE.forward(args, params, X, Bd, Ex, AE)
+    f = lambda t: t.float().to(dev)
+    emul = load_emulator(U.Emulator(args.conv, args.resnet, args.recurrent, args), params, dev)
+    y, ey = emul(f(X), f(Bd), f(Ex), f(AE))
+    close(y, ry, 5e-4); close(ey, re, 5e-4)
+    assert emul.block1.layers[0].network().plan_info()['fused'] & 8
 
 
 def test_graph_captured_rollout_equals_the_eager_loop(dev, networks):

@@ -233,6 +233,48 @@ def test_wide_layer_d128_matrix_core_unfused_path(dev):
         _lib.gat_aggregate(_lib.CsrHandle(gph.adj), hx, ss[:, :5].contiguous(), sn)
 
 
+def test_dense_wide_outputs_column_blocks(dev):
+    """Dense 64 -> 128 / 96 -> 80 with precision='bf16x3': 64-column blocks of the kernel through uds_rowgemm_forward_cat."""
+    g = torch.Generator().manual_seed(2)
+    for fi, fo, act in ((64, 128, 'relu'), (96, 80, 'tanh')):
+        x, k, b = rnd(g, 3, 1500, fi) - 0.5, rnd(g, fi, fo) - 0.5, rnd(g, fo) - 0.5
+        m = U.Dense(fo, act, in_features=fi, precision='bf16x3').to(dev)
+        m.kernel.data, m.bias.data = k.float().to(dev), b.float().to(dev)
+        close(m(x.float().to(dev)), OD.dense(x, k, b, act), TOL_BF16X3)
+
+
+@pytest.mark.parametrize('case', ['hub', 'astlingen', 'chaohu', 'tanh', 'c3'])
+def test_fused_d128_kernel_cases(dev, networks, case):
+    """k_fused128 (d = 128, h = 64): rows with more than 16 neighbours (the per-lane walk), small real networks (a single
+    tile, ragged blocks, isolated nodes / parallel links), a run-time activation, and a 50k-node network (many tiles,
+    several snapshot chunks); run twice: bitwise identical (the per-wave score partials are added in a fixed order)."""
+    d, S, act = 128, 3, 'relu'
+    if case == 'hub':
+        edges = np.array([[0, i] for i in range(1, 31)] + [[i, i + 1] for i in range(30, 45)])
+        n = 46
+    elif case == 'c3':
+        n, S = 50000, 2
+        edges = U.synthetic_drainage_network(n, 65000, 0)
+    else:
+        net = networks['astlingen' if case == 'tanh' else case]
+        edges, n = np.array(net['edges']), net['n_node']
+        act = 'tanh' if case == 'tanh' else 'relu'
+    gph = U.DrainageGraph.from_edges(edges, n)
+    p = spatial_params(gph.n_node, gph.n_edge, d, d, d, seed=3, dense_ne=False, nnz_n=gph.inc_n.nnz, nnz_e=gph.inc_e.nnz)
+    g = torch.Generator().manual_seed(4)
+    x, e = rnd(g, S, gph.n_node, d), rnd(g, S, gph.n_edge, d)
+    rx, re = OS.spatial_layer_csr(x.float() if case == 'c3' else x, e.float() if case == 'c3' else e, cast(p, torch.float32) if case == 'c3' else p,
+                                  (gph.adj.rowptr, gph.adj.col), (gph.edge_adj.rowptr, gph.edge_adj.col),
+                                  (gph.inc_n.rowptr, gph.inc_n.col), (gph.inc_e.rowptr, gph.inc_e.col), act=act)
+    layer = load_spatial_layer(U.SpatialLayer(gph, d, act, sparse_params=True, precision='bf16x3'), p, dev)
+    ox, oe = layer(x.float().to(dev), e.float().to(dev))
+    assert layer.network().plan_info()['fused'] & 8             # the d = 128 tile plan exists: the fused kernel ran
+    tol = 4e-4 if case == 'c3' else TOL_BF16X3                  # c3: fp32 oracle (the fp64 one needs minutes at this size)
+    close(ox, rx.double(), tol); close(oe, re.double(), tol)
+    ox2, oe2 = layer(x.float().to(dev), e.float().to(dev))
+    assert torch.equal(ox, ox2) and torch.equal(oe, oe2)
+
+
 def test_split_input_needs_the_fused_kernel(dev):
     gph = U.DrainageGraph.from_edges(U.synthetic_drainage_network(300, 360, 0))
     layer = U.SpatialLayer(gph, 64, 'relu', fx=96, sparse_params=True, generator=torch.Generator().manual_seed(1)).to(dev)
