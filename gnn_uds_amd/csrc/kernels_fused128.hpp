@@ -2,9 +2,9 @@
 // utils/config.yaml) as ONE launch -- the same tile / snapshot-chunk / LDS-DMA scheme as k_fused_tile (kernels_fused.hpp),
 // re-organised because at d = 128 the weight fragments (128 + 384 VGPRs per lane) fit no wave:
 //
-//   * the GEMMs are split by OUTPUT COLUMNS across the 8 waves: wave w owns 16 of the 128 columns of hx (6 k-steps x
-//     hi/lo = 48 VGPRs of weights) and, in the fusion MLP, 16 of its 64 columns (4 k-steps = 32 VGPRs): weights stay
-//     register-resident, read once per workgroup;
+//   * the GEMMs are split by OUTPUT COLUMNS (and row-block parity) across the 8 waves: a wave owns 32 of the 128 columns
+//     of hx (6 k-steps x 2 x hi/lo = 96 VGPRs of weights) and, in the fusion MLP, 16 of its 64 columns (4 k-steps = 32
+//     VGPRs), each for every second row block: weights stay register-resident, read once per workgroup;
 //   * every wave therefore needs EVERY row block's operand fragments: the wave that DMA'd a block splits it once into
 //     bf16 hi / lo fragments IN PLACE in the stage (phase P0), all waves read the shared fragments;
 //   * phases per snapshot:  P0 split | P1 fusion MLP (columns x row-block parity) | P1.5 NodeEdge aggregation -> fragments |
@@ -122,19 +122,22 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
     bo[0] = *reinterpret_cast<const f32x4 *>(S_.b_out + 4 * c16);
     bo[1] = *reinterpret_cast<const f32x4 *>(S_.b_out + 64 + 4 * c16);
   }
-  // this wave's weight columns: fusion MLP slice wave & 3, hx slice wave
+  // this wave's weight columns: fusion MLP slice wave & 3 (16 columns), hx slices 2 (wave & 3) and 2 (wave & 3) + 1 (32
+  // columns) -- both for the row blocks of parity wave >> 2: a fragment read from LDS then feeds two column blocks
   const int cs = wave & 3, par = wave >> 2;
-  bf16x8 wsh[KT_S], wsl[KT_S], wbh[KT_B], wbl[KT_B];
+  bf16x8 wsh[KT_S], wsl[KT_S], wbh[KT_B][2], wbl[KT_B][2];
 #pragma unroll
   for (int t = 0; t < KT_S; ++t) {
     wsh[t] = __builtin_bit_cast(bf16x8, S_.w_small[((t * MB_S + cs) * 2 + 0) * 64 + lane]);
     wsl[t] = __builtin_bit_cast(bf16x8, S_.w_small[((t * MB_S + cs) * 2 + 1) * 64 + lane]);
   }
 #pragma unroll
-  for (int t = 0; t < KT_B; ++t) {
-    wbh[t] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + wave) * 2 + 0) * 64 + lane]);
-    wbl[t] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + wave) * 2 + 1) * 64 + lane]);
-  }
+  for (int t = 0; t < KT_B; ++t)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      wbh[t][m] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + 2 * cs + m) * 2 + 0) * 64 + lane]);
+      wbl[t][m] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + 2 * cs + m) * 2 + 1) * 64 + lane]);
+    }
   __syncthreads();
   int n_st = 0;
 
@@ -196,35 +199,48 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
       dst[64] = __builtin_bit_cast(float4, lo);
     }
     lds_barrier();
-    // ---------------- P2: hx columns [16 wave, 16 wave + 16) of every primary block + partial attention scores ----------------
+    // ---------------- P2: hx columns [32 cs, 32 cs + 32) of the primary blocks of this wave's parity + partial scores ----------------
     {
-      const f32x4 as4 = *reinterpret_cast<const f32x4 *>(attn + 16 * wave + 4 * qd);
-      const f32x4 an4 = *reinterpret_cast<const f32x4 *>(attn + F128_D + 16 * wave + 4 * qd);
-      for (int blk = 0; blk < nb_prim; ++blk) {
+      f32x4 as4[2], an4[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        as4[m] = *reinterpret_cast<const f32x4 *>(attn + 16 * (2 * cs + m) + 4 * qd);
+        an4[m] = *reinterpret_cast<const f32x4 *>(attn + F128_D + 16 * (2 * cs + m) + 4 * qd);
+      }
+      for (int blk = par; blk < nb_prim; blk += 2) {
         const float4 *st = reinterpret_cast<const float4 *>(stage_p + blk * (8 * 256)) + lane;
         const float4 *ag = reinterpret_cast<const float4 *>(aggf + blk * 1024) + lane;
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int t = 0; t < KT_X; ++t)
-          acc = mfma3(wbh[t], wbl[t], __builtin_bit_cast(bf16x8, st[(2 * t) * 64]), __builtin_bit_cast(bf16x8, st[(2 * t + 1) * 64]), acc);
+        for (int t = 0; t < KT_X; ++t) {
+          const bf16x8 dh = __builtin_bit_cast(bf16x8, st[(2 * t) * 64]), dl = __builtin_bit_cast(bf16x8, st[(2 * t + 1) * 64]);
 #pragma unroll
-        for (int t = 0; t < KT_A; ++t)
-          acc = mfma3(wbh[KT_X + t], wbl[KT_X + t], __builtin_bit_cast(bf16x8, ag[t * 128]), __builtin_bit_cast(bf16x8, ag[t * 128 + 64]), acc);
-        float ps = 0.f, pn = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          ps = fmaf(acc[j], as4[j], ps);
-          pn = fmaf(acc[j], an4[j], pn);
+          for (int m = 0; m < 2; ++m) acc[m] = mfma3(wbh[t][m], wbl[t][m], dh, dl, acc[m]);
         }
-        ps = quarters_sum(ps);
-        pn = quarters_sum(pn);
+#pragma unroll
+        for (int t = 0; t < KT_A; ++t) {
+          const bf16x8 dh = __builtin_bit_cast(bf16x8, ag[t * 128]), dl = __builtin_bit_cast(bf16x8, ag[t * 128 + 64]);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[m] = mfma3(wbh[KT_X + t][m], wbl[KT_X + t][m], dh, dl, acc[m]);
+        }
         const int lrow = blk * 16 + r16;
-        if (lrow < n_prim) {
-          if (qd == 0) {
-            sp_self[lrow * 8 + wave] = ps;
-            sp_nbr[lrow * 8 + wave] = pn;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          float ps = 0.f, pn = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            ps = fmaf(acc[m][j], as4[m][j], ps);
+            pn = fmaf(acc[m][j], an4[m][j], pn);
           }
-          *reinterpret_cast<f32x4 *>(hx + lrow * F128_D + (((4 * wave + qd) ^ (lrow & 7)) << 2)) = acc;
+          ps = quarters_sum(ps);
+          pn = quarters_sum(pn);
+          if (lrow < n_prim) {
+            if (qd == 0) {
+              sp_self[lrow * 8 + 2 * cs + m] = ps;
+              sp_nbr[lrow * 8 + 2 * cs + m] = pn;
+            }
+            *reinterpret_cast<f32x4 *>(hx + lrow * F128_D + (((4 * (2 * cs + m) + qd) ^ (lrow & 7)) << 2)) = acc[m];
+          }
         }
       }
     }
