@@ -38,6 +38,12 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
   constexpr int KT_S = F128_F / 32, KT_X = F128_F / 32, KT_A = F128_H / 32, KT_B = KT_X + KT_A;     // 4, 4, 2, 6
   constexpr int MB_S = F128_H / 16, MB_B = F128_D / 16;                                              // 4, 8
   extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+#ifdef UDS_PHASE_TIMING
+  unsigned long long tq_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_ = clock64();
+#define UDS_STAMP128(k) do { const unsigned long long n_ = clock64(); tq_[k] += n_ - tp_; tp_ = n_; } while (0)
+#else
+#define UDS_STAMP128(k) do { } while (0)
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, qd = lane >> 4;
@@ -140,9 +146,11 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
     }
   __syncthreads();
   int n_st = 0;
+  UDS_STAMP128(0);
 
   for (int s = s_begin; s < s_end; ++s) {
     wait_all_but(n_st);       // this wave's DMA pieces of snapshot s have landed (the P3 stores are younger)
+    UDS_STAMP128(1);
     // ---------------- P0: raw fp32 rows -> bf16 hi / lo fragments, in place, by the wave that fetched them ----------------
     auto split_block = [&](float *stage, int blk) {
       float4 *st = reinterpret_cast<float4 *>(stage + blk * (8 * 256)) + lane;
@@ -157,18 +165,31 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
         st[(2 * t + 1) * 64] = __builtin_bit_cast(float4, lo);
       }
     };
+#ifndef UDS_F128_NOP0
     for (int blk = 0; blk < nb_sec; ++blk)
       if (sec_owner(blk) == wave) split_block(stage_s, blk);
     for (int blk = 0; blk < nb_prim; ++blk)
       if (prim_owner(blk) == wave) split_block(stage_p, blk);
+#else
+    (void)split_block;
+#endif
+    UDS_STAMP128(2);
     lds_barrier();
+    UDS_STAMP128(3);
     // ---------------- P1: fusion MLP, 16 columns (cs) x the row blocks of this wave's parity -> sec ----------------
     for (int blk = par; blk < nb_sec; blk += 2) {
       const float4 *st = reinterpret_cast<const float4 *>(stage_s + blk * (8 * 256)) + lane;
       f32x4 acc = *reinterpret_cast<const f32x4 *>(attn + 2 * F128_D + 16 * cs + 4 * qd);
 #pragma unroll
-      for (int t = 0; t < KT_S; ++t)
+      for (int t = 0; t < KT_S; ++t) {
+#ifndef UDS_F128_NOP0
         acc = mfma3(wsh[t], wsl[t], __builtin_bit_cast(bf16x8, st[(2 * t) * 64]), __builtin_bit_cast(bf16x8, st[(2 * t + 1) * 64]), acc);
+#else
+        bf16x8 dh, dl;
+        split8(st[(2 * t) * 64], st[(2 * t + 1) * 64], dh, dl);
+        acc = mfma3(wsh[t], wsl[t], dh, dl, acc);
+#endif
+      }
       const int lrow = blk * 16 + r16;
       if (lrow < n_sec) {
         f32x4 o;
@@ -177,7 +198,9 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
         *reinterpret_cast<f32x4 *>(sec + lrow * F128_SEC_STRIDE + 16 * cs + 4 * qd) = o;
       }
     }
+    UDS_STAMP128(4);
     lds_barrier();
+    UDS_STAMP128(5);
     if (s + 1 < s_end) dma_sec_all(s + 1);        // the secondary fragments are consumed: fetch the next snapshot's rows
     // ---------------- P1.5: NodeEdge aggregation of the primary rows -> fragments (block wave/2, k-step wave&1) ----------------
     for (int unit = wave; unit < 2 * nb_prim; unit += NW) {
@@ -198,7 +221,9 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
       dst[0] = __builtin_bit_cast(float4, hi);
       dst[64] = __builtin_bit_cast(float4, lo);
     }
+    UDS_STAMP128(6);
     lds_barrier();
+    UDS_STAMP128(7);
     // ---------------- P2: hx columns [32 cs, 32 cs + 32) of the primary blocks of this wave's parity + partial scores ----------------
     {
       f32x4 as4[2], an4[2];
@@ -213,7 +238,12 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int t = 0; t < KT_X; ++t) {
+#ifndef UDS_F128_NOP0
           const bf16x8 dh = __builtin_bit_cast(bf16x8, st[(2 * t) * 64]), dl = __builtin_bit_cast(bf16x8, st[(2 * t + 1) * 64]);
+#else
+          bf16x8 dh, dl;
+          split8(st[(2 * t) * 64], st[(2 * t + 1) * 64], dh, dl);
+#endif
 #pragma unroll
           for (int m = 0; m < 2; ++m) acc[m] = mfma3(wbh[t][m], wbl[t][m], dh, dl, acc[m]);
         }
@@ -244,7 +274,9 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
         }
       }
     }
+    UDS_STAMP128(8);
     lds_barrier();
+    UDS_STAMP128(9);
     if (s + 1 < s_end) dma_prim_all(s + 1);       // the primary fragments are consumed
     // ---------------- P3: segmented softmax + neighbour sum -> HBM (16 lanes x 2 float4 per output row) ----------------
     n_st = 0;
@@ -360,8 +392,17 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
         }
       }
     }
+    UDS_STAMP128(10);
     // no barrier here: the next P0 touches only this wave's own stage blocks, whose readers all passed the barriers above
   }
+#ifdef UDS_PHASE_TIMING
+  if (a.dbg && lane == 0) {
+    unsigned long long *o = a.dbg + ((size_t)blockIdx.x * NW + wave) * 16;
+    for (int k = 0; k < 11; ++k) o[k] = tq_[k];
+    o[12] = wave;
+    o[13] = 1ull | ((unsigned long long)sd << 8) | ((unsigned long long)n_own << 16) | ((unsigned long long)n_prim << 32) | ((unsigned long long)n_sec << 48);
+  }
+#endif
 }
 
 }  // namespace uds

@@ -766,6 +766,9 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
     a.S = (int)S;
     a.act = act;
     a.dbg = nullptr;
+#ifdef UDS_PHASE_TIMING
+    a.dbg = reinterpret_cast<unsigned long long *>(ws + PACKED_WEIGHT_FLOATS);
+#endif
     a.side_mask = 3;
     int64_t chunk = S, best = INT64_MAX;
     for (int64_t c = 1; c <= S; ++c) {
