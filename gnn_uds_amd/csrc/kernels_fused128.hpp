@@ -27,15 +27,18 @@ constexpr int F128_U = 2;                       // P3 row groups per wave
 constexpr int F128_SEC_STRIDE = F128_H + 4;     // floats: 272-B rows, conflict-free 16-B fragment writes
 
 // LDS bytes of k_fused128 for the caps of a plan (mirrors the layout in the kernel)
-inline int64_t fused128_lds_bytes(int p_cap, int q_cap, int meta_cap) {
+inline int64_t fused128_lds_bytes(int p_cap, int q_cap, int meta_cap, int fp = F128_F, int fs = F128_F) {
   return 4 * ((int64_t)meta_cap + 2 * 8 * p_cap + (2 * F128_D + F128_H) + (int64_t)q_cap * F128_SEC_STRIDE + (int64_t)p_cap * F128_H +
-              (int64_t)p_cap * F128_D + (int64_t)q_cap * F128_F + (int64_t)p_cap * F128_F);
+              (int64_t)p_cap * F128_D + (int64_t)q_cap * fs + (int64_t)p_cap * fp);
 }
 
-template <int ACT>
+// FP / FS: widths of the primary / secondary input rows, 128 or 64 (the first layer of block 2 without actions has 128-wide
+// node rows [temporal output | boundary embedding] and 64-wide link rows, emulator.py:260-262)
+template <int FP, int FS, int ACT>
 __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
+  static_assert((FP == 64 || FP == 128) && (FS == 64 || FS == 128), "row widths 64 or 128");
   constexpr int NW = FUSED_WAVES, NT = FUSED_WAVES * 64, U = F128_U;
-  constexpr int KT_S = F128_F / 32, KT_X = F128_F / 32, KT_A = F128_H / 32, KT_B = KT_X + KT_A;     // 4, 4, 2, 6
+  constexpr int KT_S = FS / 32, KT_X = FP / 32, KT_A = F128_H / 32, KT_B = KT_X + KT_A;     // 4|2, 4|2, 2, 6|4
   constexpr int MB_S = F128_H / 16, MB_B = F128_D / 16;                                              // 4, 8
   extern __shared__ __attribute__((aligned(16))) int32_t smem[];
 #ifdef UDS_PHASE_TIMING
@@ -64,8 +67,8 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
   float *sec = attn + 2 * F128_D + F128_H;                              // [q_cap][68]
   float *aggf = sec + a.q_cap * F128_SEC_STRIDE;                        // (p_cap/16) blocks x 2 k-steps x (hi 1 KiB | lo 1 KiB)
   float *hx = aggf + a.p_cap * F128_H;                                  // [p_cap][128], 16-B chunks XOR (row & 7)
-  float *stage_s = hx + a.p_cap * F128_D;                               // (q_cap/16) blocks x 4 k-steps x 2 x 1 KiB
-  float *stage_p = stage_s + a.q_cap * F128_F;                          // (p_cap/16) blocks x 4 k-steps x 2 x 1 KiB
+  float *stage_s = hx + a.p_cap * F128_D;                               // (q_cap/16) blocks x KT_S k-steps x 2 x 1 KiB
+  float *stage_p = stage_s + a.q_cap * FS;                              // (p_cap/16) blocks x KT_X k-steps x 2 x 1 KiB
 
   for (int i = tid; i < meta_len; i += NT) meta[i] = a.pool[pool_off + i];
   __syncthreads();
@@ -83,21 +86,26 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
   // block ownership (DMA issue, P0 split): secondary block b -> wave b % 8, primary block b -> wave 7 - b % 8
   auto sec_owner = [&](int blk) { return blk & 7; };
   auto prim_owner = [&](int blk) { return 7 - (blk & 7); };
-  auto dma_block = [&](const float *base, int row, float *stage, int blk) {       // 16 rows x 128 floats = 8 pieces of 1 KiB
-    const float *src = base + (int64_t)row * F128_F + 4 * qd;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(stage) + (unsigned)blk * (8 * 1024));
+  auto dma_block = [&](auto KT_, const float *base, int row, float *stage, int blk) {      // 16 rows x 32 KT floats = 2 KT pieces of 1 KiB
+    constexpr int KT = decltype(KT_)::value;
+    const float *src = base + (int64_t)row * (32 * KT) + 4 * qd;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(stage) + (unsigned)blk * (2 * KT * 1024));
     const float *p0[4] = {src, src + 16, src + 32, src + 48};
-    const float *p1[4] = {src + 64, src + 80, src + 96, src + 112};
     glds16_run<4>(p0, dst);
-    glds16_run<4>(p1, dst + 4096);
+    if constexpr (KT == 4) {
+      const float *p1[4] = {src + 64, src + 80, src + 96, src + 112};
+      glds16_run<4>(p1, dst + 4096);
+    }
   };
   auto dma_sec_all = [&](int s) {
     for (int blk = 0; blk < nb_sec; ++blk)
-      if (sec_owner(blk) == wave) dma_block(S_.sec_in + (int64_t)s * S_.n_sec_glob * F128_F, sec_ids[min(blk * 16 + r16, n_sec - 1)], stage_s, blk);
+      if (sec_owner(blk) == wave)
+        dma_block(std::integral_constant<int, KT_S>{}, S_.sec_in + (int64_t)s * S_.n_sec_glob * FS, sec_ids[min(blk * 16 + r16, n_sec - 1)], stage_s, blk);
   };
   auto dma_prim_all = [&](int s) {
     for (int blk = 0; blk < nb_prim; ++blk)
-      if (prim_owner(blk) == wave) dma_block(S_.prim_in + (int64_t)s * S_.n_prim_glob * F128_F, prim_ids[min(blk * 16 + r16, n_prim - 1)], stage_p, blk);
+      if (prim_owner(blk) == wave)
+        dma_block(std::integral_constant<int, KT_X>{}, S_.prim_in + (int64_t)s * S_.n_prim_glob * FP, prim_ids[min(blk * 16 + r16, n_prim - 1)], stage_p, blk);
   };
 
   int p3_dmax[U];
@@ -152,13 +160,14 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
     wait_all_but(n_st);       // this wave's DMA pieces of snapshot s have landed (the P3 stores are younger)
     UDS_STAMP128(1);
     // ---------------- P0: raw fp32 rows -> bf16 hi / lo fragments, in place, by the wave that fetched them ----------------
-    auto split_block = [&](float *stage, int blk) {
-      float4 *st = reinterpret_cast<float4 *>(stage + blk * (8 * 256)) + lane;
-      float4 v[8];
+    auto split_block = [&](auto KT_, float *stage, int blk) {
+      constexpr int KT = decltype(KT_)::value;
+      float4 *st = reinterpret_cast<float4 *>(stage + blk * (2 * KT * 256)) + lane;
+      float4 v[2 * KT];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = st[i * 64];
+      for (int i = 0; i < 2 * KT; ++i) v[i] = st[i * 64];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < KT; ++t) {
         bf16x8 hi, lo;
         split8(v[2 * t], v[2 * t + 1], hi, lo);
         st[(2 * t) * 64] = __builtin_bit_cast(float4, hi);
@@ -167,9 +176,9 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
     };
 #ifndef UDS_F128_NOP0
     for (int blk = 0; blk < nb_sec; ++blk)
-      if (sec_owner(blk) == wave) split_block(stage_s, blk);
+      if (sec_owner(blk) == wave) split_block(std::integral_constant<int, KT_S>{}, stage_s, blk);
     for (int blk = 0; blk < nb_prim; ++blk)
-      if (prim_owner(blk) == wave) split_block(stage_p, blk);
+      if (prim_owner(blk) == wave) split_block(std::integral_constant<int, KT_X>{}, stage_p, blk);
 #else
     (void)split_block;
 #endif
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
     UDS_STAMP128(3);
     // ---------------- P1: fusion MLP, 16 columns (cs) x the row blocks of this wave's parity -> sec ----------------
     for (int blk = par; blk < nb_sec; blk += 2) {
-      const float4 *st = reinterpret_cast<const float4 *>(stage_s + blk * (8 * 256)) + lane;
+      const float4 *st = reinterpret_cast<const float4 *>(stage_s + blk * (2 * KT_S * 256)) + lane;
       f32x4 acc = *reinterpret_cast<const f32x4 *>(attn + 2 * F128_D + 16 * cs + 4 * qd);
 #pragma unroll
       for (int t = 0; t < KT_S; ++t) {
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
         an4[m] = *reinterpret_cast<const f32x4 *>(attn + F128_D + 16 * (2 * cs + m) + 4 * qd);
       }
       for (int blk = par; blk < nb_prim; blk += 2) {
-        const float4 *st = reinterpret_cast<const float4 *>(stage_p + blk * (8 * 256)) + lane;
+        const float4 *st = reinterpret_cast<const float4 *>(stage_p + blk * (2 * KT_X * 256)) + lane;
         const float4 *ag = reinterpret_cast<const float4 *>(aggf + blk * 1024) + lane;
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll

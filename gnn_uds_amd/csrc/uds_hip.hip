@@ -79,7 +79,7 @@ struct uds_plan_slot {
 
 struct uds_network {
   const uds_csr *adj = nullptr, *edge_adj = nullptr, *inc_n = nullptr, *inc_e = nullptr;
-  uds_plan_slot slot[5];          // one per kernel variant <FP, FS>: [0] <64,64>, [1] <64,96>, [2] <96,64>, [3] <96,96>; [4] d = 128
+  uds_plan_slot slot[7];          // d = 64 variants <FP, FS>: [0] <64,64>, [1] <64,96>, [2] <96,64>, [3] <96,96>; d = 128: [4] <128,128>, [5] <128,64>, [6] <64,128>
 };
 
 namespace {
@@ -87,7 +87,10 @@ namespace {
 constexpr int64_t FUSED_LDS_BUDGET = 160 * 1024;   // one 8-wave workgroup per CU owns the whole 160 KiB LDS
 constexpr int64_t PACKED_WEIGHT_FLOATS = 2 * (2048 + 6144) * 4;   // both sides at d = 128 (128->64 and 192->128 kernels): uint4 = 4 floats
 
-inline int slot_index(int fp, int fs) { return fp == 128 ? 4 : (fp > 64 ? 2 : 0) + (fs > 64 ? 1 : 0); }
+inline int slot_index(int fp, int fs) {
+  if (fp == 128 || fs == 128) return fp == 128 ? (fs == 128 ? 4 : 5) : 6;      // the d = 128 kernel's variants
+  return (fp > 64 ? 2 : 0) + (fs > 64 ? 1 : 0);
+}
 
 // Tile plan for the kernel variant <fp, fs> (primary / secondary input rows of fp / fs floats: they set the size of the
 // DMA stage) under the LDS budget: fix the footprint limits (primary / secondary rows staged per tile, multiples of 16)
@@ -109,15 +112,15 @@ bool plan_network(const uds::HostCsr &adj, const uds::HostCsr &eadj, const uds::
 }
 
 // Tile plan of the d = 128 kernel (k_fused128): <= 64 own / primary rows, secondary rows as the LDS allows.
-bool plan_network128(const uds::HostCsr &adj, const uds::HostCsr &eadj, const uds::HostCsr &inc_n, const uds::HostCsr &inc_e,
+bool plan_network128(const uds::HostCsr &adj, const uds::HostCsr &eadj, const uds::HostCsr &inc_n, const uds::HostCsr &inc_e, int fp, int fs,
                      uds::NetworkPlan &out, int64_t &lds) {
-  const int cand[][2] = {{64, 96}, {64, 80}, {64, 64}, {48, 64}, {32, 48}, {16, 32}};
+  const int cand[][2] = {{64, 128}, {64, 112}, {64, 96}, {64, 80}, {64, 64}, {48, 64}, {32, 48}, {16, 32}};
   for (const auto &c : cand) {
     const int p_lim = c[0], q_lim = c[1];
-    if (uds::fused128_lds_bytes(p_lim, q_lim, 0) > FUSED_LDS_BUDGET) continue;
+    if (uds::fused128_lds_bytes(p_lim, q_lim, 0, fp, fs) > FUSED_LDS_BUDGET) continue;
     const int t = std::min(p_lim, 4 * uds::FUSED_WAVES * uds::F128_U);
     out = uds::build_network_plan(adj, eadj, inc_n, inc_e, t, t, p_lim, q_lim);
-    lds = uds::fused128_lds_bytes(out.p_cap, out.q_cap, out.meta_cap);
+    lds = uds::fused128_lds_bytes(out.p_cap, out.q_cap, out.meta_cap, fp, fs);
     if (lds <= FUSED_LDS_BUDGET && out.p_cap <= 4 * uds::FUSED_WAVES * uds::F128_U) return true;
   }
   return false;
@@ -127,22 +130,23 @@ bool plan_network128(const uds::HostCsr &adj, const uds::HostCsr &eadj, const ud
 
 namespace {
 
-template <int ACT>
+template <int FP, int FS, int ACT>
 hipError_t launch_fused128_act(const uds::FusedArgs &a, int grid, int64_t lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&uds::k_fused128<ACT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)FUSED_LDS_BUDGET);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&uds::k_fused128<FP, FS, ACT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BUDGET);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((uds::k_fused128<ACT>), dim3(grid), dim3(uds::FUSED_WAVES * 64), (size_t)lds, st, a);
+  hipLaunchKernelGGL((uds::k_fused128<FP, FS, ACT>), dim3(grid), dim3(uds::FUSED_WAVES * 64), (size_t)lds, st, a);
   return hipGetLastError();
 }
 
+template <int FP, int FS>
 hipError_t launch_fused128(const uds::FusedArgs &a, int grid, int64_t lds, hipStream_t st) {
-  if (a.act == UDS_ACT_RELU) return launch_fused128_act<UDS_ACT_RELU>(a, grid, lds, st);
-  return launch_fused128_act<-1>(a, grid, lds, st);
+  if (a.act == UDS_ACT_RELU) return launch_fused128_act<FP, FS, UDS_ACT_RELU>(a, grid, lds, st);
+  return launch_fused128_act<FP, FS, -1>(a, grid, lds, st);
 }
 
 template <int FP, int FS, int ACT>
@@ -540,7 +544,7 @@ static int build_slot(uds_network *n, int fp, int fs) {
   sl.built = true;
   sl.fp = fp;
   sl.fs = fs;
-  if (fp == 128 ? !plan_network128(n->adj->host, n->edge_adj->host, n->inc_n->host, n->inc_e->host, sl.plan, sl.lds_bytes)
+  if ((fp == 128 || fs == 128) ? !plan_network128(n->adj->host, n->edge_adj->host, n->inc_n->host, n->inc_e->host, fp, fs, sl.plan, sl.lds_bytes)
                 : !plan_network(n->adj->host, n->edge_adj->host, n->inc_n->host, n->inc_e->host, fp, fs, sl.plan, sl.lds_bytes))
     return UDS_OK;
   hipError_t e;
@@ -565,7 +569,11 @@ static int build_slot(uds_network *n, int fp, int fs) {
 int uds_network_prepare(uds_network_t *net, int64_t fx, int64_t fe) {
   UDS_REQUIRE(net != nullptr, "uds_network_prepare: NULL network");
   if (net->adj->n_rows == 0 || net->edge_adj->n_rows == 0) return UDS_OK;
-  if (fx == 128 && fe == 128) return build_slot(net, 128, 128);      // the d = 128 kernel
+  if (fx == 128 && (fe == 128 || fe == 64)) {      // the d = 128 kernel: node tiles <fx, fe>, link tiles <fe, fx>
+    int rc = build_slot(net, 128, (int)fe);
+    if (rc == UDS_OK && fe == 64) rc = build_slot(net, 64, 128);
+    return rc;
+  }
   if (!((fx == 64 || fx == 96) && (fe == 64 || fe == 96))) return UDS_OK;
   int rc = build_slot(net, (int)fx, (int)fe);            // node tiles run <fx, fe>
   if (rc == UDS_OK) rc = build_slot(net, (int)fe, (int)fx);   // link tiles <fe, fx>
@@ -616,7 +624,8 @@ int uds_network_destroy(uds_network_t *net) {
 int uds_network_plan_info(const uds_network_t *net, int32_t *info8) {
   UDS_REQUIRE(net && info8, "uds_network_plan_info: NULL argument");
   const uds_plan_slot &sl = net->slot[0];   // the plan for 64-float rows (d = 64 layers)
-  info8[0] = (sl.ok ? 1 : 0) | ((net->slot[1].ok && net->slot[2].ok) ? 2 : 0) | (net->slot[3].ok ? 4 : 0) | (net->slot[4].ok ? 8 : 0);
+  info8[0] = (sl.ok ? 1 : 0) | ((net->slot[1].ok && net->slot[2].ok) ? 2 : 0) | (net->slot[3].ok ? 4 : 0) | (net->slot[4].ok ? 8 : 0) |
+             ((net->slot[5].ok && net->slot[6].ok) ? 16 : 0);
   info8[1] = sl.plan.side[0].n_tiles;
   info8[2] = sl.plan.side[1].n_tiles;
   info8[3] = sl.plan.p_cap;
@@ -690,9 +699,9 @@ int64_t uds_spatial_packed_bytes(void) { return PACKED_WEIGHT_FLOATS * 4; }
 int uds_spatial_pack_weights(const uds_spatial_params_t *p, int64_t fx, int64_t fe, int64_t h, int64_t d, void *packed_out,
                              uds_stream_t stream) {
   UDS_REQUIRE(p && packed_out && p->xe_k && p->ex_k && p->gx_k && p->ge_k, "uds_spatial_pack_weights: NULL argument");
-  const bool wide = h == uds::F128_H && d == uds::F128_D && fx == 128 && fe == 128;
+  const bool wide = h == uds::F128_H && d == uds::F128_D && fx == 128 && (fe == 128 || fe == 64);
   UDS_REQUIRE(wide || (h == uds::FUSED_H && d == uds::FUSED_D && (fx == 64 || fx == 96) && (fe == 64 || fe == 96)),
-              "uds_spatial_pack_weights: the fused kernels take h=32, d=64, fx, fe in {64, 96} or h=64, d=128, fx=fe=128 (got h=%lld d=%lld "
+              "uds_spatial_pack_weights: the fused kernels take h=32, d=64, fx, fe in {64, 96} or h=64, d=128, fx=128, fe in {64, 128} (got h=%lld d=%lld "
               "fx=%lld fe=%lld)", (long long)h, (long long)d, (long long)fx, (long long)fe);
   UDS_REQUIRE(aligned16(packed_out), "uds_spatial_pack_weights: output must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -739,10 +748,9 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (S == 0) return UDS_OK;
 
-  if (h == uds::F128_H && d == uds::F128_D && fx == 128 && fe == 128 && !xb && !eb && !(flags & UDS_FLAG_EXACT_FP32) &&
-      net->slot[4].ok) {
-    // d = 128: the column-split fused kernel (kernels_fused128.hpp)
-    const uds_plan_slot &u = net->slot[4];
+  if (h == uds::F128_H && d == uds::F128_D && fx == 128 && (fe == 128 || fe == 64) && !xb && !eb && !(flags & UDS_FLAG_EXACT_FP32) &&
+      net->slot[slot_index(128, (int)fe)].ok && net->slot[slot_index((int)fe, 128)].ok) {
+    // d = 128: the column-split fused kernel (kernels_fused128.hpp); 64-wide link rows -> one launch per side
     UDS_REQUIRE(aligned16(p->xe_b) && aligned16(p->ex_b) && aligned16(p->gx_as) && aligned16(p->gx_an) && aligned16(p->gx_b) &&
                     aligned16(p->ge_as) && aligned16(p->ge_an) && aligned16(p->ge_b),
                 "uds_spatial_layer_forward: bias / attention vectors must be 16-byte aligned");
@@ -757,31 +765,42 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
     uds::FusedArgs a;
     a.side[0] = uds::FusedSide{x, e, nullptr, nullptr, out_x, wq, wq + 2048, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
     a.side[1] = uds::FusedSide{e, x, nullptr, nullptr, out_e, wq + 8192, wq + 10240, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};
-    a.hdr = u.d_hdr;
-    a.pool = u.d_pool;
-    a.n_tiles = u.plan.n_tiles;
-    a.p_cap = u.plan.p_cap;
-    a.q_cap = u.plan.q_cap;
-    a.meta_cap = u.plan.meta_cap;
     a.S = (int)S;
     a.act = act;
     a.dbg = nullptr;
 #ifdef UDS_PHASE_TIMING
     a.dbg = reinterpret_cast<unsigned long long *>(ws + PACKED_WEIGHT_FLOATS);
 #endif
-    a.side_mask = 3;
-    int64_t chunk = S, best = INT64_MAX;
-    for (int64_t c = 1; c <= S; ++c) {
-      const int64_t rounds = (((S + c - 1) / c) * a.n_tiles + 255) / 256;
-      const int64_t cost = rounds * (3 + 2 * c);
-      if (cost < best || (cost == best && c < chunk)) {
-        best = cost;
-        chunk = c;
+    auto launch_side = [&](const uds_plan_slot &u, int side, auto FP_, auto FS_) {       // side < 0: both sides in one launch
+      a.hdr = side < 0 ? u.d_hdr : u.d_hdr_side[side];
+      a.pool = u.d_pool;
+      a.n_tiles = side < 0 ? u.plan.n_tiles : u.plan.side[side].n_tiles;
+      a.p_cap = u.plan.p_cap;
+      a.q_cap = u.plan.q_cap;
+      a.meta_cap = u.plan.meta_cap;
+      a.side_mask = side < 0 ? 3 : (1 << side);
+      int64_t chunk = S, best = INT64_MAX;
+      for (int64_t c = 1; c <= S; ++c) {
+        const int64_t rounds = (((S + c - 1) / c) * a.n_tiles + 255) / 256;
+        const int64_t cost = rounds * (3 + 2 * c);
+        if (cost < best || (cost == best && c < chunk)) {
+          best = cost;
+          chunk = c;
+        }
       }
+      a.chunk = (int)chunk;
+      const int grid = (int)(((S + chunk - 1) / chunk) * a.n_tiles);
+      return launch_fused128<decltype(FP_)::value, decltype(FS_)::value>(a, grid, u.lds_bytes, st);
+    };
+    using I64 = std::integral_constant<int, 64>;
+    using I128 = std::integral_constant<int, 128>;
+    hipError_t he;
+    if (fe == 128) {
+      he = launch_side(net->slot[4], -1, I128{}, I128{});
+    } else {
+      he = launch_side(net->slot[5], 0, I128{}, I64{});                       // node tiles: 128-wide nodes fed by 64-wide links
+      if (he == hipSuccess) he = launch_side(net->slot[6], 1, I64{}, I128{});   // link tiles: 64-wide links fed by 128-wide nodes
     }
-    a.chunk = (int)chunk;
-    const int grid = (int)(((S + chunk - 1) / chunk) * a.n_tiles);
-    hipError_t he = launch_fused128(a, grid, u.lds_bytes, st);
     if (he != hipSuccess) return fail(UDS_EHIP, "uds_spatial_layer_forward: fused d=128 launch -> %s", hipGetErrorString(he));
     return UDS_OK;
   }

@@ -463,9 +463,9 @@ class SpatialLayer(nn.Module):
             if self.precision == 'bf16x3' and self.h == 32 and self.d == 64 and fx in (64, 96) and fe in (64, 96):
                 p['packed'] = self._packed_weights(p, fx, fe)       # split once per parameter update, not per call
                 self.network().prepare(fx, fe)                      # tile plans of the 96-wide variants are built on first use
-            elif self.precision == 'bf16x3' and self.h == 64 and self.d == 128 and fx == 128 and fe == 128 and xbs is None and ebs is None:
-                self.network().prepare(128, 128)                    # d = 128 (the reference default): the column-split fused kernel
-                if self.network().plan_info()['fused'] & 8:
+            elif self.precision == 'bf16x3' and self.h == 64 and self.d == 128 and fx == 128 and fe in (64, 128) and xbs is None and ebs is None:
+                self.network().prepare(128, fe)                     # d = 128 (the reference default): the column-split fused kernel
+                if self.network().plan_info()['fused'] & (8 if fe == 128 else 16):
                     p['packed'] = self._packed_weights(p, fx, fe)
             if 'packed' not in p and self.precision == 'bf16x3' and fx % 32 == 0 and fe % 32 == 0 and self.h % 16 == 0 and self.d % 16 == 0 \
                     and xs.shape[0] * xs.shape[1] >= 4096:

@@ -233,6 +233,22 @@ def test_wide_layer_d128_matrix_core_unfused_path(dev):
         _lib.gat_aggregate(_lib.CsrHandle(gph.adj), hx, ss[:, :5].contiguous(), sn)
 
 
+def test_fused_d128_mixed_width_layer(dev):
+    """First layer of block 2 at d = 128 without actions (emulator.py:260-262): 128-wide node rows, 64-wide link rows -> the
+    <128,64> (node tiles) and <64,128> (link tiles) variants of k_fused128, one launch each."""
+    gph = U.DrainageGraph.from_edges(U.synthetic_drainage_network(2000, 2500, 0))
+    d, S, fx, fe = 128, 3, 128, 64
+    p = spatial_params(2000, 2500, fx, fe, d, seed=13, dense_ne=False, nnz_n=gph.inc_n.nnz, nnz_e=gph.inc_e.nnz)
+    g = torch.Generator().manual_seed(14)
+    x, e = rnd(g, S, 2000, fx), rnd(g, S, 2500, fe)
+    rx, re = OS.spatial_layer_csr(x, e, p, (gph.adj.rowptr, gph.adj.col), (gph.edge_adj.rowptr, gph.edge_adj.col),
+                                  (gph.inc_n.rowptr, gph.inc_n.col), (gph.inc_e.rowptr, gph.inc_e.col))
+    layer = load_spatial_layer(U.SpatialLayer(gph, d, 'relu', fx=fx, fe=fe, sparse_params=True, precision='bf16x3'), p, dev)
+    ox, oe = layer(x.float().to(dev), e.float().to(dev))
+    assert layer.network().plan_info()['fused'] & 16
+    close(ox, rx, TOL_BF16X3); close(oe, re, TOL_BF16X3)
+
+
 def test_dense_wide_outputs_column_blocks(dev):
     """Dense 64 -> 128 / 96 -> 80 with precision='bf16x3': 64-column blocks of the kernel through uds_rowgemm_forward_cat."""
     g = torch.Generator().manual_seed(2)
