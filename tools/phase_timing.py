@@ -30,7 +30,7 @@ for _ in range(3):
     assert rc == 0
 torch.cuda.synchronize()
 n_tiles = info['node_tiles'] + info['link_tiles']
-raw = ws[22528:].view(torch.int64).cpu().numpy()
+raw = ws[65536:].view(torch.int64).cpu().numpy()
 n_wg = 0
 rows = raw[:(len(raw) // 16) * 16].reshape(-1, 16)
 valid = (rows[:, 7] & 1) == 1
