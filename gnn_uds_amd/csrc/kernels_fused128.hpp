@@ -1,5 +1,5 @@
-// One spatial layer at embed_size d = 128 (h = 64, 128-wide node and link rows: the reference's default model size,
-// utils/config.yaml) as ONE launch -- the same tile / snapshot-chunk / LDS-DMA scheme as k_fused_tile (kernels_fused.hpp),
+// The COLUMN-SPLIT fused spatial layer.  First written for embed_size d = 128 (h = 64, 128-wide node and link rows: the
+// reference's default model size, utils/config.yaml) as ONE launch -- the same tile / snapshot-chunk / LDS-DMA scheme as k_fused_tile (kernels_fused.hpp),
 // re-organised because at d = 128 the weight fragments (128 + 384 VGPRs per lane) fit no wave:
 //
 //   * the GEMMs are split by OUTPUT COLUMNS (and row-block parity) across the 8 waves: a wave owns 32 of the 128 columns
@@ -24,22 +24,35 @@ namespace uds {
 
 constexpr int F128_H = 64, F128_D = 128, F128_F = 128;
 constexpr int F128_U = 2;                       // P3 row groups per wave
-constexpr int F128_SEC_STRIDE = F128_H + 4;     // floats: 272-B rows, conflict-free 16-B fragment writes
 
-// LDS bytes of k_fused128 for the caps of a plan (mirrors the layout in the kernel)
+// LDS bytes of the column-split kernel for embed size d and the caps of a plan (mirrors the layout in the kernel)
+inline int64_t fused_cs_lds_bytes(int d, int p_cap, int q_cap, int meta_cap, int fp, int fs) {
+  const int h = d / 2;
+  return 4 * ((int64_t)meta_cap + 2 * (d / 16) * p_cap + (2 * d + h) + (int64_t)q_cap * (h + 4) + (int64_t)p_cap * h + (int64_t)p_cap * d +
+              (int64_t)q_cap * fs + (int64_t)p_cap * fp);
+}
 inline int64_t fused128_lds_bytes(int p_cap, int q_cap, int meta_cap, int fp = F128_F, int fs = F128_F) {
-  return 4 * ((int64_t)meta_cap + 2 * 8 * p_cap + (2 * F128_D + F128_H) + (int64_t)q_cap * F128_SEC_STRIDE + (int64_t)p_cap * F128_H +
-              (int64_t)p_cap * F128_D + (int64_t)q_cap * fs + (int64_t)p_cap * fp);
+  return fused_cs_lds_bytes(F128_D, p_cap, q_cap, meta_cap, fp, fs);
 }
 
 // FP / FS: widths of the primary / secondary input rows, 128 or 64 (the first layer of block 2 without actions has 128-wide
 // node rows [temporal output | boundary embedding] and 64-wide link rows, emulator.py:260-262)
-template <int FP, int FS, int ACT>
-__global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
-  static_assert((FP == 64 || FP == 128) && (FS == 64 || FS == 128), "row widths 64 or 128");
-  constexpr int NW = FUSED_WAVES, NT = FUSED_WAVES * 64, U = F128_U;
-  constexpr int KT_S = FS / 32, KT_X = FP / 32, KT_A = F128_H / 32, KT_B = KT_X + KT_A;     // 4|2, 4|2, 2, 6|4
-  constexpr int MB_S = F128_H / 16, MB_B = F128_D / 16;                                              // 4, 8
+// D = embed size (128 with 8 waves; 64 with 16 waves: four waves per SIMD hide the LDS / MFMA latencies the 8-wave
+// register-resident kernel k_fused_tile exposes), NW = waves per workgroup.
+template <int D, int FP, int FS, int NW, int ACT>
+__global__ __launch_bounds__(NW * 64) void k_fused_cs(FusedArgs a) {
+  static_assert(D == 64 || D == 128, "embed size 64 or 128");
+  static_assert(FP % 32 == 0 && FS % 32 == 0 && FP <= 128 && FS <= 128, "row widths: multiples of 32 up to 128");
+  constexpr int H = D / 2, NT = NW * 64, U = F128_U;
+  constexpr int KT_S = FS / 32, KT_X = FP / 32, KT_A = H / 32, KT_B = KT_X + KT_A;
+  constexpr int MB_S = H / 16, MB_B = D / 16;
+  constexpr int MPW = MB_B / 4;                 // hx column blocks per wave (four column groups)
+  constexpr int PAR_B = NW / 4;                 // row-block parities of the hx GEMM
+  constexpr int PAR_S = NW / MB_S;              // ... of the fusion MLP
+  constexpr int NSP = MB_B;                     // attention-score partials per row
+  constexpr int CH = D / 64;                    // 16-B chunks per lane and output row in P3
+  constexpr int SECS = H + 4;                   // sec row stride (floats): conflict-free 16-B fragment writes
+  static_assert(NW % 4 == 0 && NW % MB_S == 0, "waves split into column groups");
   extern __shared__ __attribute__((aligned(16))) int32_t smem[];
 #ifdef UDS_PHASE_TIMING
   unsigned long long tq_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_ = clock64();
@@ -61,13 +74,13 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
   const FusedSide &S_ = a.side[sd];
 
   int32_t *meta = smem;
-  float *sp_self = reinterpret_cast<float *>(smem + a.meta_cap);       // [p_cap][8]: per-wave partial <hx, a_self>
-  float *sp_nbr = sp_self + 8 * a.p_cap;                                // [p_cap][8]
-  float *attn = sp_nbr + 8 * a.p_cap;                                   // a_self[128] | a_nbr[128] | b_small[64]
-  float *sec = attn + 2 * F128_D + F128_H;                              // [q_cap][68]
-  float *aggf = sec + a.q_cap * F128_SEC_STRIDE;                        // (p_cap/16) blocks x 2 k-steps x (hi 1 KiB | lo 1 KiB)
-  float *hx = aggf + a.p_cap * F128_H;                                  // [p_cap][128], 16-B chunks XOR (row & 7)
-  float *stage_s = hx + a.p_cap * F128_D;                               // (q_cap/16) blocks x KT_S k-steps x 2 x 1 KiB
+  float *sp_self = reinterpret_cast<float *>(smem + a.meta_cap);       // [p_cap][NSP]: per-column-block partial <hx, a_self>
+  float *sp_nbr = sp_self + NSP * a.p_cap;                              // [p_cap][NSP]
+  float *attn = sp_nbr + NSP * a.p_cap;                                 // a_self[D] | a_nbr[D] | b_small[H]
+  float *sec = attn + 2 * D + H;                                        // [q_cap][H + 4]
+  float *aggf = sec + a.q_cap * SECS;                                   // (p_cap/16) blocks x KT_A k-steps x (hi 1 KiB | lo 1 KiB)
+  float *hx = aggf + a.p_cap * H;                                       // [p_cap][D], 16-B chunks XOR (row & 7)
+  float *stage_s = hx + a.p_cap * D;                               // (q_cap/16) blocks x KT_S k-steps x 2 x 1 KiB
   float *stage_p = stage_s + a.q_cap * FS;                              // (p_cap/16) blocks x KT_X k-steps x 2 x 1 KiB
 
   for (int i = tid; i < meta_len; i += NT) meta[i] = a.pool[pool_off + i];
@@ -83,18 +96,23 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
   const int c16 = lane & 15, rs = lane >> 4;
   const int nb_sec = (n_sec + 15) / 16, nb_prim = (n_prim + 15) / 16;
 
-  // block ownership (DMA issue, P0 split): secondary block b -> wave b % 8, primary block b -> wave 7 - b % 8
-  auto sec_owner = [&](int blk) { return blk & 7; };
-  auto prim_owner = [&](int blk) { return 7 - (blk & 7); };
+  // block ownership (DMA issue, P0 split): secondary block b -> wave b % NW, primary block b -> wave NW - 1 - b % NW
+  auto sec_owner = [&](int blk) { return blk % NW; };
+  auto prim_owner = [&](int blk) { return NW - 1 - blk % NW; };
   auto dma_block = [&](auto KT_, const float *base, int row, float *stage, int blk) {      // 16 rows x 32 KT floats = 2 KT pieces of 1 KiB
     constexpr int KT = decltype(KT_)::value;
     const float *src = base + (int64_t)row * (32 * KT) + 4 * qd;
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(stage) + (unsigned)blk * (2 * KT * 1024));
-    const float *p0[4] = {src, src + 16, src + 32, src + 48};
-    glds16_run<4>(p0, dst);
-    if constexpr (KT == 4) {
-      const float *p1[4] = {src + 64, src + 80, src + 96, src + 112};
-      glds16_run<4>(p1, dst + 4096);
+    if constexpr (KT == 3) {
+      const float *p0[6] = {src, src + 16, src + 32, src + 48, src + 64, src + 80};
+      glds16_run<6>(p0, dst);
+    } else {
+      const float *p0[4] = {src, src + 16, src + 32, src + 48};
+      glds16_run<4>(p0, dst);
+      if constexpr (KT == 4) {
+        const float *p1[4] = {src + 64, src + 80, src + 96, src + 112};
+        glds16_run<4>(p1, dst + 4096);
+      }
     }
   };
   auto dma_sec_all = [&](int s) {
@@ -126,31 +144,30 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
   }
   // everything below overlaps with the first snapshot's DMA
   for (int i = tid; i < n_inc; i += NT) reinterpret_cast<float *>(inc_w)[i] = S_.ne_val[inc_w[i]];
-  if (tid < F128_D) {
+  if (tid < D) {
     attn[tid] = S_.a_self[tid];
-    attn[F128_D + tid] = S_.a_nbr[tid];
-    if (tid < F128_H) attn[2 * F128_D + tid] = S_.b_small ? S_.b_small[tid] : 0.f;
+    attn[D + tid] = S_.a_nbr[tid];
+    if (tid < H) attn[2 * D + tid] = S_.b_small ? S_.b_small[tid] : 0.f;
   }
-  f32x4 bo[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  if (S_.b_out) {
-    bo[0] = *reinterpret_cast<const f32x4 *>(S_.b_out + 4 * c16);
-    bo[1] = *reinterpret_cast<const f32x4 *>(S_.b_out + 64 + 4 * c16);
-  }
+  f32x4 bo[CH];
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) bo[ch] = S_.b_out ? *reinterpret_cast<const f32x4 *>(S_.b_out + 64 * ch + 4 * c16) : f32x4{0.f, 0.f, 0.f, 0.f};
   // this wave's weight columns: fusion MLP slice wave & 3 (16 columns), hx slices 2 (wave & 3) and 2 (wave & 3) + 1 (32
   // columns) -- both for the row blocks of parity wave >> 2: a fragment read from LDS then feeds two column blocks
-  const int cs = wave & 3, par = wave >> 2;
-  bf16x8 wsh[KT_S], wsl[KT_S], wbh[KT_B][2], wbl[KT_B][2];
+  const int cs = wave & 3, par = wave >> 2;              // hx GEMM: column group, row-block parity
+  const int cs_s = wave % MB_S, par_s = wave / MB_S;     // fusion MLP
+  bf16x8 wsh[KT_S], wsl[KT_S], wbh[KT_B][MPW], wbl[KT_B][MPW];
 #pragma unroll
   for (int t = 0; t < KT_S; ++t) {
-    wsh[t] = __builtin_bit_cast(bf16x8, S_.w_small[((t * MB_S + cs) * 2 + 0) * 64 + lane]);
-    wsl[t] = __builtin_bit_cast(bf16x8, S_.w_small[((t * MB_S + cs) * 2 + 1) * 64 + lane]);
+    wsh[t] = __builtin_bit_cast(bf16x8, S_.w_small[((t * MB_S + cs_s) * 2 + 0) * 64 + lane]);
+    wsl[t] = __builtin_bit_cast(bf16x8, S_.w_small[((t * MB_S + cs_s) * 2 + 1) * 64 + lane]);
   }
 #pragma unroll
   for (int t = 0; t < KT_B; ++t)
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      wbh[t][m] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + 2 * cs + m) * 2 + 0) * 64 + lane]);
-      wbl[t][m] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + 2 * cs + m) * 2 + 1) * 64 + lane]);
+    for (int m = 0; m < MPW; ++m) {
+      wbh[t][m] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + MPW * cs + m) * 2 + 0) * 64 + lane]);
+      wbl[t][m] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + MPW * cs + m) * 2 + 1) * 64 + lane]);
     }
   __syncthreads();
   int n_st = 0;
@@ -186,9 +203,9 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
     lds_barrier();
     UDS_STAMP128(3);
     // ---------------- P1: fusion MLP, 16 columns (cs) x the row blocks of this wave's parity -> sec ----------------
-    for (int blk = par; blk < nb_sec; blk += 2) {
+    for (int blk = par_s; blk < nb_sec; blk += PAR_S) {
       const float4 *st = reinterpret_cast<const float4 *>(stage_s + blk * (2 * KT_S * 256)) + lane;
-      f32x4 acc = *reinterpret_cast<const f32x4 *>(attn + 2 * F128_D + 16 * cs + 4 * qd);
+      f32x4 acc = *reinterpret_cast<const f32x4 *>(attn + 2 * D + 16 * cs_s + 4 * qd);
 #pragma unroll
       for (int t = 0; t < KT_S; ++t) {
 #ifndef UDS_F128_NOP0
@@ -204,7 +221,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = fused_act<ACT>(acc[j], a.act);
-        *reinterpret_cast<f32x4 *>(sec + lrow * F128_SEC_STRIDE + 16 * cs + 4 * qd) = o;
+        *reinterpret_cast<f32x4 *>(sec + lrow * SECS + 16 * cs_s + 4 * qd) = o;
       }
     }
     UDS_STAMP128(4);
@@ -212,13 +229,13 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
     UDS_STAMP128(5);
     if (s + 1 < s_end) dma_sec_all(s + 1);        // the secondary fragments are consumed: fetch the next snapshot's rows
     // ---------------- P1.5: NodeEdge aggregation of the primary rows -> fragments (block wave/2, k-step wave&1) ----------------
-    for (int unit = wave; unit < 2 * nb_prim; unit += NW) {
-      const int blk = unit >> 1, half = unit & 1;
+    for (int unit = wave; unit < KT_A * nb_prim; unit += NW) {
+      const int blk = unit / KT_A, half = unit % KT_A;
       const int lr = min(blk * 16 + r16, n_prim - 1);
       float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
       for (int p = inc_ptr[lr]; p < inc_ptr[lr + 1]; ++p) {
         const float wv = inc_val[p];
-        const float *row = sec + inc_loc[p] * F128_SEC_STRIDE + 32 * half + 4 * qd;
+        const float *row = sec + inc_loc[p] * SECS + 32 * half + 4 * qd;
         const float4 u0 = *reinterpret_cast<const float4 *>(row);
         const float4 u1 = *reinterpret_cast<const float4 *>(row + 16);
         g0.x = fmaf(wv, u0.x, g0.x); g0.y = fmaf(wv, u0.y, g0.y); g0.z = fmaf(wv, u0.z, g0.z); g0.w = fmaf(wv, u0.w, g0.w);
@@ -235,16 +252,18 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
     UDS_STAMP128(7);
     // ---------------- P2: hx columns [32 cs, 32 cs + 32) of the primary blocks of this wave's parity + partial scores ----------------
     {
-      f32x4 as4[2], an4[2];
+      f32x4 as4[MPW], an4[MPW];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        as4[m] = *reinterpret_cast<const f32x4 *>(attn + 16 * (2 * cs + m) + 4 * qd);
-        an4[m] = *reinterpret_cast<const f32x4 *>(attn + F128_D + 16 * (2 * cs + m) + 4 * qd);
+      for (int m = 0; m < MPW; ++m) {
+        as4[m] = *reinterpret_cast<const f32x4 *>(attn + 16 * (MPW * cs + m) + 4 * qd);
+        an4[m] = *reinterpret_cast<const f32x4 *>(attn + D + 16 * (MPW * cs + m) + 4 * qd);
       }
-      for (int blk = par; blk < nb_prim; blk += 2) {
+      for (int blk = par; blk < nb_prim; blk += PAR_B) {
         const float4 *st = reinterpret_cast<const float4 *>(stage_p + blk * (2 * KT_X * 256)) + lane;
-        const float4 *ag = reinterpret_cast<const float4 *>(aggf + blk * 1024) + lane;
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        const float4 *ag = reinterpret_cast<const float4 *>(aggf + blk * (KT_A * 512)) + lane;
+        f32x4 acc[MPW];
+#pragma unroll
+        for (int m = 0; m < MPW; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < KT_X; ++t) {
 #ifndef UDS_F128_NOP0
@@ -254,17 +273,17 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
           split8(st[(2 * t) * 64], st[(2 * t + 1) * 64], dh, dl);
 #endif
 #pragma unroll
-          for (int m = 0; m < 2; ++m) acc[m] = mfma3(wbh[t][m], wbl[t][m], dh, dl, acc[m]);
+          for (int m = 0; m < MPW; ++m) acc[m] = mfma3(wbh[t][m], wbl[t][m], dh, dl, acc[m]);
         }
 #pragma unroll
         for (int t = 0; t < KT_A; ++t) {
           const bf16x8 dh = __builtin_bit_cast(bf16x8, ag[t * 128]), dl = __builtin_bit_cast(bf16x8, ag[t * 128 + 64]);
 #pragma unroll
-          for (int m = 0; m < 2; ++m) acc[m] = mfma3(wbh[KT_X + t][m], wbl[KT_X + t][m], dh, dl, acc[m]);
+          for (int m = 0; m < MPW; ++m) acc[m] = mfma3(wbh[KT_X + t][m], wbl[KT_X + t][m], dh, dl, acc[m]);
         }
         const int lrow = blk * 16 + r16;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < MPW; ++m) {
           float ps = 0.f, pn = 0.f;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -275,10 +294,10 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
           pn = quarters_sum(pn);
           if (lrow < n_prim) {
             if (qd == 0) {
-              sp_self[lrow * 8 + 2 * cs + m] = ps;
-              sp_nbr[lrow * 8 + 2 * cs + m] = pn;
+              sp_self[lrow * NSP + MPW * cs + m] = ps;
+              sp_nbr[lrow * NSP + MPW * cs + m] = pn;
             }
-            *reinterpret_cast<f32x4 *>(hx + lrow * F128_D + (((4 * (2 * cs + m) + qd) ^ (lrow & 7)) << 2)) = acc[m];
+            *reinterpret_cast<f32x4 *>(hx + lrow * D + (((4 * (MPW * cs + m) + qd) ^ (lrow & 7)) << 2)) = acc[m];
           }
         }
       }
@@ -287,7 +306,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
     lds_barrier();
     UDS_STAMP128(9);
     if (s + 1 < s_end) dma_prim_all(s + 1);       // the primary fragments are consumed
-    // ---------------- P3: segmented softmax + neighbour sum -> HBM (16 lanes x 2 float4 per output row) ----------------
+    // ---------------- P3: segmented softmax + neighbour sum -> HBM (16 lanes x CH float4 per output row) ----------------
     n_st = 0;
     {
       int deg[U], jn[U], orow[U];
@@ -301,17 +320,23 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
         ok[u] = i < n_own;
         const int b0 = adj_ptr[ic];
         deg[u] = ok[u] ? adj_ptr[ic + 1] - b0 : 0;
-        jn[u] = c16 < deg[u] ? adj_loc[b0 + c16] : 0;
-        orow[u] = prim_ids[ic] * F128_D + 4 * c16;
-        // the 8 per-wave partials of a score, added in index order: lanes 0..7 of the row group hold one partial each
-        ss[u] = row16_sum(c16 < 8 ? sp_self[ic * 8 + c16] : 0.f);
-        const f32x4 q0 = *reinterpret_cast<const f32x4 *>(sp_nbr + jn[u] * 8), q1 = *reinterpret_cast<const f32x4 *>(sp_nbr + jn[u] * 8 + 4);
-        sn[u] = ((q0[0] + q0[1]) + (q0[2] + q0[3])) + ((q1[0] + q1[1]) + (q1[2] + q1[3]));
+        jn[u] = adj_loc[b0 + min(c16, max(deg[u] - 1, 0))];          // clamped, unconditional: slots past the degree get weight 0
+        orow[u] = prim_ids[ic] * D + 4 * c16;
+        // the NSP per-column-block partials of a score, added in a fixed order: lanes 0..NSP-1 of the row group hold one each
+        ss[u] = row16_sum(c16 < NSP ? sp_self[ic * NSP + c16] : 0.f);
+        const f32x4 q0 = *reinterpret_cast<const f32x4 *>(sp_nbr + jn[u] * NSP);
+        sn[u] = (q0[0] + q0[1]) + (q0[2] + q0[3]);
+        if constexpr (NSP == 8) {
+          const f32x4 q1 = *reinterpret_cast<const f32x4 *>(sp_nbr + jn[u] * NSP + 4);
+          sn[u] += (q1[0] + q1[1]) + (q1[2] + q1[3]);
+        }
         dm = max(dm, p3_dmax[u]);
       }
-      f32x4 acc[U][2];
+      f32x4 acc[U][CH];
 #pragma unroll
-      for (int u = 0; u < U; ++u) acc[u][0] = acc[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) acc[u][ch] = f32x4{0.f, 0.f, 0.f, 0.f};
       const char *hxb = reinterpret_cast<const char *>(hx);
       if (dm <= 16) {
         int joff[U];
@@ -322,29 +347,29 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
           const float ex = __builtin_amdgcn_exp2f((lg - mx) * 1.44269504088896340736f);
           wgt[u] = c16 < deg[u] ? ex : 0.f;
           den[u] = row16_sum(wgt[u]);
-          joff[u] = jn[u] * (F128_D * 4) + ((jn[u] & 7) << 4);       // row byte offset with the swizzle key in bits 4-6
+          joff[u] = jn[u] * (D * 4) + ((jn[u] & 7) << 4);       // row byte offset with the swizzle key in bits 4-6
         }
         const int cx = c16 << 4;
         auto step = [&](auto K_, auto A_) {
           constexpr int K = decltype(K_)::value, A = decltype(A_)::value;
-          f32x4 h0[A][2], h1[A][2];
+          f32x4 h0[A][CH], h1[A][CH];
 #pragma unroll
           for (int u = 0; u < A; ++u) {
             const int a0 = row16_bcast<K>(joff[u]) ^ cx, a1 = row16_bcast<K + 1>(joff[u]) ^ cx;
-            h0[u][0] = *reinterpret_cast<const f32x4 *>(hxb + a0);
-            h0[u][1] = *reinterpret_cast<const f32x4 *>(hxb + a0 + 256);
-            h1[u][0] = *reinterpret_cast<const f32x4 *>(hxb + a1);
-            h1[u][1] = *reinterpret_cast<const f32x4 *>(hxb + a1 + 256);
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) {
+              h0[u][ch] = *reinterpret_cast<const f32x4 *>(hxb + a0 + 256 * ch);
+              h1[u][ch] = *reinterpret_cast<const f32x4 *>(hxb + a1 + 256 * ch);
+            }
           }
 #pragma unroll
           for (int u = 0; u < A; ++u) {
             const float w0 = __int_as_float(row16_bcast<K>(__float_as_int(wgt[u])));
             const float w1 = __int_as_float(row16_bcast<K + 1>(__float_as_int(wgt[u])));
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              acc[u][0][q] = fmaf(w1, h1[u][0][q], fmaf(w0, h0[u][0][q], acc[u][0][q]));
-              acc[u][1][q] = fmaf(w1, h1[u][1][q], fmaf(w0, h0[u][1][q], acc[u][1][q]));
-            }
+            for (int ch = 0; ch < CH; ++ch)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[u][ch][q] = fmaf(w1, h1[u][ch][q], fmaf(w0, h0[u][ch][q], acc[u][ch][q]));
           }
         };
         const int e1 = p3_dmax[1], e0 = max(e1, p3_dmax[0]);
@@ -364,7 +389,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
           const int b0 = i < n_own ? adj_ptr[i] : 0;
           auto s_nbr_of = [&](int j) {
             float t = 0.f;
-            for (int k = 0; k < 8; ++k) t += sp_nbr[j * 8 + k];
+            for (int k = 0; k < NSP; ++k) t += sp_nbr[j * NSP + k];
             return t;
           };
           float mx = -INFINITY;
@@ -373,31 +398,29 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused128(FusedArgs a) {
           for (int p = b0; p < b0 + deg[u]; ++p) {
             const int jj = adj_loc[p];
             const float wv = __builtin_amdgcn_exp2f((leaky02(ss[u] + s_nbr_of(jj)) - mx) * 1.44269504088896340736f);
-            const f32x4 hv0 = *reinterpret_cast<const f32x4 *>(hx + jj * F128_D + ((c16 ^ (jj & 7)) << 2));
-            const f32x4 hv1 = *reinterpret_cast<const f32x4 *>(hx + jj * F128_D + (((16 + c16) ^ (jj & 7)) << 2));
             den[u] += wv;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              acc[u][0][q] = fmaf(wv, hv0[q], acc[u][0][q]);
-              acc[u][1][q] = fmaf(wv, hv1[q], acc[u][1][q]);
+            for (int ch = 0; ch < CH; ++ch) {
+              const f32x4 hv = *reinterpret_cast<const f32x4 *>(hx + jj * D + (((16 * ch + c16) ^ (jj & 7)) << 2));
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[u][ch][q] = fmaf(wv, hv[q], acc[u][ch][q]);
             }
           }
         }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (p3_dmax[u] > 0) n_st += 2;       // wave-uniform: two store instructions per row group that has a valid row
+        if (p3_dmax[u] > 0) n_st += CH;       // wave-uniform: CH store instructions per row group that has a valid row
         if (ok[u]) {
           const float inv = __builtin_amdgcn_rcpf(den[u]);
-          f32x4 o0, o1;
+          float *dst = S_.out + ((int64_t)s * S_.n_prim_glob * D + orow[u]);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            o0[q] = fused_act<ACT>(fmaf(acc[u][0][q], inv, bo[0][q]), a.act);
-            o1[q] = fused_act<ACT>(fmaf(acc[u][1][q], inv, bo[1][q]), a.act);
+          for (int ch = 0; ch < CH; ++ch) {
+            f32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = fused_act<ACT>(fmaf(acc[u][ch][q], inv, bo[ch][q]), a.act);
+            *reinterpret_cast<f32x4 *>(dst + 64 * ch) = o;
           }
-          float *dst = S_.out + ((int64_t)s * S_.n_prim_glob * F128_D + orow[u]);
-          *reinterpret_cast<f32x4 *>(dst) = o0;
-          *reinterpret_cast<f32x4 *>(dst + 64) = o1;
         }
       }
     }
