@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "kernels_fused.hpp"
 
 namespace uds {
@@ -28,8 +30,9 @@ constexpr int F128_U = 2;                       // P3 row groups per wave
 // LDS bytes of the column-split kernel for embed size d and the caps of a plan (mirrors the layout in the kernel)
 inline int64_t fused_cs_lds_bytes(int d, int p_cap, int q_cap, int meta_cap, int fp, int fs) {
   const int h = d / 2;
-  return 4 * ((int64_t)meta_cap + 2 * (d / 16) * p_cap + (2 * d + h) + (int64_t)q_cap * (h + 4) + (int64_t)p_cap * h + (int64_t)p_cap * d +
-              (int64_t)q_cap * fs + (int64_t)p_cap * fp);
+  // the score partials (2 x d/16 floats per primary row) live in the sec region: sec is dead between P1.5 and the next P1
+  const int64_t sec = std::max<int64_t>((int64_t)q_cap * (h + 4), 2 * (d / 16) * (int64_t)p_cap);
+  return 4 * ((int64_t)meta_cap + (2 * d + h) + sec + (int64_t)p_cap * h + (int64_t)p_cap * d + (int64_t)q_cap * fs + (int64_t)p_cap * fp);
 }
 inline int64_t fused128_lds_bytes(int p_cap, int q_cap, int meta_cap, int fp = F128_F, int fs = F128_F) {
   return fused_cs_lds_bytes(F128_D, p_cap, q_cap, meta_cap, fp, fs);
@@ -74,11 +77,14 @@ __global__ __launch_bounds__(NW * 64) void k_fused_cs(FusedArgs a) {
   const FusedSide &S_ = a.side[sd];
 
   int32_t *meta = smem;
-  float *sp_self = reinterpret_cast<float *>(smem + a.meta_cap);       // [p_cap][NSP]: per-column-block partial <hx, a_self>
-  float *sp_nbr = sp_self + NSP * a.p_cap;                              // [p_cap][NSP]
-  float *attn = sp_nbr + NSP * a.p_cap;                                 // a_self[D] | a_nbr[D] | b_small[H]
+  float *attn = reinterpret_cast<float *>(smem + a.meta_cap);           // a_self[D] | a_nbr[D] | b_small[H]
   float *sec = attn + 2 * D + H;                                        // [q_cap][H + 4]
-  float *aggf = sec + a.q_cap * SECS;                                   // (p_cap/16) blocks x KT_A k-steps x (hi 1 KiB | lo 1 KiB)
+  // the per-column-block partials <hx, a_self>, <hx, a_nbr> ([p_cap][NSP] each) are written in P2 and read in P3, when the
+  // sec rows are dead (their last reader is P1.5, their next writer the P1 after the next P0 barrier): they share the region
+  float *sp_self = sec;
+  float *sp_nbr = sec + NSP * a.p_cap;
+  const int sec_floats = max(a.q_cap * SECS, 2 * NSP * a.p_cap);
+  float *aggf = sec + sec_floats;                                       // (p_cap/16) blocks x KT_A k-steps x (hi 1 KiB | lo 1 KiB)
   float *hx = aggf + a.p_cap * H;                                       // [p_cap][D], 16-B chunks XOR (row & 7)
   float *stage_s = hx + a.p_cap * D;                               // (q_cap/16) blocks x KT_S k-steps x 2 x 1 KiB
   float *stage_p = stage_s + a.q_cap * FS;                              // (p_cap/16) blocks x KT_X k-steps x 2 x 1 KiB
