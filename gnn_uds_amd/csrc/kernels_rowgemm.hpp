@@ -59,6 +59,66 @@ __device__ __forceinline__ void glds16_pair(const float *src0, const float *src1
                : "memory", "scc");
 }
 
+// Epilogue of a wave-tile: bias + activation, whole-row stores.  `tile` is the wave's 16 x LD staging tile in LDS.
+template <int MB, int NB>
+__device__ __forceinline__ void rowgemm_epilogue(const RowGemmArgs &a, f32x4 (&acc)[NB][MB], int base, int nv, float *tile,
+                                                 const float *bias_s, int lane) {
+  constexpr int CG = MB >= 2 ? 2 : 1;
+  constexpr int LD = 16 * CG + 4;
+  const int r16 = lane & 15, qd = lane >> 4;
+  with_act(a.act, [&](auto act_) {
+    constexpr int ACT_ = decltype(act_)::value;
+  if (a.fo == 16 * MB && MB >= 2) {
+    // turn each 16 x 32 accumulator pair through the wave's tile so that one store instruction writes 8 rows x 128 B
+    // (whole cache lines; 1 KiB contiguous when fo = 32) instead of sixteen 64-byte pieces
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int g = 0; g < MB / CG; ++g) {
+#pragma unroll
+        for (int mm = 0; mm < CG; ++mm) {
+          const int m = g * CG + mm;
+          const f32x4 bb = *reinterpret_cast<const f32x4 *>(bias_s + 16 * m + 4 * qd);
+          f32x4 o = acc[b][m];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = act_ct<ACT_>(o[j] + bb[j], a.act);
+          *reinterpret_cast<f32x4 *>(tile + r16 * LD + 16 * mm + 4 * qd) = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int rr = i * 8 + (lane >> 3), cc = 4 * (lane & 7);
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(tile + rr * LD + cc);
+          if (b * 16 + rr < nv) *reinterpret_cast<f32x4 *>(a.out + (int64_t)(base + b * 16 + rr) * a.ldo + a.col0 + 32 * g + cc) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+  } else {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int64_t r = (int64_t)base + b * 16 + r16;
+      if (b * 16 + r16 >= nv) continue;
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        const int c0 = 16 * m + 4 * qd;
+        f32x4 o = acc[b][m];
+        if ((a.fo & 3) == 0) {
+          if (c0 < a.fo) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = act_ct<ACT_>(o[j] + bias_s[c0 + j], a.act);
+            *reinterpret_cast<f32x4 *>(a.out + r * a.ldo + a.col0 + c0) = o;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (c0 + j < a.fo) a.out[r * a.ldo + a.col0 + c0 + j] = act_ct<ACT_>(o[j] + bias_s[c0 + j], a.act);
+        }
+      }
+    }
+  }
+  });
+}
+
 // Persistent 8-wave workgroups, one per CU.  LDS: the packed weights of every k-step and the bias (staged once per
 // workgroup) | per wave a ring of RING 2-KiB slots filled by LDS-DMA in fragment order (the lane that issues a 16-B
 // piece reads it back, so the wave's own counted vmcnt is the only synchronisation) | per wave a 16 x 32 tile that
@@ -105,8 +165,10 @@ __global__ __launch_bounds__(512, 2) void k_rowgemm_mfma(RowGemmArgs a) {
     w = (blockIdx.x >> 3) * 8 + wave;
     w_stride = (gridDim.x >> 3) * 8;
   } else {
+    // wave-major: a problem of fewer than 8 x 256 wave-tiles spreads over all the CUs (one busy wave each) before a
+    // second wave of any workgroup gets work -- the rollout's T = seq_in rows would otherwise sit on two dozen CUs
     w_total = (int)((a.rows + NB * 16 - 1) / (NB * 16));
-    w = blockIdx.x * 8 + wave;
+    w = wave * gridDim.x + blockIdx.x;
     w_stride = gridDim.x * 8;
   }
   if (w >= w_total) return;
@@ -193,58 +255,7 @@ __global__ __launch_bounds__(512, 2) void k_rowgemm_mfma(RowGemmArgs a) {
       }
     }
 
-    with_act(a.act, [&](auto act_) {
-    constexpr int ACT_ = decltype(act_)::value;
-    // ---- epilogue: bias + activation, whole-row stores ----
-    if (a.fo == 16 * MB && MB >= 2) {
-      // turn each 16 x 32 accumulator pair through the wave's tile so that one store instruction writes 8 rows x 128 B
-      // (whole cache lines; 1 KiB contiguous when fo = 32) instead of sixteen 64-byte pieces
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int g = 0; g < MB / CG; ++g) {
-#pragma unroll
-          for (int mm = 0; mm < CG; ++mm) {
-            const int m = g * CG + mm;
-            const f32x4 bb = *reinterpret_cast<const f32x4 *>(bias_s + 16 * m + 4 * qd);
-            f32x4 o = acc[b][m];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = act_ct<ACT_>(o[j] + bb[j], a.act);
-            *reinterpret_cast<f32x4 *>(tile + r16 * LD + 16 * mm + 4 * qd) = o;
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const int rr = i * 8 + (lane >> 3), cc = 4 * (lane & 7);
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(tile + rr * LD + cc);
-            if (b * 16 + rr < nv) *reinterpret_cast<f32x4 *>(a.out + (int64_t)(base + b * 16 + rr) * a.ldo + a.col0 + 32 * g + cc) = v;
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-    } else {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int64_t r = (int64_t)base + b * 16 + r16;
-        if (b * 16 + r16 >= nv) continue;
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-          const int c0 = 16 * m + 4 * qd;
-          f32x4 o = acc[b][m];
-          if ((a.fo & 3) == 0) {
-            if (c0 < a.fo) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) o[j] = act_ct<ACT_>(o[j] + bias_s[c0 + j], a.act);
-              *reinterpret_cast<f32x4 *>(a.out + r * a.ldo + a.col0 + c0) = o;
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (c0 + j < a.fo) a.out[r * a.ldo + a.col0 + c0 + j] = act_ct<ACT_>(o[j] + bias_s[c0 + j], a.act);
-          }
-        }
-      }
-    }
-    });
+    rowgemm_epilogue<MB, NB>(a, acc, base, nv, tile, bias_s, lane);
     base = base_n;
     nv = nv_n;
 #pragma unroll
@@ -254,6 +265,106 @@ __global__ __launch_bounds__(512, 2) void k_rowgemm_mfma(RowGemmArgs a) {
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the dummy pieces land before the LDS is released
+}
+
+// Small problems (the rollout's T = seq_in windows: a few thousand rows).  The persistent kernel above is built for
+// streams: a wave keeps RING-1 pieces in flight and pays one memory latency per RING-1 pieces, so a problem of one
+// wave-tile per wave is a chain of K/32 * NB / (RING-1) latencies (14 us for 12 k rows x 192).  Here a wave owns ONE
+// 16-row block and loads its whole A row (KT k-steps, 8 floats per lane each) into registers up front -- one latency --
+// while the workgroup stages the weights; blocks are dealt wave-major so every CU gets one before any gets two.
+// Same fragment layout, split and MFMA order as k_rowgemm_mfma: bit-identical results.
+template <int MB, int KT>
+__global__ __launch_bounds__(512) void k_rowgemm_small(RowGemmArgs a) {
+  constexpr int CG = MB >= 2 ? 2 : 1;
+  constexpr int LD = 16 * CG + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem_rg[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, qd = lane >> 4;
+  constexpr int n_w = KT * MB * 2 * 64;
+  uint4 *wlds = reinterpret_cast<uint4 *>(smem_rg);
+  float *bias_s = smem_rg + n_w * 4;
+  float *tile = bias_s + 64 + wave * (16 * LD);
+  const int n_blocks = (int)((a.rows + 15) / 16);
+  const int blk = wave * gridDim.x + blockIdx.x;
+  const bool active = blk < n_blocks;
+  const int base = blk * 16;
+  const int nv = active ? (int)min<int64_t>(16, a.rows - base) : 0;
+  float4 v[KT][2];
+  int tx = 0;
+  if (active) {
+    const int rw = base + min(r16, nv - 1);
+    tx = (rw / a.t_rows) % a.T;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const int k0 = 32 * t;
+      const int j = k0 / a.F, f0 = k0 - j * a.F;
+      const int shift = (a.taps - 1 - j) * a.dil;
+      const bool live = tx - shift >= 0 && tx - shift < a.T;
+      const float *src = a.x + (int64_t)(rw - (live ? shift * a.t_rows : 0)) * a.F + f0 + 4 * qd;
+      if (a.x2) src = k0 < a.F1 ? a.x + (int64_t)rw * a.F1 + k0 + 4 * qd : a.x2 + (int64_t)rw * (a.F - a.F1) + (k0 - a.F1) + 4 * qd;
+      v[t][0] = *reinterpret_cast<const float4 *>(src);
+      v[t][1] = *reinterpret_cast<const float4 *>(src + 16);
+    }
+  }
+  for (int i = tid; i < n_w; i += 512) wlds[i] = a.packed[i];
+  if (tid < 64) bias_s[tid] = (a.bias && tid < a.fo) ? a.bias[tid] : 0.f;
+  __syncthreads();
+  if (!active) return;
+  f32x4 acc[1][MB];
+#pragma unroll
+  for (int m = 0; m < MB; ++m) acc[0][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    const int ts = tx - (a.taps - 1 - (32 * t) / a.F) * a.dil;
+    float4 v0 = v[t][0], v1 = v[t][1];
+    if (!(ts >= 0 && ts < a.T)) v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    bf16x8 dh, dl;
+    split8(v0, v1, dh, dl);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const bf16x8 wh = __builtin_bit_cast(bf16x8, wlds[((t * MB + m) * 2 + 0) * 64 + lane]);
+      const bf16x8 wl = __builtin_bit_cast(bf16x8, wlds[((t * MB + m) * 2 + 1) * 64 + lane]);
+      acc[0][m] = mfma3(wh, wl, dh, dl, acc[0][m]);
+    }
+  }
+  rowgemm_epilogue<MB, 1>(a, acc, base, nv, tile, bias_s, lane);
+}
+
+constexpr int64_t ROWGEMM_SMALL_ROWS = 16 * 8 * 256;      // one 16-row block per wave of one workgroup per CU
+
+template <int MB, int KT>
+inline hipError_t launch_rowgemm_small_k(const RowGemmArgs &a, hipStream_t st) {
+  constexpr int cg = MB >= 2 ? 2 : 1;
+  const size_t lds = (size_t)KT * MB * 2 * 1024 + 256 + 8 * 16 * (16 * cg + 4) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowgemm_small<MB, KT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int64_t n_blocks = (a.rows + 15) / 16;
+  const int64_t grid = std::min<int64_t>(256, n_blocks);
+  RowGemmArgs b = a;
+  b.seg = 0;
+  hipLaunchKernelGGL((k_rowgemm_small<MB, KT>), dim3((unsigned)grid), dim3(512), lds, st, b);
+  return hipGetLastError();
+}
+
+// true (and launched) when the problem is small and K / 32 is one of the instantiated depths
+template <int MB>
+inline bool launch_rowgemm_small(const RowGemmArgs &a, hipStream_t st, hipError_t &e) {
+  if (a.rows > ROWGEMM_SMALL_ROWS) return false;
+  switch (a.taps * a.F / 32) {
+    case 2: e = launch_rowgemm_small_k<MB, 2>(a, st); return true;
+    case 3: e = launch_rowgemm_small_k<MB, 3>(a, st); return true;
+    case 4: e = launch_rowgemm_small_k<MB, 4>(a, st); return true;
+    case 6: e = launch_rowgemm_small_k<MB, 6>(a, st); return true;
+    case 9: e = launch_rowgemm_small_k<MB, 9>(a, st); return true;
+    case 12: e = launch_rowgemm_small_k<MB, 12>(a, st); return true;
+    default: return false;
+  }
 }
 
 inline int64_t rowgemm_lds_bytes(int K, int MB, int ring) {
@@ -281,7 +392,7 @@ inline hipError_t launch_rowgemm_r(const RowGemmArgs &a, hipStream_t st) {
   const int64_t lds = rowgemm_lds_bytes(a.taps * a.F, MB, RING);
   RowGemmArgs b = a;
   b.seg = 0;
-  int64_t grid = std::min<int64_t>(256, ((a.rows + WT - 1) / WT + 7) / 8);      // one persistent workgroup per CU
+  int64_t grid = std::min<int64_t>(256, (a.rows + WT - 1) / WT);                // one persistent workgroup per CU
   if (a.taps > 1 && a.t_rows >= 64 * WT) {                 // a slab wide enough to give every XCD several wave-tiles
     b.seg = (int)(((a.t_rows + 7) / 8 + 15) / 16 * 16);
     grid = 256;
@@ -301,6 +412,12 @@ inline hipError_t launch_rowgemm_t(const RowGemmArgs &a, hipStream_t st) {
 inline int rowgemm_mb(int fo) { return fo <= 16 ? 1 : (fo <= 32 ? 2 : 4); }
 
 inline hipError_t launch_rowgemm(const RowGemmArgs &a, hipStream_t st) {
+  hipError_t e = hipSuccess;
+  switch (rowgemm_mb(a.fo)) {
+    case 1: if (launch_rowgemm_small<1>(a, st, e)) return e; break;
+    case 2: if (launch_rowgemm_small<2>(a, st, e)) return e; break;
+    default: if (launch_rowgemm_small<4>(a, st, e)) return e; break;
+  }
   switch (rowgemm_mb(a.fo)) {
     case 1: return launch_rowgemm_t<1, 4>(a, st);
     case 2: return launch_rowgemm_t<2, 4>(a, st);
