@@ -224,7 +224,7 @@ inline hipError_t launch_embed_f(const DenseArgs &a, hipStream_t st) {
 }
 
 inline hipError_t launch_dense_act(const DenseArgs &a, hipStream_t st) {
-  if (a.fb == 0 && a.taps == 0 && a.a_self == nullptr && a.fa <= 8 && (a.fo & 3) == 0 && a.rows >= 4096) {
+  if (a.fb == 0 && a.taps == 0 && a.a_self == nullptr && a.fa <= 8 && (a.fo & 3) == 0 && a.rows >= 64) {
     switch (a.fa) {
       case 1: return launch_embed_f<1>(a, st);
       case 2: return launch_embed_f<2>(a, st);

@@ -198,6 +198,7 @@ class Emulator(nn.Module):
         self._has_pump = bool(float(self.pump.min()) > 0) if self.n_edge else False
         self._has_any_pump = bool(float(self.pump_in.sum() + self.pump_out.sum() + self.pump.sum()) > 0)
         self._idx_cache = {}
+        self._norm_derived = {}
         self._graph = None
 
         d, h, H, L, gen = self.embed_size, self.embed_size // 2, self.hidden_dim, self.n_sp_layer, generator
@@ -304,11 +305,20 @@ class Emulator(nn.Module):
             t = self._norms[item] = t.to(device)
         return t
 
+    def _norm_parts(self, item, dim, device):
+        """(maxi - mini, mini) of the first `dim` channels, computed once per norm tensor (the rollout calls normalize a dozen
+        times per step on constants)."""
+        normal = self._norm(item, device)
+        key = (item, dim, str(device))
+        hit = self._norm_derived.get(key)
+        if hit is None or hit[0] is not normal:
+            maxi, mini = normal[0, ..., :dim], normal[1, ..., :dim]
+            hit = self._norm_derived[key] = (normal, (maxi - mini).contiguous(), mini.contiguous())
+        return hit[1], hit[2]
+
     def normalize(self, dat, item, inverse=False):
-        normal = self._norm(item, dat.device)
-        dim = dat.shape[-1]
-        maxi, mini = normal[0, ..., :dim], normal[1, ..., :dim]
-        return dat * (maxi - mini) + mini if inverse else (dat - mini) / (maxi - mini)
+        span, mini = self._norm_parts(item, dat.shape[-1], dat.device)
+        return dat * span + mini if inverse else (dat - mini) / span
 
     # ------------------------------------------------------------------ actions (:364-398)
     def _act_edge_index(self):
@@ -342,16 +352,17 @@ class Emulator(nn.Module):
         if self._inc_handle is None:
             self._inc_handle = _lib.CsrHandle(self.graph.inc_n)
         ny = self._norm('y', flow.device)
-        s_out = (ny[0, :, 2] > 1e-3).float() / ny[0, :, 2]
-        s_in = (ny[0, :, 1] > 1e-3).float() / ny[0, :, 1]
+        hit = self._norm_derived.get(('flow_scale', str(flow.device)))
+        if hit is None or hit[0] is not ny:
+            hit = self._norm_derived[('flow_scale', str(flow.device))] = (
+                ny, ((ny[0, :, 1] > 1e-3).float() / ny[0, :, 1]).contiguous(), ((ny[0, :, 2] > 1e-3).float() / ny[0, :, 2]).contiguous())
+        s_in, s_out = hit[1], hit[2]
         lead = flow.shape[:-2]
         if _ag.grad_on(flow):
             edges = torch.as_tensor(self.edges, dtype=torch.int64, device=flow.device)
-            q_in, q_out = _ag.FlowBalanceFn.apply(flow.reshape(-1, self.n_edge), self._inc_handle, self._inc_sign,
-                                                  s_in.contiguous(), s_out.contiguous(), edges)
+            q_in, q_out = _ag.FlowBalanceFn.apply(flow.reshape(-1, self.n_edge), self._inc_handle, self._inc_sign, s_in, s_out, edges)
         else:
-            q_in, q_out = _lib.flow_balance(self._inc_handle, self._inc_sign, flow.reshape(-1, self.n_edge).contiguous(),
-                                            s_in.contiguous(), s_out.contiguous())
+            q_in, q_out = _lib.flow_balance(self._inc_handle, self._inc_sign, flow.reshape(-1, self.n_edge).contiguous(), s_in, s_out)
         return q_in.reshape(lead + (self.n_node, 1)), q_out.reshape(lead + (self.n_node, 1))
 
     def post_proc_tf(self, preds, a, b):
@@ -386,7 +397,8 @@ class Emulator(nn.Module):
                 outflow = preds[..., 2] * (flo == 0).float() + flo
                 preds = torch.cat([torch.stack([preds[..., 0], inflow * a_in, outflow * a_out], dim=-1), preds[..., 3:]], dim=-1)
         if self.edge_fusion:
-            flow = self.normalize(edge_preds, 'e', True)[..., -1:]
+            span, mini = self._norm_parts('e', edge_preds.shape[-1], edge_preds.device)
+            flow = edge_preds[..., -1:] * span[..., -1:] + mini[..., -1:]        # de-normalised flow channel only
             q_in, q_out = self._flow_balance(flow)
             preds = torch.cat([preds[..., :1], q_in, q_out, preds[..., 1:]], dim=-1)
         return preds, edge_preds
