@@ -341,7 +341,8 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': recorded_traffic(args),
                          'algorithmic_bytes_per_launch': S * bytes_gs, 'launch_ms': dev_ms / L,
-                         'kernel': 'k_fused_tile<64,64,relu> (one launch per layer over S snapshots)' if args.precision == 'bf16x3' else
+                         'kernel': ('k_fused_cs<128,128,128,8,relu>' if d == 128 else 'k_fused_tile<64,64,relu>') +
+                                   ' (one launch per layer over S snapshots)' if args.precision == 'bf16x3' else
                                    'uds_spatial_layer_forward, unfused (8 launches per layer over S snapshots)',
                          'algorithmic_bytes_per_graph_step': bytes_gs, 'device_ms_per_step': dev_ms},
         }

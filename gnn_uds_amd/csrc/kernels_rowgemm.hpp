@@ -60,7 +60,7 @@ __device__ __forceinline__ void glds16_pair(const float *src0, const float *src1
 }
 
 // Epilogue of a wave-tile: bias + activation, whole-row stores.  `tile` is the wave's 16 x LD staging tile in LDS.
-template <int MB, int NB>
+template <int MB, int NB, bool STAGE = true>
 __device__ __forceinline__ void rowgemm_epilogue(const RowGemmArgs &a, f32x4 (&acc)[NB][MB], int base, int nv, float *tile,
                                                  const float *bias_s, int lane) {
   constexpr int CG = MB >= 2 ? 2 : 1;
@@ -132,7 +132,9 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemmArgs &a, f32x4 (&a
 // the last tile, so the count never changes) and then waits for vmcnt <= 2 (RING-1).  The output stores of a finished
 // tile are younger than the pieces already in flight, so this wait is at worst conservative (it may also wait for some
 // stores), never too weak.
-template <int MB, int NB, int RING>
+// STAGE = false drops the per-wave output tile (direct 64-byte stores from the accumulators): 18 KiB of LDS that buy a
+// deeper ring when the weights are large (K = 384, the first Conv1D of a d = 128 emulator: ring 3 instead of 2).
+template <int MB, int NB, int RING, bool STAGE = true>
 __global__ __launch_bounds__(512, 2) void k_rowgemm_mfma(RowGemmArgs a) {
   static_assert(RING - 1 <= NB && RING >= 2, "the ring may reach at most one k-step ahead");
   constexpr int CG = MB >= 2 ? 2 : 1;            // accumulator fragments per transposed store group (32 columns)
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void k_rowgemm_mfma(RowGemmArgs a) {
       }
     }
 
-    rowgemm_epilogue<MB, NB>(a, acc, base, nv, tile, bias_s, lane);
+    rowgemm_epilogue<MB, NB, STAGE>(a, acc, base, nv, tile, bias_s, lane);
     base = base_n;
     nv = nv_n;
 #pragma unroll
@@ -367,29 +369,30 @@ inline bool launch_rowgemm_small(const RowGemmArgs &a, hipStream_t st, hipError_
   }
 }
 
-inline int64_t rowgemm_lds_bytes(int K, int MB, int ring) {
+inline int64_t rowgemm_lds_bytes(int K, int MB, int ring, bool stage = true) {
   const int cg = MB >= 2 ? 2 : 1;
-  return (int64_t)(K / 32) * MB * 2 * 1024 + 256 + 8 * ring * 2048 + 8 * 16 * (16 * cg + 4) * 4;
+  return (int64_t)(K / 32) * MB * 2 * 1024 + 256 + 8 * ring * 2048 + (stage ? 8 * 16 * (16 * cg + 4) * 4 : 0);
 }
-// deepest ring (5, 3, else 2) that fits the LDS next to the weights; 0 = the weights alone are too large
+// deepest ring (5, 3, 3 without the output tile = -3, else 2) that fits the LDS next to the weights; 0 = the weights alone are too large
 inline int rowgemm_ring(int K, int MB) {
   if (rowgemm_lds_bytes(K, MB, 5) <= 160 * 1024) return 5;
   if (rowgemm_lds_bytes(K, MB, 3) <= 160 * 1024) return 3;
+  if (rowgemm_lds_bytes(K, MB, 3, false) <= 160 * 1024) return -3;
   if (rowgemm_lds_bytes(K, MB, 2) <= 160 * 1024) return 2;
   return 0;
 }
 
-template <int MB, int NB, int RING>
+template <int MB, int NB, int RING, bool STAGE = true>
 inline hipError_t launch_rowgemm_r(const RowGemmArgs &a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowgemm_mfma<MB, NB, RING>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowgemm_mfma<MB, NB, RING, STAGE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   constexpr int64_t WT = NB * 16;                          // rows of a wave-tile
-  const int64_t lds = rowgemm_lds_bytes(a.taps * a.F, MB, RING);
+  const int64_t lds = rowgemm_lds_bytes(a.taps * a.F, MB, RING, STAGE);
   RowGemmArgs b = a;
   b.seg = 0;
   int64_t grid = std::min<int64_t>(256, (a.rows + WT - 1) / WT);                // one persistent workgroup per CU
@@ -397,7 +400,7 @@ inline hipError_t launch_rowgemm_r(const RowGemmArgs &a, hipStream_t st) {
     b.seg = (int)(((a.t_rows + 7) / 8 + 15) / 16 * 16);
     grid = 256;
   }
-  hipLaunchKernelGGL((k_rowgemm_mfma<MB, NB, RING>), dim3((unsigned)grid), dim3(512), (size_t)lds, st, b);
+  hipLaunchKernelGGL((k_rowgemm_mfma<MB, NB, RING, STAGE>), dim3((unsigned)grid), dim3(512), (size_t)lds, st, b);
   return hipGetLastError();
 }
 
@@ -406,6 +409,7 @@ inline hipError_t launch_rowgemm_t(const RowGemmArgs &a, hipStream_t st) {
   const int ring = rowgemm_ring(a.taps * a.F, MB);
   if (ring == 5) return launch_rowgemm_r<MB, NB, 5>(a, st);
   if (ring == 3) return launch_rowgemm_r<MB, NB, 3>(a, st);
+  if (ring == -3) return launch_rowgemm_r<MB, NB, 3, false>(a, st);
   return launch_rowgemm_r<MB, NB, 2>(a, st);      // e.g. the 3 x 128 -> 64 Conv1D of a d = 128 emulator: 96 KB of weights
 }
 

@@ -373,7 +373,7 @@ int uds_rowgemm_forward_cat(const float *x, int64_t F1, const float *x2, int64_t
               (long long)T, (long long)R, (long long)F, (long long)taps, (long long)f_out);
   UDS_REQUIRE(act >= UDS_ACT_LINEAR && act <= UDS_ACT_HARD_SIGMOID, "uds_rowgemm_forward: unknown activation %d", act);
   UDS_REQUIRE(aligned16(x) && aligned16(packed) && aligned16(out) && aligned16(bias), "uds_rowgemm_forward: pointers must be 16-byte aligned");
-  UDS_REQUIRE(uds::rowgemm_ring((int)(taps * F), uds::rowgemm_mb((int)f_out)) > 0,
+  UDS_REQUIRE(uds::rowgemm_ring((int)(taps * F), uds::rowgemm_mb((int)f_out)) != 0,
               "uds_rowgemm_forward: K=%lld x f_out=%lld weights do not fit the LDS", (long long)(taps * F), (long long)f_out);
   UDS_REQUIRE(B * T * R < INT32_MAX, "uds_rowgemm_forward: %lld rows exceed the int32 row index", (long long)(B * T * R));
   if (B == 0) return UDS_OK;
