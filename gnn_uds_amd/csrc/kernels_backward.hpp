@@ -43,6 +43,46 @@ __global__ __launch_bounds__(256) void k_gat_bwd_rows(GatBwdRowsArgs a) {
   float m = -INFINITY;
   for (int p = beg; p < end; ++p) m = fmaxf(m, leaky02(ss + sn[a.col[p]]));
   float den = 0.f, cn = 0.f;
+  if (end - beg <= a.G) {
+    // the usual case (degree <= lanes per row): lane k of the row keeps entry k's (exp, q, logit sign) in registers, the
+    // row sums are known to every lane after the loop, and the lanes write alpha / de of their entries side by side --
+    // no second walk through memory by one lane.  Same operation order per value as the general path below.
+    float wk = 0.f, qk = 0.f;
+    bool pos = false;
+    for (int p = beg; p < end; ++p) {
+      const int j = a.col[p];
+      const float lgt = ss + sn[j];
+      const float w = expf(leaky02(lgt) - m);
+      float q = 0.f;
+      for (int c = lg; c < a.d4; c += a.G) {
+        const float4 gv = g4[c], hv = hx4[(int64_t)j * a.d4 + c];
+        q = fmaf(gv.x, hv.x, fmaf(gv.y, hv.y, fmaf(gv.z, hv.z, fmaf(gv.w, hv.w, q))));
+      }
+      for (int o = a.G >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o);
+      den += w;
+      cn = fmaf(w, q, cn);
+      if (p - beg == lg) {
+        wk = w;
+        qk = q;
+        pos = lgt > 0.0f;
+      }
+    }
+    const float inv = end > beg ? 1.0f / den : 0.0f;
+    const float cbar = cn * inv;
+    const bool mine = lg < end - beg;
+    const float w = wk * inv;
+    const float dl = w * (qk - cbar);
+    const float dv = mine ? (pos ? dl : 0.2f * dl) : 0.f;
+    if (mine && row_ok) {
+      al[beg + lg] = w;
+      de[beg + lg] = dv;
+    }
+    // ds_self = sum of the row's de in entry order (the order the one-lane walk below adds them in)
+    float dss = 0.f;
+    for (int k = 0; k < end - beg; ++k) dss += __shfl(dv, k, a.G);
+    if (lg == 0 && row_ok) a.ds_self[(int64_t)s * a.n + i] = dss;
+    return;
+  }
   for (int p = beg; p < end; ++p) {
     const int j = a.col[p];
     const float w = expf(leaky02(ss + sn[j]) - m);
@@ -74,7 +114,117 @@ __global__ __launch_bounds__(256) void k_gat_bwd_rows(GatBwdRowsArgs a) {
   a.ds_self[(int64_t)s * a.n + i] = dss;
 }
 
+// Grouped variant (see kernels_sparse.hpp): the G lanes of a row load G entries' indices and scores side by side, each
+// lane ends up holding (exp, q, sign) of "its" entry, and alpha / de are written side by side.  Rows of more than G entries
+// park the raw (exp, q) pairs in alpha / de per chunk and finish them in a second walk (same lane wrote them).
+template <int G, int NC>
+__global__ __launch_bounds__(256) void k_gat_bwd_rows_g(GatBwdRowsArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c = (int)(t % G);
+  const int64_t r = t / G;
+  const bool row_ok = r < a.n;
+  const int i = (int)(row_ok ? r : a.n - 1);
+  const int s = blockIdx.y;
+  const int beg = a.rowptr[i], end = a.rowptr[i + 1];
+  const float *sn = a.s_nbr + (int64_t)s * a.n;
+  const float ss = a.s_self[(int64_t)s * a.n + i];
+  const float4 *g4 = reinterpret_cast<const float4 *>(a.g) + ((int64_t)s * a.n + i) * a.d4 + c;
+  const float4 *hx4 = reinterpret_cast<const float4 *>(a.hx) + (int64_t)s * a.n * a.d4 + c;
+  float *al = a.alpha + (int64_t)s * a.nnz, *de = a.de + (int64_t)s * a.nnz;
+  float4 gv[NC];
+#pragma unroll
+  for (int q = 0; q < NC; ++q) gv[q] = g4[G * q];
+  float m = -INFINITY, l0 = 0.f;
+  int j0 = 0;
+  for (int b0 = beg; b0 < end; b0 += G) {
+    const int p = b0 + c;
+    const int j = a.col[min(p, end - 1)];
+    const float lgt = ss + sn[j];
+    if (b0 == beg) {
+      j0 = j;
+      l0 = lgt;
+    }
+    m = fmaxf(m, p < end ? leaky02(lgt) : -INFINITY);
+  }
+  m = group_max<G>(m);
+  const bool single = end - beg <= G;
+  float den = 0.f, cn = 0.f, wk = 0.f, qk = 0.f, lk = 0.f;
+  for (int b0 = beg; b0 < end; b0 += G) {
+    const int p = b0 + c;
+    int j = j0;
+    float lgt = l0;
+    if (b0 != beg) {
+      j = a.col[min(p, end - 1)];
+      lgt = ss + sn[j];
+    }
+    const float w = p < end ? expf(leaky02(lgt) - m) : 0.f;
+    const int nk = min(G, end - b0);
+    float qm = 0.f;
+    for (int k = 0; k < nk; ++k) {
+      const int jj = __shfl(j, k, G);
+      const float ww = __shfl(w, k, G);
+      float q = 0.f;
+#pragma unroll
+      for (int u = 0; u < NC; ++u) {      // the one-lane-per-chunk kernel adds a lane's chunks c, c + G, .. in this order
+        const float4 hv = hx4[(int64_t)jj * a.d4 + G * u];
+        q = fmaf(gv[u].x, hv.x, fmaf(gv[u].y, hv.y, fmaf(gv[u].z, hv.z, fmaf(gv[u].w, hv.w, q))));
+      }
+#pragma unroll
+      for (int o = G >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o);
+      den += ww;
+      cn = fmaf(ww, q, cn);
+      if (k == c) qm = q;
+    }
+    if (single) {
+      wk = w;
+      qk = qm;
+      lk = lgt;
+    } else if (p < end && row_ok) {
+      al[p] = w;
+      de[p] = qm;
+    }
+  }
+  const float inv = end > beg ? 1.0f / den : 0.0f;
+  const float cbar = cn * inv;
+  if (single) {
+    const bool mine = c < end - beg;
+    const float w = wk * inv;
+    const float dl = w * (qk - cbar);
+    const float dv = mine ? (lk > 0.0f ? dl : 0.2f * dl) : 0.f;
+    if (mine && row_ok) {
+      al[beg + c] = w;
+      de[beg + c] = dv;
+    }
+    float dss = 0.f;
+    for (int k = 0; k < end - beg; ++k) dss += __shfl(dv, k, G);      // entry order, as the one-lane walk adds them
+    if (c == 0 && row_ok) a.ds_self[(int64_t)s * a.n + i] = dss;
+    return;
+  }
+  float dss = 0.f;
+  for (int b0 = beg; b0 < end; b0 += G) {
+    const int p = b0 + c;
+    float dv = 0.f;
+    if (p < end && row_ok) {
+      const float w = al[p] * inv;
+      const float dl = w * (de[p] - cbar);
+      dv = ss + sn[a.col[p]] > 0.0f ? dl : 0.2f * dl;
+      al[p] = w;
+      de[p] = dv;
+    }
+    dss += dv;
+  }
+#pragma unroll
+  for (int o = G >> 1; o > 0; o >>= 1) dss += __shfl_xor(dss, o);
+  if (c == 0 && row_ok) a.ds_self[(int64_t)s * a.n + i] = dss;
+}
+
 inline hipError_t launch_gat_bwd_rows(const GatBwdRowsArgs &a, hipStream_t st) {
+  int G, NC;
+  group_shape(a.d4, G, NC);
+  if (G && a.n > 0)
+    return launch_grouped(a, a.n, a.S, a.d4, st, [&](auto g_, auto nc_, dim3 grid) {
+      hipLaunchKernelGGL((k_gat_bwd_rows_g<decltype(g_)::value, decltype(nc_)::value>), grid, dim3(256), 0, st, a);
+    });
   const int64_t total = (int64_t)a.n * a.G;
   hipLaunchKernelGGL(k_gat_bwd_rows, dim3((unsigned)((total + 255) / 256), (unsigned)a.S), dim3(256), 0, st, a);
   return hipGetLastError();
@@ -119,7 +269,62 @@ __global__ __launch_bounds__(256) void k_gat_bwd_cols(GatBwdColsArgs a) {
   if (c == 0) a.ds_nbr[(int64_t)s * a.n + j] = dsn;
 }
 
+template <int G, int NC>
+__global__ __launch_bounds__(256) void k_gat_bwd_cols_g(GatBwdColsArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c = (int)(t % G);
+  const int64_t r = t / G;
+  const bool row_ok = r < a.n;
+  const int j = (int)(row_ok ? r : a.n - 1);
+  const int s = blockIdx.y;
+  const float4 *g4 = reinterpret_cast<const float4 *>(a.g) + (int64_t)s * a.n * a.d4 + c;
+  const float *al = a.alpha + (int64_t)s * a.nnz, *de = a.de + (int64_t)s * a.nnz;
+  float4 acc[NC];
+#pragma unroll
+  for (int q = 0; q < NC; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dsn = 0.f;
+  const int beg = a.rowptr_t[j], end = a.rowptr_t[j + 1];
+  for (int b0 = beg; b0 < end; b0 += G) {
+    const int p = min(b0 + c, end - 1);
+    const int i = a.col_t[p], k = a.perm_t[p];
+    const float w = al[k], d = de[k];
+    const int nk = min(G, end - b0);
+    for (int e = 0; e < nk; ++e) {
+      const int ii = __shfl(i, e, G);
+      const float ww = __shfl(w, e, G);
+      dsn += __shfl(d, e, G);
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        const float4 gv = g4[(int64_t)ii * a.d4 + G * q];
+        acc[q].x = fmaf(ww, gv.x, acc[q].x);
+        acc[q].y = fmaf(ww, gv.y, acc[q].y);
+        acc[q].z = fmaf(ww, gv.z, acc[q].z);
+        acc[q].w = fmaf(ww, gv.w, acc[q].w);
+      }
+    }
+  }
+  if (!row_ok) return;
+  const float dss = a.ds_self[(int64_t)s * a.n + j];
+#pragma unroll
+  for (int q = 0; q < NC; ++q) {
+    const float4 as = reinterpret_cast<const float4 *>(a.a_self)[c + G * q], an = reinterpret_cast<const float4 *>(a.a_nbr)[c + G * q];
+    float4 o;
+    o.x = fmaf(an.x, dsn, fmaf(as.x, dss, acc[q].x));
+    o.y = fmaf(an.y, dsn, fmaf(as.y, dss, acc[q].y));
+    o.z = fmaf(an.z, dsn, fmaf(as.z, dss, acc[q].z));
+    o.w = fmaf(an.w, dsn, fmaf(as.w, dss, acc[q].w));
+    reinterpret_cast<float4 *>(a.d_hx)[((int64_t)s * a.n + j) * a.d4 + c + G * q] = o;
+  }
+  if (c == 0) a.ds_nbr[(int64_t)s * a.n + j] = dsn;
+}
+
 inline hipError_t launch_gat_bwd_cols(const GatBwdColsArgs &a, hipStream_t st) {
+  int G, NC;
+  group_shape(a.d4, G, NC);
+  if (G && a.n > 0)
+    return launch_grouped(a, a.n, a.S, a.d4, st, [&](auto g_, auto nc_, dim3 grid) {
+      hipLaunchKernelGGL((k_gat_bwd_cols_g<decltype(g_)::value, decltype(nc_)::value>), grid, dim3(256), 0, st, a);
+    });
   const int64_t total = (int64_t)a.n * a.d4;
   hipLaunchKernelGGL(k_gat_bwd_cols, dim3((unsigned)((total + 255) / 256), (unsigned)a.S), dim3(256), 0, st, a);
   return hipGetLastError();

@@ -52,7 +52,100 @@ __global__ __launch_bounds__(256) void k_csr_spmm(SpmmArgs a) {
   reinterpret_cast<float4 *>(a.out)[((int64_t)s * a.n_rows + i) * a.f4 + c] = acc;
 }
 
+// Grouped variants (the ones that run when the row is G * NC float4 chunks wide, G a power of two <= 16).  The kernels
+// above walk a row's entries with one dependent load chain per entry and lane (col[p] -> x[col[p]]): ~2 memory latencies
+// per entry, 18 per GAT row -- at 2 M rows (the C5 training batch) that chain, not the bandwidth, was the run time.  Here
+// the G lanes of a row load G entries' indices / weights / scores side by side (one latency), the softmax terms are
+// computed once per entry instead of once per lane, and (index, weight) pairs reach the row's lanes by shuffles, so the
+// feature-row gathers of a row are independent loads.  Values are accumulated in entry order exactly as above:
+// bit-identical results.
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int o = G >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+template <int G, int NC>
+__global__ __launch_bounds__(256) void k_csr_spmm_g(SpmmArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t grp = t / G;
+  const int c = (int)(t % G);
+  const bool row_ok = grp < a.n_rows;
+  const int i = a.order[row_ok ? grp : a.n_rows - 1];       // surplus groups shadow the last row (they take part in the shuffles)
+  const int s = blockIdx.y;
+  const int beg = a.rowptr[i], end = a.rowptr[i + 1];
+  const float4 *x4 = reinterpret_cast<const float4 *>(a.x) + (int64_t)s * a.n_cols * a.f4 + c;
+  float4 acc[NC];
+#pragma unroll
+  for (int q = 0; q < NC; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b0 = beg; b0 < end; b0 += G) {
+    const int p = min(b0 + c, end - 1);
+    const int j = a.col[p];
+    const float v = a.val ? a.val[p] : 1.0f;
+    const int nk = min(G, end - b0);
+    for (int k = 0; k < nk; ++k) {
+      const int jj = __shfl(j, k, G);
+      const float vv = __shfl(v, k, G);
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        const float4 xv = x4[(int64_t)jj * a.f4 + G * q];
+        acc[q].x = fmaf(vv, xv.x, acc[q].x);
+        acc[q].y = fmaf(vv, xv.y, acc[q].y);
+        acc[q].z = fmaf(vv, xv.z, acc[q].z);
+        acc[q].w = fmaf(vv, xv.w, acc[q].w);
+      }
+    }
+  }
+  if (!row_ok) return;
+#pragma unroll
+  for (int q = 0; q < NC; ++q) {
+    float4 o = acc[q];
+    if (a.bias) {
+      const float4 b = reinterpret_cast<const float4 *>(a.bias)[c + G * q];
+      o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+    }
+    with_act(a.act, [&](auto act_) {
+      constexpr int A = decltype(act_)::value;
+      o.x = act_ct<A>(o.x, a.act);
+      o.y = act_ct<A>(o.y, a.act);
+      o.z = act_ct<A>(o.z, a.act);
+      o.w = act_ct<A>(o.w, a.act);
+    });
+    reinterpret_cast<float4 *>(a.out)[((int64_t)s * a.n_rows + i) * a.f4 + c + G * q] = o;
+  }
+}
+
+// (G, NC) of a row of f4 float4 chunks; G = 0: no grouped instance (odd widths take the one-lane-per-chunk kernels)
+inline void group_shape(int f4, int &G, int &NC) {
+  G = 0;
+  NC = 1;
+  if (f4 == 2 || f4 == 4 || f4 == 8 || f4 == 16) G = f4;
+  else if (f4 == 32) { G = 16; NC = 2; }
+}
+
+template <class Args, class F>
+inline hipError_t launch_grouped(const Args &a, int64_t rows, int S, int f4, hipStream_t st, F &&pick) {
+  int G, NC;
+  group_shape(f4, G, NC);
+  const dim3 grid((unsigned)((rows * G + 255) / 256), (unsigned)S);
+  switch (G * 4 + NC) {
+    case 2 * 4 + 1: pick(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, grid); break;
+    case 4 * 4 + 1: pick(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{}, grid); break;
+    case 8 * 4 + 1: pick(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{}, grid); break;
+    case 16 * 4 + 1: pick(std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{}, grid); break;
+    default: pick(std::integral_constant<int, 16>{}, std::integral_constant<int, 2>{}, grid); break;
+  }
+  return hipGetLastError();
+}
+
 inline hipError_t launch_csr_spmm(const SpmmArgs &a, hipStream_t st) {
+  int G, NC;
+  group_shape(a.f4, G, NC);
+  if (G && a.n_rows > 0)
+    return launch_grouped(a, a.n_rows, a.S, a.f4, st, [&](auto g_, auto nc_, dim3 grid) {
+      hipLaunchKernelGGL((k_csr_spmm_g<decltype(g_)::value, decltype(nc_)::value>), grid, dim3(256), 0, st, a);
+    });
   const int64_t per_snap = (int64_t)a.n_rows * a.f4;
   hipLaunchKernelGGL(k_csr_spmm, dim3((unsigned)((per_snap + 255) / 256), (unsigned)a.S), dim3(256), 0, st, a);
   return hipGetLastError();
@@ -108,7 +201,85 @@ __global__ __launch_bounds__(256) void k_gat_aggregate(GatArgs a) {
   reinterpret_cast<float4 *>(a.out)[((int64_t)s * a.n + i) * a.d4 + c] = o;
 }
 
+template <int G, int NC>
+__global__ __launch_bounds__(256) void k_gat_aggregate_g(GatArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t grp = t / G;
+  const int c = (int)(t % G);
+  const bool row_ok = grp < a.n;
+  const int i = a.order[row_ok ? grp : a.n - 1];
+  const int s = blockIdx.y;
+  const int beg = a.rowptr[i], end = a.rowptr[i + 1];
+  const float *sn = a.s_nbr + (int64_t)s * a.n;
+  const float ss = a.s_self[(int64_t)s * a.n + i];
+  // pass 1: row maximum of the logits; the single-chunk row (degree <= G, the usual case) keeps its logits for pass 2
+  float m = -INFINITY, l0 = -INFINITY;
+  int j0 = 0;
+  for (int b0 = beg; b0 < end; b0 += G) {
+    const int p = b0 + c;
+    const int j = a.col[min(p, end - 1)];
+    const float l = p < end ? leaky02(ss + sn[j]) : -INFINITY;
+    if (b0 == beg) {
+      j0 = j;
+      l0 = l;
+    }
+    m = fmaxf(m, l);
+  }
+  m = group_max<G>(m);
+  const float4 *hx4 = reinterpret_cast<const float4 *>(a.hx) + (int64_t)s * a.n * a.d4 + c;
+  float den = 0.0f;
+  float4 acc[NC];
+#pragma unroll
+  for (int q = 0; q < NC; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b0 = beg; b0 < end; b0 += G) {
+    const int p = b0 + c;
+    int j = j0;
+    float l = l0;
+    if (b0 != beg) {
+      j = a.col[min(p, end - 1)];
+      l = p < end ? leaky02(ss + sn[j]) : -INFINITY;
+    }
+    const float w = expf(l - m);                  // one exp per entry (lanes past the row's end hold exp(-inf) = 0, unused)
+    const int nk = min(G, end - b0);
+    for (int k = 0; k < nk; ++k) {
+      const int jj = __shfl(j, k, G);
+      const float ww = __shfl(w, k, G);
+      den += ww;
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        const float4 hv = hx4[(int64_t)jj * a.d4 + G * q];
+        acc[q].x = fmaf(ww, hv.x, acc[q].x);
+        acc[q].y = fmaf(ww, hv.y, acc[q].y);
+        acc[q].z = fmaf(ww, hv.z, acc[q].z);
+        acc[q].w = fmaf(ww, hv.w, acc[q].w);
+      }
+    }
+  }
+  if (!row_ok) return;
+  const float inv = end > beg ? 1.0f / den : 0.0f;
+#pragma unroll
+  for (int q = 0; q < NC; ++q) {
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) b = reinterpret_cast<const float4 *>(a.bias)[c + G * q];
+    float4 o;
+    with_act(a.act, [&](auto act_) {
+      constexpr int A = decltype(act_)::value;
+      o.x = act_ct<A>(fmaf(acc[q].x, inv, b.x), a.act);
+      o.y = act_ct<A>(fmaf(acc[q].y, inv, b.y), a.act);
+      o.z = act_ct<A>(fmaf(acc[q].z, inv, b.z), a.act);
+      o.w = act_ct<A>(fmaf(acc[q].w, inv, b.w), a.act);
+    });
+    reinterpret_cast<float4 *>(a.out)[((int64_t)s * a.n + i) * a.d4 + c + G * q] = o;
+  }
+}
+
 inline hipError_t launch_gat_aggregate(const GatArgs &a, hipStream_t st) {
+  int G, NC;
+  group_shape(a.d4, G, NC);
+  if (G && a.n > 0)
+    return launch_grouped(a, a.n, a.S, a.d4, st, [&](auto g_, auto nc_, dim3 grid) {
+      hipLaunchKernelGGL((k_gat_aggregate_g<decltype(g_)::value, decltype(nc_)::value>), grid, dim3(256), 0, st, a);
+    });
   const int64_t per_snap = (int64_t)a.n * a.d4;
   hipLaunchKernelGGL(k_gat_aggregate, dim3((unsigned)((per_snap + 255) / 256), (unsigned)a.S), dim3(256), 0, st, a);
   return hipGetLastError();

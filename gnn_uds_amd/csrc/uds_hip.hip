@@ -238,12 +238,15 @@ int uds_csr_create(const int32_t *rowptr, const int32_t *col, int64_t n_rows, in
   c->host.n_cols = n_cols;
   c->host.rowptr.assign(rowptr, rowptr + n_rows + 1);
   c->host.col.assign(col, col + nnz);
-  // degree-sorted schedule: descending degree, ties by row index (stable)
+  // degree-sorted schedule inside windows of 1024 consecutive rows: descending degree, ties by row index (stable).
+  // Windowed so that neighbouring workgroups gather neighbouring rows (L2 hits); a global sort scatters them.
+  constexpr int64_t ORDER_WINDOW = 1024;
   c->h_order.resize(n_rows);
   std::iota(c->h_order.begin(), c->h_order.end(), 0);
-  std::stable_sort(c->h_order.begin(), c->h_order.end(), [&](int32_t a, int32_t b) {
-    return (rowptr[a + 1] - rowptr[a]) > (rowptr[b + 1] - rowptr[b]);
-  });
+  for (int64_t r0 = 0; r0 < n_rows; r0 += ORDER_WINDOW)
+    std::stable_sort(c->h_order.begin() + r0, c->h_order.begin() + std::min(n_rows, r0 + ORDER_WINDOW), [&](int32_t a, int32_t b) {
+      return (rowptr[a + 1] - rowptr[a]) > (rowptr[b + 1] - rowptr[b]);
+    });
   auto cleanup = [&](int code) {
     hipFree(c->d_rowptr);
     hipFree(c->d_col);

@@ -51,11 +51,19 @@ class CSR:
         out[self.rows(), self.col.astype(np.int64)] = 1.0 if self.val is None else self.val
         return out
 
+    ORDER_WINDOW = 1024
+
     def degree_sorted_rows(self):
-        """Row schedule used by the kernels: rows by descending degree, ties in row
-        order (stable), so a wave's lanes see equal trip counts."""
+        """Row schedule used by the kernels: inside every window of ORDER_WINDOW consecutive rows, rows by descending
+        degree, ties in row order (stable), so a wave's lanes see equal trip counts while neighbouring workgroups
+        still work on neighbouring rows (a global sort scatters the gathers of a 2M-row batch over the whole array:
+        every neighbour row then comes from HBM instead of L2)."""
         deg = self.degrees().astype(np.int64)
-        return np.argsort(-deg, kind='stable').astype(I32)
+        out = np.empty(self.n_rows, dtype=I32)
+        for r0 in range(0, self.n_rows, self.ORDER_WINDOW):
+            r1 = min(self.n_rows, r0 + self.ORDER_WINDOW)
+            out[r0:r1] = r0 + np.argsort(-deg[r0:r1], kind='stable')
+        return out
 
 
 def _csr_from_pairs(rows, cols, n_rows, n_cols, val=None):
