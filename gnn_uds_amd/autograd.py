@@ -25,7 +25,7 @@ def act_grad(y, gy, act):
     if act == 'linear':
         return gy
     if act == 'relu':
-        return gy * (y > 0).to(gy.dtype)
+        return torch.ops.aten.threshold_backward(gy, y, 0.0)        # gy where y > 0 else 0, one kernel (no mask tensor)
     if act == 'tanh':
         return gy * (1.0 - y * y)
     if act == 'sigmoid':
