@@ -160,20 +160,36 @@ __global__ __launch_bounds__(256) void k_gat_bwd_rows_g(GatBwdRowsArgs a) {
     const float w = p < end ? expf(leaky02(lgt) - m) : 0.f;
     const int nk = min(G, end - b0);
     float qm = 0.f;
-    for (int k = 0; k < nk; ++k) {
-      const int jj = __shfl(j, k, G);
-      const float ww = __shfl(w, k, G);
-      float q = 0.f;
+    for (int k0 = 0; k0 < nk; k0 += GU) {
+      float ww[GU], qq[GU];
+      float4 hv[GU][NC];
 #pragma unroll
-      for (int u = 0; u < NC; ++u) {      // the one-lane-per-chunk kernel adds a lane's chunks c, c + G, .. in this order
-        const float4 hv = hx4[(int64_t)jj * a.d4 + G * u];
-        q = fmaf(gv[u].x, hv.x, fmaf(gv[u].y, hv.y, fmaf(gv[u].z, hv.z, fmaf(gv[u].w, hv.w, q))));
+      for (int u = 0; u < GU; ++u) {
+        const int k = min(k0 + u, nk - 1);
+        const int jj = __shfl(j, k, G);
+        ww[u] = __shfl(w, k, G);
+#pragma unroll
+        for (int v = 0; v < NC; ++v) hv[u][v] = hx4[(int64_t)jj * a.d4 + G * v];
       }
 #pragma unroll
-      for (int o = G >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o);
-      den += ww;
-      cn = fmaf(ww, q, cn);
-      if (k == c) qm = q;
+      for (int u = 0; u < GU; ++u) {
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < NC; ++v)      // the one-lane-per-chunk kernel adds a lane's chunks c, c + G, .. in this order
+          q = fmaf(gv[v].x, hv[u][v].x, fmaf(gv[v].y, hv[u][v].y, fmaf(gv[v].z, hv[u][v].z, fmaf(gv[v].w, hv[u][v].w, q))));
+        qq[u] = q;
+      }
+#pragma unroll
+      for (int o = G >> 1; o > 0; o >>= 1)
+#pragma unroll
+        for (int u = 0; u < GU; ++u) qq[u] += __shfl_xor(qq[u], o);
+#pragma unroll
+      for (int u = 0; u < GU; ++u)
+        if (k0 + u < nk) {
+          den += ww[u];
+          cn = fmaf(ww[u], qq[u], cn);
+          if (k0 + u == c) qm = qq[u];
+        }
     }
     if (single) {
       wk = w;
@@ -289,18 +305,30 @@ __global__ __launch_bounds__(256) void k_gat_bwd_cols_g(GatBwdColsArgs a) {
     const int i = a.col_t[p], k = a.perm_t[p];
     const float w = al[k], d = de[k];
     const int nk = min(G, end - b0);
-    for (int e = 0; e < nk; ++e) {
-      const int ii = __shfl(i, e, G);
-      const float ww = __shfl(w, e, G);
-      dsn += __shfl(d, e, G);
+    for (int e0 = 0; e0 < nk; e0 += GU) {
+      float ww[GU], dd[GU];
+      float4 gv[GU][NC];
 #pragma unroll
-      for (int q = 0; q < NC; ++q) {
-        const float4 gv = g4[(int64_t)ii * a.d4 + G * q];
-        acc[q].x = fmaf(ww, gv.x, acc[q].x);
-        acc[q].y = fmaf(ww, gv.y, acc[q].y);
-        acc[q].z = fmaf(ww, gv.z, acc[q].z);
-        acc[q].w = fmaf(ww, gv.w, acc[q].w);
+      for (int u = 0; u < GU; ++u) {
+        const int e = min(e0 + u, nk - 1);
+        const int ii = __shfl(i, e, G);
+        ww[u] = __shfl(w, e, G);
+        dd[u] = __shfl(d, e, G);
+#pragma unroll
+        for (int q = 0; q < NC; ++q) gv[u][q] = g4[(int64_t)ii * a.d4 + G * q];
       }
+#pragma unroll
+      for (int u = 0; u < GU; ++u)
+        if (e0 + u < nk) {
+          dsn += dd[u];
+#pragma unroll
+          for (int q = 0; q < NC; ++q) {
+            acc[q].x = fmaf(ww[u], gv[u][q].x, acc[q].x);
+            acc[q].y = fmaf(ww[u], gv[u][q].y, acc[q].y);
+            acc[q].z = fmaf(ww[u], gv[u][q].z, acc[q].z);
+            acc[q].w = fmaf(ww[u], gv[u][q].w, acc[q].w);
+          }
+        }
     }
   }
   if (!row_ok) return;

@@ -59,6 +59,8 @@ __global__ __launch_bounds__(256) void k_csr_spmm(SpmmArgs a) {
 // computed once per entry instead of once per lane, and (index, weight) pairs reach the row's lanes by shuffles, so the
 // feature-row gathers of a row are independent loads.  Values are accumulated in entry order exactly as above:
 // bit-identical results.
+constexpr int GU = 4;      // feature-row gathers a lane keeps in flight
+
 template <int G>
 __device__ __forceinline__ float group_max(float v) {
 #pragma unroll
@@ -84,17 +86,28 @@ __global__ __launch_bounds__(256) void k_csr_spmm_g(SpmmArgs a) {
     const int j = a.col[p];
     const float v = a.val ? a.val[p] : 1.0f;
     const int nk = min(G, end - b0);
-    for (int k = 0; k < nk; ++k) {
-      const int jj = __shfl(j, k, G);
-      const float vv = __shfl(v, k, G);
+    for (int k0 = 0; k0 < nk; k0 += GU) {          // GU gathers in flight per lane; entries are still added in order
+      float vv[GU];
+      float4 xv[GU][NC];
 #pragma unroll
-      for (int q = 0; q < NC; ++q) {
-        const float4 xv = x4[(int64_t)jj * a.f4 + G * q];
-        acc[q].x = fmaf(vv, xv.x, acc[q].x);
-        acc[q].y = fmaf(vv, xv.y, acc[q].y);
-        acc[q].z = fmaf(vv, xv.z, acc[q].z);
-        acc[q].w = fmaf(vv, xv.w, acc[q].w);
+      for (int u = 0; u < GU; ++u) {
+        const int k = min(k0 + u, nk - 1);
+        const int jj = __shfl(j, k, G);
+        vv[u] = __shfl(v, k, G);
+#pragma unroll
+        for (int q = 0; q < NC; ++q) xv[u][q] = x4[(int64_t)jj * a.f4 + G * q];
       }
+#pragma unroll
+      for (int u = 0; u < GU; ++u)
+        if (k0 + u < nk) {
+#pragma unroll
+          for (int q = 0; q < NC; ++q) {
+            acc[q].x = fmaf(vv[u], xv[u][q].x, acc[q].x);
+            acc[q].y = fmaf(vv[u], xv[u][q].y, acc[q].y);
+            acc[q].z = fmaf(vv[u], xv[u][q].z, acc[q].z);
+            acc[q].w = fmaf(vv[u], xv[u][q].w, acc[q].w);
+          }
+        }
     }
   }
   if (!row_ok) return;
@@ -241,18 +254,29 @@ __global__ __launch_bounds__(256) void k_gat_aggregate_g(GatArgs a) {
     }
     const float w = expf(l - m);                  // one exp per entry (lanes past the row's end hold exp(-inf) = 0, unused)
     const int nk = min(G, end - b0);
-    for (int k = 0; k < nk; ++k) {
-      const int jj = __shfl(j, k, G);
-      const float ww = __shfl(w, k, G);
-      den += ww;
+    for (int k0 = 0; k0 < nk; k0 += GU) {
+      float ww[GU];
+      float4 hv[GU][NC];
 #pragma unroll
-      for (int q = 0; q < NC; ++q) {
-        const float4 hv = hx4[(int64_t)jj * a.d4 + G * q];
-        acc[q].x = fmaf(ww, hv.x, acc[q].x);
-        acc[q].y = fmaf(ww, hv.y, acc[q].y);
-        acc[q].z = fmaf(ww, hv.z, acc[q].z);
-        acc[q].w = fmaf(ww, hv.w, acc[q].w);
+      for (int u = 0; u < GU; ++u) {
+        const int k = min(k0 + u, nk - 1);
+        const int jj = __shfl(j, k, G);
+        ww[u] = __shfl(w, k, G);
+#pragma unroll
+        for (int q = 0; q < NC; ++q) hv[u][q] = hx4[(int64_t)jj * a.d4 + G * q];
       }
+#pragma unroll
+      for (int u = 0; u < GU; ++u)
+        if (k0 + u < nk) {
+          den += ww[u];
+#pragma unroll
+          for (int q = 0; q < NC; ++q) {
+            acc[q].x = fmaf(ww[u], hv[u][q].x, acc[q].x);
+            acc[q].y = fmaf(ww[u], hv[u][q].y, acc[q].y);
+            acc[q].z = fmaf(ww[u], hv[u][q].z, acc[q].z);
+            acc[q].w = fmaf(ww[u], hv[u][q].w, acc[q].w);
+          }
+        }
     }
   }
   if (!row_ok) return;
