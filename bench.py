@@ -213,7 +213,7 @@ def bench_c5(args, U, dist, world, rank, dev):
         for p in params:
             p.grad = None
         ox, oe = block(x, e)
-        loss = ((ox - tx) ** 2).mean() + ((oe - te) ** 2).mean()
+        loss = torch.nn.functional.mse_loss(ox, tx) + torch.nn.functional.mse_loss(oe, te)      # mean squared error, fused fwd / bwd kernels
         loss.backward()
         D.allreduce_gradients(params)
         opt.step()

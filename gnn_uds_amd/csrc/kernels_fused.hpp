@@ -58,6 +58,7 @@ struct FusedSide {
 struct FusedArgs {
   FusedSide side[2];
   const int32_t *hdr, *pool;
+  const int32_t *sched;      // balanced static schedule (tile_plan.hpp: build_schedule), or nullptr: workgroup = (tile, chunk)
   int n_tiles, S, chunk, p_cap, q_cap, meta_cap, act, side_mask;
   unsigned long long *dbg;   // diagnostic builds only (UDS_PHASE_TIMING): 8 cycle sums per wave
 };
@@ -250,7 +251,26 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
   const int W = gridDim.x, b = blockIdx.x;
   const int q8 = W / 8, r8 = W % 8, xcd = b % 8;
   const int w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
-  const int tile = w % a.n_tiles, chunk_id = w / a.n_tiles;
+  // Work of this workgroup: with a schedule, up to SCHED_MAX_SEG pieces (tile, snapshot range) of equal total cost per
+  // workgroup; else one piece, (tile, chunk) from the grid index.
+  const int32_t *sg = a.sched ? a.sched + w * SCHED_INTS : nullptr;
+  const int n_seg = sg ? sg[0] : 1;
+  bool ran = false;
+  for (int seg = 0; seg < n_seg; ++seg) {
+  int tile, s_begin, s_end;
+  if (sg) {
+    tile = sg[1 + 3 * seg];
+    s_begin = (int)(((int64_t)a.S * sg[2 + 3 * seg] + 32768) >> 16);
+    s_end = (int)(((int64_t)a.S * sg[3 + 3 * seg] + 32768) >> 16);
+    if (s_begin >= s_end) continue;
+    if (ran) __syncthreads();      // the previous piece's readers of meta / hx / the stage are done before they are rewritten
+    ran = true;
+  } else {
+    tile = w % a.n_tiles;
+    const int chunk_id = w / a.n_tiles;
+    s_begin = chunk_id * a.chunk;
+    s_end = min(a.S, (chunk_id + 1) * a.chunk);
+  }
   const int32_t *hd = a.hdr + tile * TILE_HDR_INTS;
   const int n_own = hd[0], n_prim = hd[1], n_sec = hd[2], n_inc = hd[3], pool_off = hd[5], sd = hd[6], meta_len = hd[7];
   if (!((a.side_mask >> sd) & 1)) return;
@@ -338,7 +358,6 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
     p3_dmax[u] = __builtin_amdgcn_readfirstlane(dmx);
   }
 
-  const int s_begin = chunk_id * a.chunk, s_end = min(a.S, (chunk_id + 1) * a.chunk);
   if (s_begin < s_end) {
     for (int blk = wave; blk * 16 < n_sec; blk += NW) dma_sec(blk, s_begin);
     for (int blk = wave; blk * 16 < n_prim; blk += NW) dma_prim(blk, s_begin);
@@ -665,6 +684,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
            ((unsigned long long)n_sec << 48);
   }
 #endif
+  }   // pieces of the schedule
 }
 
 }  // namespace uds

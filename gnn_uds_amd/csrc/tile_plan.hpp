@@ -16,6 +16,7 @@
 // All lists are int32; local CSR indices point into prim / sec.  Tested in tests/test_tile_plan.py.
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <numeric>
 #include <vector>
@@ -356,6 +357,59 @@ inline int64_t fused_lds_bytes(int p_cap, int q_cap, int meta_cap, int h, int d,
   const int64_t cold = (fp > 64 ? (d / 16) * 2 * 1024 : 0) + (fs > 64 ? (h / 16) * 2 * 1024 : 0);   // LDS-resident third k-step
 #endif
   return 4 * ((int64_t)meta_cap + 2 * p_cap + 2 * d + h + (int64_t)q_cap * (h + 4) + (int64_t)p_cap * d) + cold + stage;
+}
+
+// Balanced static schedule of a fused launch.  Snapshots are independent and a tile costs the same for every snapshot,
+// so the work of a launch is the sequence tile 0 x S snapshots, tile 1 x S snapshots, ... with a per-snapshot cost per
+// tile; it is cut into SCHED_WGS ranges of equal cost, one per workgroup (one workgroup per CU, every CU busy for the
+// same time, metadata / weights set up once per range piece instead of once per (tile, chunk)).  A range is stored as
+// up to SCHED_MAX_SEG pieces (tile, from, to) with from / to as fractions of S in 1/65536 -- independent of S, so the
+// schedule is built once per plan.  Record of workgroup w: sched[w * SCHED_INTS] = n_seg, then n_seg x (tile, from, to).
+constexpr int SCHED_WGS = 256, SCHED_MAX_SEG = 24, SCHED_INTS = 1 + 3 * SCHED_MAX_SEG + 3;
+
+// per-snapshot cost of a tile in arbitrary units, from the phase shares measured on full tiles (tools/phase_timing.py):
+// fixed part (barriers, loop) 14, secondary MLP 0.85 per 16-row block, primary GEMM 4 per block, aggregation 29 / 128 rows
+inline double tile_cost(const int32_t *hd) {
+  return 14.0 + 0.85 * ((hd[2] + 15) / 16) + 4.0 * ((hd[1] + 15) / 16) + 29.0 * hd[0] / 128.0;
+}
+
+// false: some workgroup would need more than SCHED_MAX_SEG pieces (many small tiles) -> the (tile, chunk) grid is used
+inline bool build_schedule(const std::vector<int32_t> &hdr, int n_tiles, std::vector<int32_t> &out) {
+  out.assign((size_t)SCHED_WGS * SCHED_INTS, 0);
+  if (n_tiles <= 0) return false;
+  std::vector<double> start(n_tiles + 1, 0.0);
+  for (int t = 0; t < n_tiles; ++t) start[t + 1] = start[t] + tile_cost(hdr.data() + (size_t)t * TILE_HDR_INTS);
+  const double total = start[n_tiles];
+  auto frac = [&](int t, double c) {      // position c inside tile t as a fraction of its snapshots, 0 .. 65536
+    const double f = (c - start[t]) / (start[t + 1] - start[t]);
+    return (int32_t)std::lround(65536.0 * std::min(1.0, std::max(0.0, f)));
+  };
+  int t = 0;
+  int32_t from = 0;                       // where the previous range stopped inside tile t
+  for (int w = 0; w < SCHED_WGS; ++w) {
+    const double hi = w + 1 == SCHED_WGS ? total : total * (w + 1) / SCHED_WGS;
+    int32_t *rec = out.data() + (size_t)w * SCHED_INTS;
+    int n = 0;
+    while (t < n_tiles) {
+      const bool whole = w + 1 == SCHED_WGS || start[t + 1] <= hi;
+      const int32_t to = whole ? 65536 : frac(t, hi);
+      if (to > from) {
+        if (n == SCHED_MAX_SEG) return false;
+        rec[1 + 3 * n] = t;
+        rec[2 + 3 * n] = from;
+        rec[3 + 3 * n] = to;
+        ++n;
+      }
+      if (!whole) {
+        from = to;
+        break;
+      }
+      ++t;
+      from = 0;
+    }
+    rec[0] = n;
+  }
+  return true;
 }
 
 // Both sides of a network merged into one tile list ordered by locality key, so that the node tile and

@@ -74,6 +74,7 @@ struct uds_plan_slot {
   uds::NetworkPlan plan;
   int32_t *d_hdr = nullptr, *d_pool = nullptr;
   int32_t *d_hdr_side[2] = {nullptr, nullptr};   // headers of one side's tiles only (same pool): single-side launches
+  int32_t *d_sched = nullptr, *d_sched_side[2] = {nullptr, nullptr};   // balanced schedules of the three tile lists (nullptr: none)
   int64_t lds_bytes = 0;
 };
 
@@ -585,6 +586,16 @@ static int build_slot(uds_network *n, int fp, int fs) {
       (e = hipMemcpy(sl.d_hdr, sl.plan.hdr.data(), sizeof(int32_t) * sl.plan.hdr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
       (e = hipMemcpy(sl.d_pool, sl.plan.pool.data(), sizeof(int32_t) * sl.plan.pool.size(), hipMemcpyHostToDevice)) != hipSuccess)
     return fail(UDS_ENOMEM, "tile plan upload -> %s", hipGetErrorString(e));
+  // balanced static schedule of a tile list (k_fused_tile only), uploaded next to it
+  auto upload_schedule = [&](const std::vector<int32_t> &hdr, int n_tiles, int32_t **dst) -> hipError_t {
+    std::vector<int32_t> sc;
+    if (fp == 128 || fs == 128 || !uds::build_schedule(hdr, n_tiles, sc)) return hipSuccess;
+    hipError_t e2 = hipMalloc(dst, sizeof(int32_t) * sc.size());
+    if (e2 != hipSuccess) return e2;
+    return hipMemcpy(*dst, sc.data(), sizeof(int32_t) * sc.size(), hipMemcpyHostToDevice);
+  };
+  if ((e = upload_schedule(sl.plan.hdr, sl.plan.n_tiles, &sl.d_sched)) != hipSuccess)
+    return fail(UDS_ENOMEM, "schedule upload -> %s", hipGetErrorString(e));
   for (int side = 0; side < 2; ++side) {   // compact per-side header lists, in the merged (locality) order
     std::vector<int32_t> hs;
     for (int t = 0; t < sl.plan.n_tiles; ++t)
@@ -593,6 +604,8 @@ static int build_slot(uds_network *n, int fp, int fs) {
     if ((e = hipMalloc(&sl.d_hdr_side[side], sizeof(int32_t) * std::max<size_t>(hs.size(), 1))) != hipSuccess ||
         (!hs.empty() && (e = hipMemcpy(sl.d_hdr_side[side], hs.data(), sizeof(int32_t) * hs.size(), hipMemcpyHostToDevice)) != hipSuccess))
       return fail(UDS_ENOMEM, "tile plan upload -> %s", hipGetErrorString(e));
+    if ((e = upload_schedule(hs, (int)(hs.size() / uds::TILE_HDR_INTS), &sl.d_sched_side[side])) != hipSuccess)
+      return fail(UDS_ENOMEM, "schedule upload -> %s", hipGetErrorString(e));
   }
   sl.ok = true;
   return UDS_OK;
@@ -665,6 +678,9 @@ int uds_network_destroy(uds_network_t *net) {
     hipFree(sl.d_pool);
     hipFree(sl.d_hdr_side[0]);
     hipFree(sl.d_hdr_side[1]);
+    hipFree(sl.d_sched);
+    hipFree(sl.d_sched_side[0]);
+    hipFree(sl.d_sched_side[1]);
   }
   delete net;
   return UDS_OK;
@@ -732,6 +748,21 @@ int uds_tile_plan_copy(const uds_tile_plan_t *tp, int32_t *hdr_out, int32_t *poo
   UDS_REQUIRE(tp && hdr_out && pool_out, "uds_tile_plan_copy: NULL argument");
   std::memcpy(hdr_out, tp->plan.hdr.data(), sizeof(int32_t) * tp->plan.hdr.size());
   std::memcpy(pool_out, tp->plan.pool.data(), sizeof(int32_t) * tp->plan.pool.size());
+  return UDS_OK;
+}
+
+int uds_tile_plan_schedule(const uds_tile_plan_t *tp, int32_t *sched_out, int32_t *dims3) {
+  UDS_REQUIRE(tp != nullptr, "uds_tile_plan_schedule: NULL plan");
+  if (dims3) {
+    dims3[0] = uds::SCHED_WGS;
+    dims3[1] = uds::SCHED_INTS;
+    dims3[2] = uds::SCHED_MAX_SEG;
+  }
+  if (!sched_out) return UDS_OK;
+  std::vector<int32_t> sc;
+  UDS_REQUIRE(uds::build_schedule(tp->plan.hdr, tp->plan.n_tiles, sc), "uds_tile_plan_schedule: a workgroup would need more than %d pieces",
+              uds::SCHED_MAX_SEG);
+  std::memcpy(sched_out, sc.data(), sizeof(int32_t) * sc.size());
   return UDS_OK;
 }
 
@@ -812,6 +843,7 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
       UDS_REQUIRE(aligned16(wq), "uds_spatial_layer_forward: packed weights must be 16-byte aligned");
     }
     uds::FusedArgs a;
+    a.sched = nullptr;
     a.side[0] = uds::FusedSide{x, e, nullptr, nullptr, out_x, wq, wq + 2048, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
     a.side[1] = uds::FusedSide{e, x, nullptr, nullptr, out_e, wq + 8192, wq + 10240, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};
     a.S = (int)S;
@@ -863,6 +895,7 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
       wq = reinterpret_cast<const uint4 *>(ws);
     }
     uds::FusedArgs a;
+    a.sched = nullptr;
     a.side[0] = uds::FusedSide{x, e, nullptr, nullptr, out_x, wq, wq + 768, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
     a.side[1] = uds::FusedSide{e, x, nullptr, nullptr, out_e, wq + 768 + 2048, wq + 2 * 768 + 2048, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val,
                                (int)E, (int)N};
@@ -915,9 +948,15 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
     }
     const uint4 *w_small_n = wq, *w_big_n = wq + 768, *w_small_e = wq + 768 + 2048, *w_big_e = wq + 2 * 768 + 2048;
     uds::FusedArgs a;
+    a.sched = nullptr;
     a.side[0] = uds::FusedSide{x, e, xb, eb, out_x, w_small_n, w_big_n, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
     a.side[1] = uds::FusedSide{e, x, eb, xb, out_e, w_small_e, w_big_e, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};
     int64_t lds_need = 0;
+    // The balanced static schedule is an experiment knob (UDS_SCHED=1), off by default: measured 314 us per launch against 281
+    // for the (tile, chunk) grid on the headline.  Tiles cost 8.4k cycles per snapshot +-4 % whatever their size, but ~4 % of
+    // the workgroups run 25 % slower for no structural reason (tools/tile_cost_fit.py), and a static range that lands on one
+    // of them sets the launch time; the hardware's dynamic dispatch of ~4 short workgroups per CU absorbs them.
+    static const bool no_sched = std::getenv("UDS_SCHED") == nullptr;
     auto use_plan = [&](const uds_plan_slot &u, int side) {     // side < 0: both sides (merged tile list), else that side's tiles only
       a.hdr = side < 0 ? u.d_hdr : u.d_hdr_side[side];
       a.pool = u.d_pool;
@@ -926,6 +965,8 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
       a.q_cap = u.plan.q_cap;
       a.meta_cap = u.plan.meta_cap;
       lds_need = u.lds_bytes;
+      // the balanced schedule pays when every workgroup gets several tile-snapshots; tiny launches keep one piece each
+      a.sched = (!no_sched && (int64_t)a.n_tiles * S >= 4 * uds::SCHED_WGS) ? (side < 0 ? u.d_sched : u.d_sched_side[side]) : nullptr;
     };
     use_plan(sl, -1);
     a.S = (int)S;
@@ -949,7 +990,9 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
           chunk = c;
         }
       }
+      if (const char *ov = std::getenv("UDS_CHUNK")) chunk = std::max<int64_t>(1, std::min<int64_t>(S, std::atoll(ov)));   // experiment knob
       a.chunk = (int)chunk;
+      if (a.sched) return uds::SCHED_WGS;
       return (int)(((S + chunk - 1) / chunk) * a.n_tiles);
     };
     if (fx == fe) {

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 4
+#define UDS_ABI_VERSION 5
 
 enum {
   UDS_OK = 0,
@@ -211,6 +211,13 @@ int uds_tile_plan_create(const int32_t *adj_rowptr, const int32_t *adj_col, cons
 int uds_tile_plan_destroy(uds_tile_plan_t *plan);
 int uds_tile_plan_sizes(const uds_tile_plan_t *plan, int64_t *n_tiles, int64_t *pool_len, int32_t *caps3);
 int uds_tile_plan_copy(const uds_tile_plan_t *plan, int32_t *hdr_out, int32_t *pool_out);
+/* Balanced static schedule of one fused launch over the plan's merged tile list (host-only, integer bookkeeping): the
+ * sequence tile 0 x S snapshots, tile 1 x S snapshots, ... is cut into dims3[0] workgroup ranges of equal estimated
+ * cost; record w = sched_out[w * dims3[1] ..]: n_pieces, then n_pieces x (tile, from, to) with from / to fractions of S
+ * in 1/65536 (snapshot range [round(S from / 65536), round(S to / 65536))).  dims3 = {workgroups, ints per record, max
+ * pieces}; pass sched_out = NULL to query dims3 only.  Returns UDS_EINVAL when a workgroup would need more than the
+ * maximum number of pieces (the launch then uses the (tile, chunk) grid). */
+int uds_tile_plan_schedule(const uds_tile_plan_t *plan, int32_t *sched_out, int32_t *dims3);
 
 typedef struct uds_spatial_params {
   const float *xe_k, *xe_b; /* Dense(h) on e -> x_e : (fe, h), (h)            emulator.py:225 */

@@ -91,3 +91,27 @@ def test_headline_plan_fits_the_cu_lds():
     assert lds <= 160 * 1024
     a, b, c = _lib.tile_plan(g, 128, 128, 128, 208)
     assert np.array_equal(a, hdr) and np.array_equal(b, pool)   # deterministic
+
+
+def test_balanced_schedule_covers_every_tile_snapshot_once():
+    """uds_tile_plan_schedule: for any S every (tile, snapshot) belongs to exactly one workgroup piece, pieces are in tile
+    order, and the estimated cost per workgroup is level (within one tile-snapshot of the mean)."""
+    g = U.DrainageGraph.from_edges(U.synthetic_drainage_network(10000, 12000, 0))
+    hdr, pool, caps = _lib.tile_plan(g, 128, 128, 128, 208, schedule=True)
+    sched = caps['schedule']
+    assert sched is not None and sched.shape[0] == 256
+    cost = 14.0 + 0.85 * ((hdr[:, 2] + 15) // 16) + 4.0 * ((hdr[:, 1] + 15) // 16) + 29.0 * hdr[:, 0] / 128.0
+    for S in (1, 6, 60, 61, 257):
+        seen = np.zeros((hdr.shape[0], S), dtype=np.int32)
+        load = np.zeros(sched.shape[0])
+        for w, rec in enumerate(sched):
+            last = -1
+            for k in range(rec[0]):
+                t, a, b = rec[1 + 3 * k: 4 + 3 * k]
+                assert t >= last and 0 <= a < b <= 65536
+                last = t
+                s0, s1 = (S * int(a) + 32768) >> 16, (S * int(b) + 32768) >> 16
+                seen[t, s0:s1] += 1
+                load[w] += (s1 - s0) * cost[t]
+        assert (seen == 1).all()
+        assert load.max() - load.min() <= 2 * cost.max() + 1e-9
