@@ -58,6 +58,7 @@ struct FusedSide {
 struct FusedArgs {
   FusedSide side[2];
   const int32_t *hdr, *pool;
+  const int32_t *blocks;     // k_fused_tile: per tile of the list one block [header 8 | metadata | pad] of meta_cap ints
   const int32_t *sched;      // balanced static schedule (tile_plan.hpp: build_schedule), or nullptr: workgroup = (tile, chunk)
   int n_tiles, S, chunk, p_cap, q_cap, meta_cap, act, side_mask;
   unsigned long long *dbg;   // diagnostic builds only (UDS_PHASE_TIMING): 8 cycle sums per wave
@@ -271,29 +272,69 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
     s_begin = chunk_id * a.chunk;
     s_end = min(a.S, (chunk_id + 1) * a.chunk);
   }
-  const int32_t *hd = a.hdr + tile * TILE_HDR_INTS;
-  const int n_own = hd[0], n_prim = hd[1], n_sec = hd[2], n_inc = hd[3], pool_off = hd[5], sd = hd[6], meta_len = hd[7];
+  // Set-up is two dependent round trips, ~4 and ~5 us under load (tools/tile_cost_fit.py): (1) everything that needs no
+  // metadata -- the side's weight fragments, attention vectors, biases -- together with the tile's block (header +
+  // metadata at a fixed stride, so nothing has to be known before the fetch); (2) the first snapshot's rows and the
+  // NodeEdge values the metadata points at.  The side comes from the (scalar-cached) header array.
+  const int sd = __builtin_amdgcn_readfirstlane(a.hdr[tile * TILE_HDR_INTS + 6]);
   if (!((a.side_mask >> sd) & 1)) return;
   const FusedSide &S_ = a.side[sd];
-
-  int32_t *meta = smem;
+  constexpr bool COLD_X = FP > 64, COLD_S = FS > 64 || SMALL_IN_LDS;
+  constexpr int T_COLD_X = KT_X - 1, T_COLD_S = SMALL_IN_LDS ? 0 : KT_S - 1;     // first k-step that lives in LDS
+  constexpr int N_COLD_S = (KT_S - T_COLD_S) * MB_S * 2 * 64;
+  const int c16 = lane & 15, rs = lane >> 4;     // P3 mapping: 16 lanes x float4 per output row, 4 rows per group
   float *s_self = reinterpret_cast<float *>(smem + a.meta_cap);
   float *s_nbr = s_self + a.p_cap;
   float *attn = s_nbr + a.p_cap;                 // a_self[64] | a_nbr[64]
   // 96-wide inputs: the weight fragments of the third 32-wide k-step stay in LDS ("cold": read per 16-row block) so
   // that the register-resident set is the same as for 64-wide inputs (no spills)
-  constexpr bool COLD_X = FP > 64, COLD_S = FS > 64 || SMALL_IN_LDS;
-  constexpr int T_COLD_X = KT_X - 1, T_COLD_S = SMALL_IN_LDS ? 0 : KT_S - 1;     // first k-step that lives in LDS
-  constexpr int N_COLD_S = (KT_S - T_COLD_S) * MB_S * 2 * 64;
   uint4 *cold_b = reinterpret_cast<uint4 *>(attn + 2 * FUSED_D + FUSED_H);     // MB_B x 2 fragments x 64 lanes
   uint4 *cold_s = cold_b + (COLD_X ? MB_B * 2 * 64 : 0);                        // (KT_S - T_COLD_S) x MB_S x 2 fragments x 64 lanes
+  // weight fragments straight from global memory into registers (every wave reads the same 22-45 KB: L2 / L1 hits after the first)
+  bf16x8 wsh[KT_S][MB_S], wsl[KT_S][MB_S], wbh[KT_B][MB_B], wbl[KT_B][MB_B];
+#pragma unroll
+  for (int t = 0; t < KT_S; ++t)
+#pragma unroll
+    for (int m = 0; m < MB_S; ++m) {
+      if (COLD_S && t >= T_COLD_S) continue;
+      wsh[t][m] = __builtin_bit_cast(bf16x8, S_.w_small[((t * MB_S + m) * 2 + 0) * 64 + lane]);
+      wsl[t][m] = __builtin_bit_cast(bf16x8, S_.w_small[((t * MB_S + m) * 2 + 1) * 64 + lane]);
+    }
+#pragma unroll
+  for (int t = 0; t < KT_B; ++t)
+#pragma unroll
+    for (int m = 0; m < MB_B; ++m) {
+      if (COLD_X && t == T_COLD_X) continue;
+      wbh[t][m] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + m) * 2 + 0) * 64 + lane]);
+      wbl[t][m] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + m) * 2 + 1) * 64 + lane]);
+    }
+  if (COLD_X)
+    for (int i = tid; i < MB_B * 2 * 64; i += NT) cold_b[i] = S_.w_big[T_COLD_X * MB_B * 2 * 64 + i];
+  if (COLD_S)
+    for (int i = tid; i < N_COLD_S; i += NT) cold_s[i] = S_.w_small[T_COLD_S * MB_S * 2 * 64 + i];
+  f32x4 bo = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (S_.b_out) bo = *reinterpret_cast<const f32x4 *>(S_.b_out + 4 * c16);
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.blocks + (int64_t)tile * a.meta_cap);
+    uint4 *dst = reinterpret_cast<uint4 *>(smem);
+    for (int i = tid; i < a.meta_cap / 4; i += NT) dst[i] = src[i];
+  }
+  if (tid < FUSED_D) {   // attention vectors and the small GEMM's bias live in LDS (read once per 16-row block)
+    attn[tid] = S_.a_self[tid];
+    attn[FUSED_D + tid] = S_.a_nbr[tid];
+    if (tid < FUSED_H) attn[2 * FUSED_D + tid] = S_.b_small ? S_.b_small[tid] : 0.f;
+  }
+  __syncthreads();
+  UDS_STAMP(7);   // tile block (header + metadata) fetched
+  const int n_own = __builtin_amdgcn_readfirstlane(smem[0]), n_prim = __builtin_amdgcn_readfirstlane(smem[1]),
+            n_sec = __builtin_amdgcn_readfirstlane(smem[2]), n_inc = __builtin_amdgcn_readfirstlane(smem[3]);
+
+  int32_t *meta = smem + TILE_HDR_INTS;
   float *sec = reinterpret_cast<float *>(cold_s + (COLD_S ? N_COLD_S : 0));
   float *hx = sec + a.q_cap * SEC_STRIDE;
   float *stage_s = hx + a.p_cap * FUSED_D;       // (q_cap/16) blocks x KT_S x 2 pieces x 1 KiB, fragment order
   float *stage_p = stage_s + a.q_cap * FS;       // (p_cap/16) blocks x KT_X x 2 pieces x 1 KiB
 
-  for (int i = tid; i < meta_len; i += NT) meta[i] = a.pool[pool_off + i];
-  __syncthreads();
   const int32_t *prim_ids = meta;
   const int32_t *sec_ids = prim_ids + n_prim;
   const int32_t *inc_ptr = sec_ids + n_sec;
@@ -302,8 +343,6 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
   const int32_t *adj_ptr = inc_w + n_inc;
   const int32_t *adj_loc = adj_ptr + n_own + 1;
   const float *inc_val = reinterpret_cast<const float *>(inc_w);
-  const int c16 = lane & 15, rs = lane >> 4;     // P3 mapping: 16 lanes x float4 per output row, 4 rows per group
-
   // LDS-DMA of one 16-row block in fragment order: piece (t, i) of lane (r16, qd) = floats 32t + 16i + 4qd .. +3
   // of row r16 of the block.  The destination is wave-uniform (base + lane * 16 B is implicit).  Row offsets do not
   // change from snapshot to snapshot, so a wave keeps those of its first two P1 blocks and first P2 block in registers.
@@ -363,39 +402,15 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
     for (int blk = wave; blk * 16 < n_prim; blk += NW) dma_prim(blk, s_begin);
   }
   // everything below overlaps with the first snapshot's DMA
+#ifdef UDS_PHASE_TIMING
+  const unsigned long long t_dma_issued_ = clock64();
+#endif
   for (int i = tid; i < n_inc; i += NT) reinterpret_cast<float *>(inc_w)[i] = S_.ne_val[inc_w[i]];
 
-  if (tid < FUSED_D) {   // attention vectors and the small GEMM's bias live in LDS (read once per 16-row block)
-    attn[tid] = S_.a_self[tid];
-    attn[FUSED_D + tid] = S_.a_nbr[tid];
-    if (tid < FUSED_H) attn[2 * FUSED_D + tid] = S_.b_small ? S_.b_small[tid] : 0.f;
-  }
-  f32x4 bo = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (S_.b_out) bo = *reinterpret_cast<const f32x4 *>(S_.b_out + 4 * c16);
 
-  // weight fragments straight from global memory into registers (every wave reads the same 22-45 KB: L2 / L1 hits after
-  // the first), issued AFTER the first snapshot's DMA so both latencies overlap
-  bf16x8 wsh[KT_S][MB_S], wsl[KT_S][MB_S], wbh[KT_B][MB_B], wbl[KT_B][MB_B];
-#pragma unroll
-  for (int t = 0; t < KT_S; ++t)
-#pragma unroll
-    for (int m = 0; m < MB_S; ++m) {
-      if (COLD_S && t >= T_COLD_S) continue;
-      wsh[t][m] = __builtin_bit_cast(bf16x8, S_.w_small[((t * MB_S + m) * 2 + 0) * 64 + lane]);
-      wsl[t][m] = __builtin_bit_cast(bf16x8, S_.w_small[((t * MB_S + m) * 2 + 1) * 64 + lane]);
-    }
-#pragma unroll
-  for (int t = 0; t < KT_B; ++t)
-#pragma unroll
-    for (int m = 0; m < MB_B; ++m) {
-      if (COLD_X && t == T_COLD_X) continue;
-      wbh[t][m] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + m) * 2 + 0) * 64 + lane]);
-      wbl[t][m] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + m) * 2 + 1) * 64 + lane]);
-    }
-  if (COLD_X)
-    for (int i = tid; i < MB_B * 2 * 64; i += NT) cold_b[i] = S_.w_big[T_COLD_X * MB_B * 2 * 64 + i];
-  if (COLD_S)
-    for (int i = tid; i < N_COLD_S; i += NT) cold_s[i] = S_.w_small[T_COLD_S * MB_S * 2 * 64 + i];
+#ifdef UDS_PHASE_TIMING
+  const unsigned long long t_loads_issued_ = clock64();
+#endif
   __syncthreads();   // NodeEdge values, attention vectors and bias are in LDS
   int n_st = 0;   // output-store instructions this wave issued in the previous P3 (still in flight, younger than the DMA)
   UDS_STAMP(0);   // setup: metadata, first DMA issue, weights
@@ -678,6 +693,8 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
   if (a.dbg && lane == 0) {
     unsigned long long *o = a.dbg + ((size_t)blockIdx.x * NW + wave) * 16;
     o[12] = wave;
+    o[13] = tm_[7];
+    o[14] = t_loads_issued_ - t_dma_issued_;
     for (int k = 0; k < 7; ++k) o[k] = tm_[k];
     o[8] = tm_[8]; o[9] = tm_[9]; o[10] = tm_[10]; o[11] = tm_[11];
     o[7] = 1ull | ((unsigned long long)sd << 8) | ((unsigned long long)n_own << 16) | ((unsigned long long)n_prim << 32) |

@@ -29,6 +29,8 @@ struct HostCsr {
 };
 
 constexpr int TILE_HDR_INTS = 8;  // n_own, n_prim, n_sec, n_inc, n_adj, pool_off, side, meta_len
+// ints of a tile's fixed-stride block: header + metadata, padded to 16 bytes (k_fused_tile fetches it whole)
+inline int tile_block_ints(int meta_cap) { return (TILE_HDR_INTS + meta_cap + 3) & ~3; }
 
 struct SidePlan {
   int n_tiles = 0;

@@ -75,6 +75,9 @@ struct uds_plan_slot {
   int32_t *d_hdr = nullptr, *d_pool = nullptr;
   int32_t *d_hdr_side[2] = {nullptr, nullptr};   // headers of one side's tiles only (same pool): single-side launches
   int32_t *d_sched = nullptr, *d_sched_side[2] = {nullptr, nullptr};   // balanced schedules of the three tile lists (nullptr: none)
+  // k_fused_tile: header + metadata of every tile as one fixed-stride block (tile_block_ints(meta_cap) ints), so a workgroup
+  // fetches both in ONE round trip without knowing the header first; one array per tile list
+  int32_t *d_blocks = nullptr, *d_blocks_side[2] = {nullptr, nullptr};
   int64_t lds_bytes = 0;
 };
 
@@ -106,7 +109,7 @@ bool plan_network(const uds::HostCsr &adj, const uds::HostCsr &eadj, const uds::
     if (uds::fused_lds_bytes(p_lim, q_lim, 0, uds::FUSED_H, uds::FUSED_D, fp, fs) > FUSED_LDS_BUDGET) continue;
     const int t = std::min(p_lim, 4 * uds::FUSED_WAVES * uds::FUSED_U);        // own rows: P3 covers a tile in one trip
     out = uds::build_network_plan(adj, eadj, inc_n, inc_e, t, t, p_lim, q_lim);
-    lds = uds::fused_lds_bytes(out.p_cap, out.q_cap, out.meta_cap, uds::FUSED_H, uds::FUSED_D, fp, fs);
+    lds = uds::fused_lds_bytes(out.p_cap, out.q_cap, uds::tile_block_ints(out.meta_cap), uds::FUSED_H, uds::FUSED_D, fp, fs);
     if (lds <= FUSED_LDS_BUDGET && out.p_cap <= 4 * uds::FUSED_WAVES * uds::FUSED_U) return true;   // P3 covers a tile in one trip
   }
   return false;
@@ -596,6 +599,21 @@ static int build_slot(uds_network *n, int fp, int fs) {
   };
   if ((e = upload_schedule(sl.plan.hdr, sl.plan.n_tiles, &sl.d_sched)) != hipSuccess)
     return fail(UDS_ENOMEM, "schedule upload -> %s", hipGetErrorString(e));
+  auto upload_blocks = [&](const std::vector<int32_t> &hdr, int n_tiles, int32_t **dst) -> hipError_t {
+    if (fp == 128 || fs == 128) return hipSuccess;
+    const size_t stride = (size_t)uds::tile_block_ints(sl.plan.meta_cap);
+    std::vector<int32_t> bl(std::max<size_t>(stride * n_tiles, 4), 0);
+    for (int t = 0; t < n_tiles; ++t) {
+      const int32_t *hd = hdr.data() + (size_t)t * uds::TILE_HDR_INTS;
+      std::copy(hd, hd + uds::TILE_HDR_INTS, bl.begin() + stride * t);
+      std::copy(sl.plan.pool.begin() + hd[5], sl.plan.pool.begin() + hd[5] + hd[7], bl.begin() + stride * t + uds::TILE_HDR_INTS);
+    }
+    hipError_t e2 = hipMalloc(dst, sizeof(int32_t) * bl.size());
+    if (e2 != hipSuccess) return e2;
+    return hipMemcpy(*dst, bl.data(), sizeof(int32_t) * bl.size(), hipMemcpyHostToDevice);
+  };
+  if ((e = upload_blocks(sl.plan.hdr, sl.plan.n_tiles, &sl.d_blocks)) != hipSuccess)
+    return fail(UDS_ENOMEM, "tile block upload -> %s", hipGetErrorString(e));
   for (int side = 0; side < 2; ++side) {   // compact per-side header lists, in the merged (locality) order
     std::vector<int32_t> hs;
     for (int t = 0; t < sl.plan.n_tiles; ++t)
@@ -606,6 +624,8 @@ static int build_slot(uds_network *n, int fp, int fs) {
       return fail(UDS_ENOMEM, "tile plan upload -> %s", hipGetErrorString(e));
     if ((e = upload_schedule(hs, (int)(hs.size() / uds::TILE_HDR_INTS), &sl.d_sched_side[side])) != hipSuccess)
       return fail(UDS_ENOMEM, "schedule upload -> %s", hipGetErrorString(e));
+    if ((e = upload_blocks(hs, (int)(hs.size() / uds::TILE_HDR_INTS), &sl.d_blocks_side[side])) != hipSuccess)
+      return fail(UDS_ENOMEM, "tile block upload -> %s", hipGetErrorString(e));
   }
   sl.ok = true;
   return UDS_OK;
@@ -681,6 +701,9 @@ int uds_network_destroy(uds_network_t *net) {
     hipFree(sl.d_sched);
     hipFree(sl.d_sched_side[0]);
     hipFree(sl.d_sched_side[1]);
+    hipFree(sl.d_blocks);
+    hipFree(sl.d_blocks_side[0]);
+    hipFree(sl.d_blocks_side[1]);
   }
   delete net;
   return UDS_OK;
@@ -844,6 +867,7 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
     }
     uds::FusedArgs a;
     a.sched = nullptr;
+    a.blocks = nullptr;
     a.side[0] = uds::FusedSide{x, e, nullptr, nullptr, out_x, wq, wq + 2048, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
     a.side[1] = uds::FusedSide{e, x, nullptr, nullptr, out_e, wq + 8192, wq + 10240, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};
     a.S = (int)S;
@@ -896,6 +920,7 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
     }
     uds::FusedArgs a;
     a.sched = nullptr;
+    a.blocks = nullptr;
     a.side[0] = uds::FusedSide{x, e, nullptr, nullptr, out_x, wq, wq + 768, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
     a.side[1] = uds::FusedSide{e, x, nullptr, nullptr, out_e, wq + 768 + 2048, wq + 2 * 768 + 2048, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val,
                                (int)E, (int)N};
@@ -949,6 +974,7 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
     const uint4 *w_small_n = wq, *w_big_n = wq + 768, *w_small_e = wq + 768 + 2048, *w_big_e = wq + 2 * 768 + 2048;
     uds::FusedArgs a;
     a.sched = nullptr;
+    a.blocks = nullptr;
     a.side[0] = uds::FusedSide{x, e, xb, eb, out_x, w_small_n, w_big_n, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
     a.side[1] = uds::FusedSide{e, x, eb, xb, out_e, w_small_e, w_big_e, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};
     int64_t lds_need = 0;
@@ -963,7 +989,8 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
       a.n_tiles = side < 0 ? u.plan.n_tiles : u.plan.side[side].n_tiles;
       a.p_cap = u.plan.p_cap;
       a.q_cap = u.plan.q_cap;
-      a.meta_cap = u.plan.meta_cap;
+      a.meta_cap = uds::tile_block_ints(u.plan.meta_cap);      // LDS ints of the tile block (header + metadata)
+      a.blocks = side < 0 ? u.d_blocks : u.d_blocks_side[side];
       lds_need = u.lds_bytes;
       // the balanced schedule pays when every workgroup gets several tile-snapshots; tiny launches keep one piece each
       a.sched = (!no_sched && (int64_t)a.n_tiles * S >= 4 * uds::SCHED_WGS) ? (side < 0 ? u.d_sched : u.d_sched_side[side]) : nullptr;

@@ -49,6 +49,8 @@ np.savetxt('gpurun_out/tile_costs.csv', out, fmt='%.1f', delimiter=',', header='
 y = out[:, 6]
 A = np.stack([np.ones(T), np.ceil(out[:, 3] / 16), np.ceil(out[:, 2] / 16), out[:, 1], out[:, 5], out[:, 4]], 1)
 coef, res, *_ = np.linalg.lstsq(A, y, rcond=None)
+print('setup split (mean cycles): block fetch + barrier %.0f | rest of setup %.0f (of which issue of gathers + weight loads %.0f)' % (rows[:, :, 13].max(1).mean(), rows[:, :, 0].max(1).mean(), rows[:, :, 14].max(1).mean()))
+print('first stage wait (stamp 1 / S) %.0f' % (rows[:, :, 1].max(1).mean() / S))
 print('tiles', T, 'cycles/snapshot min %.0f mean %.0f max %.0f; setup mean %.0f' % (y.min(), y.mean(), y.max(), out[:, 7].mean()))
 print('fit: const %.1f + %.2f*sec_blocks + %.2f*prim_blocks + %.3f*n_own + %.4f*n_adj + %.4f*n_inc; rms resid %.1f' % (*coef, np.sqrt(((A @ coef - y) ** 2).mean())))
 A2 = A[:, :4]
