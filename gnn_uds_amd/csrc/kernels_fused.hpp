@@ -105,10 +105,13 @@ __device__ __forceinline__ f32x4 mfma3(const bf16x8 &wh, const bf16x8 &wl, const
   return acc;
 }
 
-// 16-lane all-reduce (max / sum) with DPP row operations: no LDS traffic, VALU latency only.
+// 16-lane all-reduce (max / sum) with DPP row operations: no LDS traffic, VALU latency only.  quad_perm / row_ror read
+// a valid lane everywhere, so bound_ctrl changes nothing -- but with it (and full masks) the backend folds the move into
+// the max / add that consumes it (v_max_f32_dpp): 4 instructions per reduction instead of 8.
 template <int CTRL>
 __device__ __forceinline__ float row_dpp(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+  const int x = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float row16_max(float v) {
   v = fmaxf(v, row_dpp<0xB1>(v));    // quad_perm [1,0,3,2]
@@ -123,6 +126,27 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += row_dpp<0x124>(v);
   v += row_dpp<0x128>(v);
   return v;
+}
+
+// The same all-reduces for FOUR values at once with the DPP move folded into the max / add (v_max_f32_dpp: hipcc keeps a
+// separate v_mov_b32_dpp per step, 8 instructions per reduction instead of 4).  Written as one asm block because the
+// "VALU write -> DPP read of the same VGPR" hazard (2 wait states) is invisible to the compiler inside inline asm: the
+// four values are interleaved so that dependent steps are 3 instructions apart, and one s_nop covers the producer of
+// the inputs.  In-place is safe: quad_perm and row_ror read inside the 16-lane row that the same pass writes.
+#define UDS_DPP4(op, ctrl)                                                      \
+  op " %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"       \
+  op " %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"       \
+  op " %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"       \
+  op " %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void row16_max4(float &a, float &b, float &c, float &d) {
+  asm("s_nop 1\n\t" UDS_DPP4("v_max_f32_dpp", "quad_perm:[1,0,3,2]") UDS_DPP4("v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+      UDS_DPP4("v_max_f32_dpp", "row_ror:4") UDS_DPP4("v_max_f32_dpp", "row_ror:8")
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void row16_sum4(float &a, float &b, float &c, float &d) {
+  asm("s_nop 1\n\t" UDS_DPP4("v_add_f32_dpp", "quad_perm:[1,0,3,2]") UDS_DPP4("v_add_f32_dpp", "quad_perm:[2,3,0,1]")
+      UDS_DPP4("v_add_f32_dpp", "row_ror:4") UDS_DPP4("v_add_f32_dpp", "row_ror:8")
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
 // sum over the four lanes l, l^16, l^32, l^48 with v_permlane16_swap / v_permlane32_swap (VALU, no LDS round trip):
@@ -606,14 +630,19 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
           lg[u] = c16 < deg[u] ? sc : -INFINITY;
         }
         int joff[U];      // byte offset of the neighbour's hx row with its swizzle key in bits 4-6: j*256 + (j&7)*16
+        static_assert(U == 4, "the four-at-once reductions below");
+        float mx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) mx[u] = lg[u];
+        row16_max4(mx[0], mx[1], mx[2], mx[3]);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const float mx = row16_max(lg[u]);
-          const float ex = __builtin_amdgcn_exp2f((lg[u] - mx) * 1.44269504088896340736f);
+          const float ex = __builtin_amdgcn_exp2f((lg[u] - mx[u]) * 1.44269504088896340736f);
           wgt[u] = c16 < deg[u] ? ex : 0.f;     // rows past the tile have degree 0: every weight 0, the NaN of -inf - -inf dropped
-          den[u] = row16_sum(wgt[u]);
+          den[u] = wgt[u];
           joff[u] = jn[u] * (FUSED_D * 4) + ((jn[u] & 7) << 4);
         }
+        row16_sum4(den[0], den[1], den[2], den[3]);
         // Lane c of a 16-lane row group holds (weight, offset) of neighbour c.  Neighbour K reaches the row's other
         // lanes by a DPP row broadcast (v_mov_b32_dpp row_newbcast:K): no LDS round trip for the pairs.  The XOR with
         // the lane's own chunk offset (c16 << 4) applies the hx swizzle: bits 4-6 key ^ chunk, bits >= 8 the row.
