@@ -553,19 +553,21 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
 #pragma unroll
       for (int m = 0; m < MB_B; ++m) acc[m] = mfma3(wbh[KT_X][m], wbl[KT_X][m], dh[KT_X], dl[KT_X], acc[m]);
       UDS_STAMP(11);   // P2d: index prefetch + MFMA chain
-      float ps = 0.f, pn = 0.f;
+      // <hx row, a_self>, <hx row, a_nbr>: even and odd columns in the two halves of packed FMAs (16 v_pk_fma_f32 instead of
+      // 32 dependent v_fmac_f32), halves added, then the four lanes that share the row
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 ps2 = {0.f, 0.f}, pn2 = {0.f, 0.f};
 #pragma unroll
       for (int m = 0; m < MB_B; ++m) {
         const f32x4 as4 = *reinterpret_cast<const f32x4 *>(attn + 16 * m + 4 * qd);
         const f32x4 an4 = *reinterpret_cast<const f32x4 *>(attn + FUSED_D + 16 * m + 4 * qd);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          ps = fmaf(acc[m][j], as4[j], ps);
-          pn = fmaf(acc[m][j], an4[j], pn);
-        }
+        ps2 = __builtin_elementwise_fma(acc[m].xy, as4.xy, ps2);
+        pn2 = __builtin_elementwise_fma(acc[m].xy, an4.xy, pn2);
+        ps2 = __builtin_elementwise_fma(acc[m].zw, as4.zw, ps2);
+        pn2 = __builtin_elementwise_fma(acc[m].zw, an4.zw, pn2);
       }
-      ps = quarters_sum(ps);
-      pn = quarters_sum(pn);
+      float ps = quarters_sum(ps2.x + ps2.y);
+      float pn = quarters_sum(pn2.x + pn2.y);
       if (valid) {
         if (qd == 0) {
           s_self[lrow] = ps;
