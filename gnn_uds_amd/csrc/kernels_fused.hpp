@@ -138,15 +138,23 @@ __device__ __forceinline__ float row16_sum(float v) {
   op " %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"       \
   op " %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"       \
   op " %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-__device__ __forceinline__ void row16_max4(float &a, float &b, float &c, float &d) {
-  asm("s_nop 1\n\t" UDS_DPP4("v_max_f32_dpp", "quad_perm:[1,0,3,2]") UDS_DPP4("v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+// first step: out = op(dpp(in), in) into fresh registers (the inputs stay live, no copies), the rest in place
+#define UDS_DPP4_FIRST(op, ctrl)                                                \
+  op " %0, %4, %4 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"       \
+  op " %1, %5, %5 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"       \
+  op " %2, %6, %6 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"       \
+  op " %3, %7, %7 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void row16_max4(const float (&in)[4], float (&out)[4]) {
+  asm("s_nop 1\n\t" UDS_DPP4_FIRST("v_max_f32_dpp", "quad_perm:[1,0,3,2]") UDS_DPP4("v_max_f32_dpp", "quad_perm:[2,3,0,1]")
       UDS_DPP4("v_max_f32_dpp", "row_ror:4") UDS_DPP4("v_max_f32_dpp", "row_ror:8")
-      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+      : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
+      : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]));
 }
-__device__ __forceinline__ void row16_sum4(float &a, float &b, float &c, float &d) {
-  asm("s_nop 1\n\t" UDS_DPP4("v_add_f32_dpp", "quad_perm:[1,0,3,2]") UDS_DPP4("v_add_f32_dpp", "quad_perm:[2,3,0,1]")
+__device__ __forceinline__ void row16_sum4(const float (&in)[4], float (&out)[4]) {
+  asm("s_nop 1\n\t" UDS_DPP4_FIRST("v_add_f32_dpp", "quad_perm:[1,0,3,2]") UDS_DPP4("v_add_f32_dpp", "quad_perm:[2,3,0,1]")
       UDS_DPP4("v_add_f32_dpp", "row_ror:4") UDS_DPP4("v_add_f32_dpp", "row_ror:8")
-      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+      : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
+      : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]));
 }
 
 // sum over the four lanes l, l^16, l^32, l^48 with v_permlane16_swap / v_permlane32_swap (VALU, no LDS round trip):
@@ -344,8 +352,10 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
     for (int i = tid; i < a.meta_cap / 4; i += NT) dst[i] = src[i];
   }
   if (tid < FUSED_D) {   // attention vectors and the small GEMM's bias live in LDS (read once per 16-row block)
-    attn[tid] = S_.a_self[tid];
-    attn[FUSED_D + tid] = S_.a_nbr[tid];
+    // scaled by log2(e): the scores s_self, s_nbr then are logits in base-2 units (leaky_relu commutes with a positive
+    // scale, softmax = exp2 of base-2 logits), and P3 needs no multiply in front of its exp2
+    attn[tid] = S_.a_self[tid] * 1.44269504088896340736f;
+    attn[FUSED_D + tid] = S_.a_nbr[tid] * 1.44269504088896340736f;
     if (tid < FUSED_H) attn[2 * FUSED_D + tid] = S_.b_small ? S_.b_small[tid] : 0.f;
   }
   __syncthreads();
@@ -628,23 +638,21 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
       if (dm <= 16) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const float sc = leaky02(ss[u] + s_nbr[jn[u]]);
+          const float sv = ss[u] + s_nbr[jn[u]];
+          const float sc = fmaxf(sv, 0.2f * sv);      // leaky_relu(0.2): the larger of v and 0.2 v, for either sign (2 ops, not 3)
           lg[u] = c16 < deg[u] ? sc : -INFINITY;
         }
         int joff[U];      // byte offset of the neighbour's hx row with its swizzle key in bits 4-6: j*256 + (j&7)*16
         static_assert(U == 4, "the four-at-once reductions below");
         float mx[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) mx[u] = lg[u];
-        row16_max4(mx[0], mx[1], mx[2], mx[3]);
+        row16_max4(lg, mx);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const float ex = __builtin_amdgcn_exp2f((lg[u] - mx[u]) * 1.44269504088896340736f);
+          const float ex = __builtin_amdgcn_exp2f(lg[u] - mx[u]);      // logits are in base-2 units (see the set-up)
           wgt[u] = c16 < deg[u] ? ex : 0.f;     // rows past the tile have degree 0: every weight 0, the NaN of -inf - -inf dropped
-          den[u] = wgt[u];
           joff[u] = jn[u] * (FUSED_D * 4) + ((jn[u] & 7) << 4);
         }
-        row16_sum4(den[0], den[1], den[2], den[3]);
+        row16_sum4(wgt, den);
         // Lane c of a 16-lane row group holds (weight, offset) of neighbour c.  Neighbour K reaches the row's other
         // lanes by a DPP row broadcast (v_mov_b32_dpp row_newbcast:K): no LDS round trip for the pairs.  The XOR with
         // the lane's own chunk offset (c16 << 4) applies the hx swizzle: bits 4-6 key ^ chunk, bits >= 8 the row.
@@ -696,7 +704,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
           den[u] = 0.f;
           for (int p = b0; p < b0 + deg[u]; ++p) {
             const int jj = adj_loc[p];
-            const float wv = __builtin_amdgcn_exp2f((leaky02(ss[u] + s_nbr[jj]) - mx) * 1.44269504088896340736f);
+            const float wv = __builtin_amdgcn_exp2f(leaky02(ss[u] + s_nbr[jj]) - mx);
             const f32x4 hv = *reinterpret_cast<const f32x4 *>(hx + jj * FUSED_D + ((c16 ^ (jj & 7)) << 2));
             den[u] += wv;
 #pragma unroll
