@@ -678,7 +678,12 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
               for (int q = 0; q < 4; ++q) acc[u][q] = fmaf(w, hh[u][i][q], acc[u][q]);
             });
         };
-        const int e3 = dmax[3], e2 = max(e3, dmax[2]), e1 = max(e2, dmax[1]), e0 = max(e1, dmax[0]);
+        // The degree bounds never change from snapshot to snapshot, so the compiler hoists all 32 "slot K < bound" tests out
+        // of the snapshot loop as 64-bit masks, spills them to VGPR lanes and reads them back with v_readlane (vector-ALU
+        // issue slots) at every branch.  Laundering the four scalars keeps the tests where they are: s_cmp on the scalar unit.
+        int d0 = dmax[0], d1 = dmax[1], d2 = dmax[2], d3 = dmax[3];
+        asm volatile("" : "+s"(d0), "+s"(d1), "+s"(d2), "+s"(d3));
+        const int e3 = d3, e2 = max(e3, d2), e1 = max(e2, d1), e0 = max(e1, d0);
         auto steps = [&](auto K_) {      // slots K .. K+W-1: as many groups as still have neighbours there
           constexpr int K = decltype(K_)::value;
           if (K < e3) step(K_, std::integral_constant<int, 4>{});
