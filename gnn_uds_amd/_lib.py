@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libuds_hip.so')
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
 PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
 
@@ -63,6 +63,7 @@ SYMBOLS = {
     'uds_tile_plan_sizes': (_c_int, [_c_ptr, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64), _c_ptr]),
     'uds_tile_plan_copy': (_c_int, [_c_ptr, _c_ptr, _c_ptr]),
     'uds_tile_plan_schedule': (_c_int, [_c_ptr, _c_ptr, _c_ptr]),
+    'uds_roll_update': (_c_int, [_c_ptr] * 7 + [_c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'uds_spatial_workspace_floats': (_c_i64, [_c_ptr, _c_i64, _c_i64, _c_i64]),
     'uds_spatial_packed_bytes': (_c_i64, []),
     'uds_spatial_pack_weights': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr]),
@@ -428,6 +429,24 @@ def flow_balance(handle, sign, flow, scale_in, scale_out):
                                 _dev(scale_out, 'scale_out'), _dev(q_in, 'q_in'), _dev(q_out, 'q_out'), _stream()),
            'uds_flow_balance')
     return q_in, q_out
+
+
+def roll_update(handle, sign, span_e, mini_e, scale_in, scale_out, y, ey, b, x, ex, flood):
+    """The post-forward part of one autoregressive chunk (include/uds_hip.h: uds_roll_update): returns preds (B,so,N,cy+2) and
+    shifts the state windows x (B,T,N,cy+3), ex (B,T,E,ce+1) IN PLACE, feeding the prediction back."""
+    lib = load()
+    B, so, N, cy = y.shape
+    ce, T = ey.shape[-1], x.shape[1]
+    if (tuple(ey.shape[:3]) != (B, so, handle.n_cols) or tuple(b.shape) != (B, so, N, 1) or tuple(x.shape) != (B, T, N, cy + 3) or
+            tuple(ex.shape) != (B, T, handle.n_cols, ce + 1) or N != handle.n_rows):
+        raise UdsError('roll_update: inconsistent shapes y %r ey %r b %r x %r ex %r' % tuple(tuple(t.shape) for t in (y, ey, b, x, ex)))
+    if not (x.is_contiguous() and ex.is_contiguous()):
+        raise UdsError('roll_update: the state windows are updated in place and must be contiguous')
+    preds = torch.empty((B, so, N, cy + 2), device=y.device, dtype=torch.float32)
+    _check(lib.uds_roll_update(handle.ptr, _dev(sign, 'sign'), _dev(span_e, 'span_e'), _dev(mini_e, 'mini_e'), _dev(scale_in, 'scale_in'),
+                               _dev(scale_out, 'scale_out'), _dev(y.contiguous(), 'y'), cy, _dev(ey.contiguous(), 'ey'), ce, _dev(b.contiguous(), 'b'),
+                               B, so, T, int(bool(flood)), _dev(x, 'x'), _dev(ex, 'ex'), _dev(preds, 'preds'), _stream()), 'uds_roll_update')
+    return preds
 
 
 def csr_spmm(handle, val, x, bias=None, act='linear'):

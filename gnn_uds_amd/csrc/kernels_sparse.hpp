@@ -379,4 +379,76 @@ inline hipError_t launch_flow_balance(const FlowArgs &a, hipStream_t st) {
   return hipGetLastError();
 }
 
+// One chunk of the autoregressive rollout after the forward (emulator.py:403-423 with post_proc_tf's edge-fusion branch,
+// :717-724): de-normalise the predicted link flow, balance it onto the nodes (as k_flow_balance), assemble the node
+// prediction [h, q_in, q_out, (flood)], and shift both state windows by `so` steps in place, feeding the prediction back
+// (flood bit thresholded at 0.5, runoff appended; link rows get the constant setting 1).  Replaces ~15 elementwise /
+// concatenation launches per step.  Same operations in the same order as the tensor code (no fused multiply-add): the
+// results are bit-identical.
+struct RollArgs {
+  const int32_t *rowptr, *col;
+  const float *sign, *span_e, *mini_e, *scale_in, *scale_out;
+  const float *y, *ey, *b;      // (B,so,N,cy), (B,so,E,ce), (B,so,N,1)
+  float *x, *ex, *preds;        // (B,T,N,cy+3), (B,T,E,ce+1) in place; (B,so,N,cy+2)
+  int B, so, T, N, E, cy, ce, flood;
+};
+
+__global__ __launch_bounds__(256) void k_roll_node(RollArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)a.B * a.N) return;
+  const int b = (int)(t / a.N), n = (int)(t % a.N);
+  const int cx = a.cy + 3, cp = a.cy + 2, keep = a.T - a.so;
+  float *xw = a.x + ((int64_t)b * a.T * a.N + n) * cx;
+  const int64_t xs = (int64_t)a.N * cx;                       // stride of a time step
+  for (int k = 0; k < keep; ++k)
+    for (int c = 0; c < cx; ++c) xw[k * xs + c] = xw[(k + a.so) * xs + c];
+  for (int j = 0; j < a.so; ++j) {
+    const float *f = a.ey + ((int64_t)b * a.so + j) * a.E * a.ce + (a.ce - 1);
+    float qi = 0.f, qo = 0.f;
+    for (int p = a.rowptr[n]; p < a.rowptr[n + 1]; ++p) {
+      const int l = a.col[p];
+      const float v = __fadd_rn(__fmul_rn(f[(int64_t)l * a.ce], a.span_e[l]), a.mini_e[l]);
+      const float fp = fmaxf(v, 0.f), fn = fmaxf(-v, 0.f);
+      if (a.sign[p] > 0.f) { qo += fp; qi += fn; } else { qi += fp; qo += fn; }
+    }
+    qi = __fmul_rn(qi, a.scale_in[n]);
+    qo = __fmul_rn(qo, a.scale_out[n]);
+    const float *yr = a.y + (((int64_t)b * a.so + j) * a.N + n) * a.cy;
+    float *pr = a.preds + (((int64_t)b * a.so + j) * a.N + n) * cp;
+    float *xn = xw + (int64_t)(keep + j) * xs;
+    pr[0] = xn[0] = yr[0];
+    pr[1] = xn[1] = qi;
+    pr[2] = xn[2] = qo;
+    for (int c = 1; c < a.cy; ++c) {
+      const float v = yr[c];
+      pr[2 + c] = v;
+      xn[2 + c] = (a.flood && c == a.cy - 1) ? (v > 0.5f ? 1.f : 0.f) : v;
+    }
+    xn[cx - 1] = a.b[((int64_t)b * a.so + j) * a.N + n];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_roll_edge(RollArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)a.B * a.E) return;
+  const int b = (int)(t / a.E), l = (int)(t % a.E);
+  const int cx = a.ce + 1, keep = a.T - a.so;
+  float *xw = a.ex + ((int64_t)b * a.T * a.E + l) * cx;
+  const int64_t xs = (int64_t)a.E * cx;
+  for (int k = 0; k < keep; ++k)
+    for (int c = 0; c < cx; ++c) xw[k * xs + c] = xw[(k + a.so) * xs + c];
+  for (int j = 0; j < a.so; ++j) {
+    const float *er = a.ey + (((int64_t)b * a.so + j) * a.E + l) * a.ce;
+    float *xn = xw + (int64_t)(keep + j) * xs;
+    for (int c = 0; c < a.ce; ++c) xn[c] = er[c];
+    xn[a.ce] = 1.f;
+  }
+}
+
+inline hipError_t launch_roll_update(const RollArgs &a, hipStream_t st) {
+  hipLaunchKernelGGL(k_roll_node, dim3((unsigned)(((int64_t)a.B * a.N + 255) / 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_roll_edge, dim3((unsigned)(((int64_t)a.B * a.E + 255) / 256)), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 }  // namespace uds

@@ -440,6 +440,21 @@ int uds_flow_balance(const uds_csr_t *inc_n, const float *sign, const float *flo
   return UDS_OK;
 }
 
+int uds_roll_update(const uds_csr_t *inc_n, const float *sign, const float *span_e, const float *mini_e, const float *scale_in,
+                    const float *scale_out, const float *y, int64_t cy, const float *ey, int64_t ce, const float *b, int64_t B, int64_t so,
+                    int64_t T, int flood, float *x, float *ex, float *preds, uds_stream_t stream) {
+  UDS_REQUIRE(inc_n && sign && span_e && mini_e && scale_in && scale_out && y && ey && b && x && ex && preds, "uds_roll_update: NULL argument");
+  UDS_REQUIRE(B >= 0 && so >= 1 && T >= so && cy >= 1 && cy <= 8 && ce >= 1 && ce <= 8, "uds_roll_update: bad sizes B=%lld so=%lld T=%lld cy=%lld ce=%lld",
+              (long long)B, (long long)so, (long long)T, (long long)cy, (long long)ce);
+  UDS_REQUIRE(B * std::max(inc_n->n_rows, inc_n->n_cols) < INT32_MAX, "uds_roll_update: batch x rows exceeds the int32 index");
+  if (B == 0) return UDS_OK;
+  uds::RollArgs a{inc_n->d_rowptr, inc_n->d_col, sign, span_e, mini_e, scale_in, scale_out, y, ey, b, x, ex, preds,
+                  (int)B, (int)so, (int)T, (int)inc_n->n_rows, (int)inc_n->n_cols, (int)cy, (int)ce, flood};
+  hipError_t e = uds::launch_roll_update(a, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_roll_update: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
 int uds_csr_spmm(const uds_csr_t *csr, const float *val, const float *x, int64_t S, int64_t F, const float *bias,
                  int act, float *out, uds_stream_t stream) {
   UDS_REQUIRE(csr && x && out, "uds_csr_spmm: NULL csr/x/out");

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 5
+#define UDS_ABI_VERSION 6
 
 enum {
   UDS_OK = 0,
@@ -129,6 +129,17 @@ int uds_cumsum_act(const float *x, const float *res, int64_t B, int64_t T, int64
 int uds_flow_balance(const uds_csr_t *inc_n, const float *sign, const float *flow, int64_t S,
                      const float *scale_in, const float *scale_out, float *q_in, float *q_out,
                      uds_stream_t stream);
+
+/* One chunk of the autoregressive rollout after the forward (Emulator._model, emulator.py:403-423, with the edge-fusion
+ * branch of post_proc_tf, :717-724): flow = ey[..., ce-1] * span_e + mini_e (de-normalised link flow, per link), q_in /
+ * q_out as uds_flow_balance, preds (B,so,N,cy+2) = [y[...,0], q_in, q_out, y[...,1:]]; then both state windows are shifted
+ * by `so` steps IN PLACE and fed with the prediction: x (B,T,N,cy+3) gets [preds with the last channel thresholded at 0.5
+ * when flood != 0, b], ex (B,T,E,ce+1) gets [ey, 1].  y (B,so,N,cy), ey (B,so,E,ce), b (B,so,N,1).  Bit-identical to the
+ * tensor-by-tensor composition. */
+int uds_roll_update(const uds_csr_t *inc_n, const float *sign, const float *span_e, const float *mini_e,
+                    const float *scale_in, const float *scale_out, const float *y, int64_t cy, const float *ey,
+                    int64_t ce, const float *b, int64_t B, int64_t so, int64_t T, int flood, float *x, float *ex,
+                    float *preds, uds_stream_t stream);
 
 /* Floats of workspace uds_gat_forward needs: S * n * (d + 2). */
 int64_t uds_gat_workspace_floats(int64_t n, int64_t S, int64_t d);
