@@ -88,14 +88,26 @@ __global__ void k_pack_weight_frags(const float *__restrict__ W, int K, int F_ou
   out[((t * MB + m) * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
 }
 
+// hi = bf16(v) (round to nearest even), lo = bf16(v - hi) for 8 floats, written pair-wise so that every pair takes the
+// five-instruction form: v_cvt_pk_bf16_f32 (hi pair), shift / mask (the two hi values back as floats), v_pk_add_f32 with
+// negated operand (both differences), v_cvt_pk_bf16_f32 (lo pair).  The element-wise formulation gives the same values
+// but the compiler converts one pair of every eight separately (8 instructions for it).
 __device__ __forceinline__ void split8(const float4 &a, const float4 &b, bf16x8 &hi, bf16x8 &lo) {
-  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v[4] = {{a.x, a.y}, {a.z, a.w}, {b.x, b.y}, {b.z, b.w}};
+  unsigned hw[4], lw[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const __bf16 h = (__bf16)v[j];
-    hi[j] = h;
-    lo[j] = (__bf16)(v[j] - (float)h);
+  for (int p = 0; p < 4; ++p) {
+    const bf16x2_t h = __builtin_convertvector(v[p], bf16x2_t);
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    const f32x2_t hf = {__uint_as_float(hb << 16), __uint_as_float(hb & 0xffff0000u)};
+    const bf16x2_t l = __builtin_convertvector(v[p] - hf, bf16x2_t);
+    hw[p] = hb;
+    lw[p] = __builtin_bit_cast(unsigned, l);
   }
+  hi = __builtin_bit_cast(bf16x8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
+  lo = __builtin_bit_cast(bf16x8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
 }
 
 __device__ __forceinline__ f32x4 mfma3(const bf16x8 &wh, const bf16x8 &wl, const bf16x8 &dh, const bf16x8 &dl, f32x4 acc) {
@@ -171,7 +183,11 @@ __device__ __forceinline__ float quarters_sum(float v) {
 // ACT: UDS_ACT_* known at compile time (relu / linear fast paths), or -1 = decide at run time from a.act.
 template <int ACT>
 __device__ __forceinline__ float fused_act(float v, int act_rt) {
-  if constexpr (ACT == UDS_ACT_RELU) return fmaxf(v, 0.0f);
+  // relu as a signed-integer max on the bit pattern: negative floats (sign bit set) are negative integers, so max(bits, 0)
+  // is +0 for them and the value itself otherwise -- ONE instruction (v_max_i32).  fmaxf(v, 0) costs two: the IEEE rules
+  // make the compiler canonicalise the MFMA result first (v_max_f32 v, v, v), in every epilogue.  Same result for every
+  // finite input and +-inf; a NaN stays a NaN (as tf.nn.relu) where fmaxf would return 0.
+  if constexpr (ACT == UDS_ACT_RELU) return __int_as_float(max(__float_as_int(v), 0));
   else if constexpr (ACT == UDS_ACT_LINEAR) return v;
   else return apply_act(v, act_rt);
 }
@@ -254,6 +270,40 @@ __device__ __forceinline__ void glds16_run(const float *const (&src)[NP], unsign
                  "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), "s"(lds_byte)
+                 : "memory", "scc");
+  }
+}
+// The same run with ONE 32-bit per-lane byte offset and a wave-uniform 64-bit base in SGPRs (saddr form): piece i reads
+// base + voff + 64 i.  The instruction offset is added to the memory address AND to the LDS address, so M0 advances by
+// 1 KiB - 64 B per piece to land piece i at lds_byte + i KiB.  No 64-bit vector address arithmetic per piece and
+// snapshot (it was ~8 VALU instructions per 16-row block): the snapshot only moves the scalar base.
+template <int NP>
+__device__ __forceinline__ void glds16_run_s(const float *base, unsigned voff, unsigned lds_byte) {
+  static_assert(NP == 2 || NP == 4 || NP == 6, "pieces per run");
+  unsigned keep;
+  if constexpr (NP == 2) {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_add_u32 m0, m0, 0x3c0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:64\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base), "s"(lds_byte)
+                 : "memory", "scc");
+  } else if constexpr (NP == 4) {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_add_u32 m0, m0, 0x3c0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:64\n\t"
+                 "s_add_u32 m0, m0, 0x3c0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:128\n\t"
+                 "s_add_u32 m0, m0, 0x3c0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:192\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base), "s"(lds_byte)
+                 : "memory", "scc");
+  } else {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_add_u32 m0, m0, 0x3c0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:64\n\t"
+                 "s_add_u32 m0, m0, 0x3c0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:128\n\t"
+                 "s_add_u32 m0, m0, 0x3c0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:192\n\t"
+                 "s_add_u32 m0, m0, 0x3c0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:256\n\t"
+                 "s_add_u32 m0, m0, 0x3c0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:320\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base), "s"(lds_byte)
                  : "memory", "scc");
   }
 }
@@ -386,36 +436,24 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
   const int prow0 = wave * 16 < n_prim ? prim_row(wave) : 0;
   const bool sec_split = FS == 96 && S_.sec_in2 != nullptr, prim_split = FP == 96 && S_.prim_in2 != nullptr;
   auto dma_sec = [&](int blk, int s) {
-    const int row = blk == wave ? srow0 : (blk == wave + NW ? srow1 : sec_row(blk));
+    const unsigned row = (unsigned)(blk == wave ? srow0 : (blk == wave + NW ? srow1 : sec_row(blk)));
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(stage_s) + (unsigned)blk * (KT_S * 2 * 1024));
-    const float *pc[2 * KT_S];
-    if (sec_split) {
-      const float *sa = S_.sec_in + ((int64_t)s * S_.n_sec_glob + row) * 64 + 4 * qd;
-      const float *sb = S_.sec_in2 + ((int64_t)s * S_.n_sec_glob + row) * 32 + 4 * qd;
-#pragma unroll
-      for (int i = 0; i < 2 * KT_S; ++i) pc[i] = i < 4 ? sa + 16 * i : sb + 16 * (i - 4);
-    } else {
-      const float *src = S_.sec_in + ((int64_t)s * S_.n_sec_glob + row) * FS + 4 * qd;
-#pragma unroll
-      for (int i = 0; i < 2 * KT_S; ++i) pc[i] = src + 16 * i;      // piece (t, i) = floats 32t + 16i = 16 * (2t + i)
+    if (sec_split) {      // 96 floats from two tensors: 64 (four pieces) + 32 (two pieces)
+      glds16_run_s<4>(S_.sec_in + (int64_t)s * S_.n_sec_glob * 64, row * 256u + 16u * qd, dst);
+      glds16_run_s<2>(S_.sec_in2 + (int64_t)s * S_.n_sec_glob * 32, row * 128u + 16u * qd, dst + 4096u);
+    } else {              // piece (t, i) = floats 32t + 16i = 16 * (2t + i) of the row
+      glds16_run_s<2 * KT_S>(S_.sec_in + (int64_t)s * S_.n_sec_glob * FS, row * (unsigned)(FS * 4) + 16u * qd, dst);
     }
-    glds16_run<2 * KT_S>(pc, dst);
   };
   auto dma_prim = [&](int blk, int s) {
-    const int row = blk == wave ? prow0 : prim_row(blk);
+    const unsigned row = (unsigned)(blk == wave ? prow0 : prim_row(blk));
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(stage_p) + (unsigned)blk * (KT_X * 2 * 1024));
-    const float *pc[2 * KT_X];
     if (prim_split) {
-      const float *sa = S_.prim_in + ((int64_t)s * S_.n_prim_glob + row) * 64 + 4 * qd;
-      const float *sb = S_.prim_in2 + ((int64_t)s * S_.n_prim_glob + row) * 32 + 4 * qd;
-#pragma unroll
-      for (int i = 0; i < 2 * KT_X; ++i) pc[i] = i < 4 ? sa + 16 * i : sb + 16 * (i - 4);
+      glds16_run_s<4>(S_.prim_in + (int64_t)s * S_.n_prim_glob * 64, row * 256u + 16u * qd, dst);
+      glds16_run_s<2>(S_.prim_in2 + (int64_t)s * S_.n_prim_glob * 32, row * 128u + 16u * qd, dst + 4096u);
     } else {
-      const float *src = S_.prim_in + ((int64_t)s * S_.n_prim_glob + row) * FP + 4 * qd;
-#pragma unroll
-      for (int i = 0; i < 2 * KT_X; ++i) pc[i] = src + 16 * i;
+      glds16_run_s<2 * KT_X>(S_.prim_in + (int64_t)s * S_.n_prim_glob * FP, row * (unsigned)(FP * 4) + 16u * qd, dst);
     }
-    glds16_run<2 * KT_X>(pc, dst);
   };
 
   // P3 (the planner keeps n_own <= 4*NW*U, so one trip covers the tile: row = wave*4 + 4*NW*u + rs): the (wave-

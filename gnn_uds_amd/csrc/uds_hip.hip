@@ -965,7 +965,9 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
     if (he != hipSuccess) return fail(UDS_EHIP, "uds_spatial_layer_forward: 16-wave d=64 launch -> %s", hipGetErrorString(he));
     return UDS_OK;
   }
-  const bool shape_ok = h == uds::FUSED_H && d == uds::FUSED_D && (fx == 64 || fx == 96) && (fe == 64 || fe == 96);
+  // (rows of one snapshot are addressed with a 32-bit byte offset from a per-snapshot base: N, E < 2^31 / 384)
+  const bool shape_ok = h == uds::FUSED_H && d == uds::FUSED_D && (fx == 64 || fx == 96) && (fe == 64 || fe == 96) &&
+                        std::max(N, E) * 384 < ((int64_t)1 << 31);
   // node tiles run the variant <fx, fe>, link tiles <fe, fx>: one launch when they coincide, else one per side
   const uds_plan_slot &sl = net->slot[slot_index((int)fx, (int)fe)];
   const uds_plan_slot &sl_link = net->slot[slot_index((int)fe, (int)fx)];
