@@ -162,7 +162,7 @@ class Emulator(nn.Module):
                 if self.conv_kind != 'GAT':
                     raise NotImplementedError('graph_base with a CSR graph is built for conv=GAT')
                 build = node_based_adj_csr if self.graph_base == 1 else edge_based_adj_csr
-                self._base_filter = build(self.edges, self.n_node, bool(g('directed', False)), int(g('order', 1)), g('length', 0))
+                self._base_filter = build(self.edges, self.n_node, bool(g('directed', False)), int(g('order', 1)), g('length', 0), g('lengths', None))
             self.filter = self.edge_filter = None
         elif isinstance(graph, DrainageGraph):
             # large networks: `args.graph` (CSR, e.g. DrainageGraph.from_edges) instead of the dense (N,N) / (E,E) / (N,E)

@@ -253,16 +253,41 @@ def edge_adjacency_csr(edges, directed=False, order=1, length=0, lengths=None):
     return _csr_from_pairs(rows, cols, n_edge, n_edge)
 
 
-def node_based_adj_csr(edges, n_node=None, directed=False, order=1, length=0):
+def _gaussian_rows(g, n, sigma, cutoff):
+    """Rows of exp(-(dist / (sigma + 1e-5))^2) over the Dijkstra ball (weight 'length', cutoff inclusive) of every vertex of
+    the weighted `_OrderedGraph` g -- the `length > 0` loops of base.py:484-487,526-529.  A vertex without any edge keeps
+    itself only (the reference would raise NodeNotFound for it)."""
+    nbrs = {v: [(u, float(at['length'])) for u, at in adj.items()] for v, adj in g.succ.items()}
+    rows, cols, vals = [], [], []
+    for r in range(n):
+        for a, dist in _dijkstra_ball(nbrs, r, float(cutoff)).items():
+            v = float(np.exp(-(dist / (sigma + 1e-5)) ** 2))
+            if v > 0.0:
+                rows.append(r)
+                cols.append(a)
+                vals.append(v)
+    return _csr_from_pairs(rows, cols, n, n, vals)
+
+
+def node_based_adj_csr(edges, n_node=None, directed=False, order=1, length=0, lengths=None):
     """Sparse `get_node_based_adj` (`base.py:471-498`, `graph_base = 1`): ONE graph over the N nodes and the E links
     (vertex N + i = link i) with the edges (u, v), (u, link), (link, v) of every link; row n holds the depth-`order` DFS
-    ball of n, symmetrised unless `directed`."""
-    if length:
-        raise NotImplementedError('graph_base with length > 0 (Gaussian kernel over the combined graph) is not built')
+    ball of n, symmetrised unless `directed`.  `length > 0` (needs `lengths`, one per link): every one of the three edges
+    of link i weighs lengths[i] / 2 and row n holds the Gaussian kernel over the Dijkstra ball of radius `length`."""
     edges = _check_edges(edges)
     if n_node is None:
         n_node = int(edges.max()) + 1 if edges.size else 0
     n = n_node + edges.shape[0]
+    if length:
+        if lengths is None:
+            raise ValueError('length > 0 needs the link lengths')
+        lengths = np.asarray(lengths, dtype=np.float64)
+        g = _OrderedGraph(directed)
+        for i, ((u, v), ln) in enumerate(zip(edges, lengths)):
+            g.add_edge(int(u), int(v), length=ln / 2)
+            g.add_edge(int(u), n_node + i, length=ln / 2)
+            g.add_edge(n_node + i, int(v), length=ln / 2)
+        return _gaussian_rows(g, n, float(np.std(lengths)), length)
     me = np.arange(n, dtype=np.int64)
     if order <= 0:
         return _csr_from_pairs(me, me, n, n)
@@ -282,41 +307,45 @@ def node_based_adj_csr(edges, n_node=None, directed=False, order=1, length=0):
     return _csr_from_pairs(rows, cols, n, n)
 
 
-def edge_based_adj_csr(edges, n_node=None, directed=False, order=1, length=0):
+def edge_based_adj_csr(edges, n_node=None, directed=False, order=1, length=0, lengths=None):
     """Sparse `get_edge_based_adj` (`base.py:500-532`, `graph_base = 2`): the line graph (links meeting at a node) plus
     an edge between every link and its end nodes, over the N + E vertices; row n = depth-`order` DFS ball, NOT symmetrised
-    (as the reference)."""
-    if length:
-        raise NotImplementedError('graph_base with length > 0 (Gaussian kernel over the combined graph) is not built')
+    (as the reference).  `length > 0` (needs `lengths`): two links meeting at a node are (l_p + l_q) / 2 apart, a link and
+    its end node l / 2; row n holds the Gaussian kernel over the Dijkstra ball of radius `length`."""
     edges = _check_edges(edges)
     if n_node is None:
         n_node = int(edges.max()) + 1 if edges.size else 0
     n = n_node + edges.shape[0]
     me = np.arange(n, dtype=np.int64)
-    if order <= 0:
+    if length and lengths is None:
+        raise ValueError('length > 0 needs the link lengths')
+    if order <= 0 and not length:
         return _csr_from_pairs(me, me, n, n)
+    ln_of = np.asarray(lengths, dtype=np.float64) if length else np.zeros(edges.shape[0])
     g = _OrderedGraph(directed)
     for i, (u, v) in enumerate(edges):
-        g.add_edge(int(u), int(v), edge=n_node + i)
+        g.add_edge(int(u), int(v), edge=n_node + i, length=float(ln_of[i]))
     ex = _OrderedGraph(directed)
     for v in list(g.succ):
         if directed:
-            ins = [g.succ[a][v]['edge'] for a in g.pred[v]]
-            outs = [g.succ[v][d]['edge'] for d in g.succ[v]]
+            ins = [g.succ[a][v] for a in g.pred[v]]
+            outs = [g.succ[v][d] for d in g.succ[v]]
             for p in ins:
                 for q in outs:
-                    ex.add_edge(p, q)
+                    ex.add_edge(p['edge'], q['edge'], length=(p['length'] + q['length']) / 2)
             for p in ins:
-                ex.add_edge(p, v)
+                ex.add_edge(p['edge'], v, length=p['length'] / 2)
             for q in outs:
-                ex.add_edge(v, q)
+                ex.add_edge(v, q['edge'], length=q['length'] / 2)
         else:
-            inc = [g.succ[v][b]['edge'] for b in g.succ[v]]
+            inc = [g.succ[v][b] for b in g.succ[v]]
             for i in range(len(inc)):
                 for j in range(i + 1, len(inc)):
-                    ex.add_edge(inc[i], inc[j])
+                    ex.add_edge(inc[i]['edge'], inc[j]['edge'], length=(inc[i]['length'] + inc[j]['length']) / 2)
             for p in inc:
-                ex.add_edge(p, v)
+                ex.add_edge(p['edge'], v, length=p['length'] / 2)
+    if length:
+        return _gaussian_rows(ex, n, float(np.std(ln_of)), length)
     rows, cols = [], []
     for r in range(n):
         for a in ex.ball(r, order):

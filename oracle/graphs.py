@@ -84,12 +84,23 @@ def edge_adjacency(edges, directed=False, length=0, order=1, lengths=None):
     return adj
 
 
-def node_based_adjacency(edges, directed=False, order=1):
-    """`get_node_based_adj` with length = 0 (`base.py:471-498`): nodes and links in one graph, vertex n_node + i = link i."""
+def node_based_adjacency(edges, directed=False, order=1, length=0, lengths=None):
+    """`get_node_based_adj` (`base.py:471-498`): nodes and links in one graph, vertex n_node + i = link i; with length > 0 the
+    three edges of link i weigh lengths[i] / 2 and the entries are the Gaussian kernel over the Dijkstra ball (:479-487)."""
     edges = np.asarray(edges)
     n_node, n_edge = int(edges.max()) + 1, edges.shape[0]
     adj = np.zeros((n_node + n_edge, n_node + n_edge))
     g = nx.DiGraph() if directed else nx.Graph()
+    if length:
+        sigma = np.std(lengths)
+        for i, ((u, v), ln) in enumerate(zip(edges, lengths)):
+            g.add_edge(int(u), int(v), length=ln / 2)
+            g.add_edge(int(u), n_node + i, length=ln / 2)
+            g.add_edge(n_node + i, int(v), length=ln / 2)
+        for n in range(n_node + n_edge):
+            for a, dist in nx.single_source_dijkstra_path_length(g, n, weight='length', cutoff=length).items():
+                adj[n, a] = np.exp(-(dist / (sigma + 1e-5)) ** 2)
+        return adj
     for i, (u, v) in enumerate(edges):
         g.add_edge(int(u), int(v))
         g.add_edge(int(u), n_node + i)
@@ -102,28 +113,35 @@ def node_based_adjacency(edges, directed=False, order=1):
     return adj
 
 
-def edge_based_adjacency(edges, directed=False, order=1):
-    """`get_edge_based_adj` with length = 0 (`base.py:500-532`)."""
+def edge_based_adjacency(edges, directed=False, order=1, length=0, lengths=None):
+    """`get_edge_based_adj` (`base.py:500-532`); length > 0: link pairs (l_p + l_q) / 2 apart, link -- end node l / 2, entries
+    = Gaussian kernel over the Dijkstra ball (:526-529)."""
     from itertools import product
     edges = np.asarray(edges)
     n_node, n_edge = int(edges.max()) + 1, edges.shape[0]
     g = nx.DiGraph() if directed else nx.Graph()
     for i, (u, v) in enumerate(edges):
-        g.add_edge(int(u), int(v), edge=n_node + i)
+        g.add_edge(int(u), int(v), edge=n_node + i, length=lengths[i] if length else 0)
     ex = nx.DiGraph() if directed else nx.Graph()
     for n in g.nodes():
         pairs = product(g.in_edges(n), g.out_edges(n)) if directed else combinations(g.edges(n), 2)
         for (a, b), (c, d) in pairs:
-            ex.add_edge(g[a][b]['edge'], g[c][d]['edge'])
+            ex.add_edge(g[a][b]['edge'], g[c][d]['edge'], length=(g[a][b]['length'] + g[c][d]['length']) / 2 if length else 0)
         if directed:
             for a, b in g.in_edges(n):
-                ex.add_edge(g[a][b]['edge'], n)
+                ex.add_edge(g[a][b]['edge'], n, length=g[a][b]['length'] / 2 if length else 0)
             for c, d in g.out_edges(n):
-                ex.add_edge(n, g[c][d]['edge'])
+                ex.add_edge(n, g[c][d]['edge'], length=g[c][d]['length'] / 2 if length else 0)
         else:
             for a, b in g.edges(n):
-                ex.add_edge(g[a][b]['edge'], n)
+                ex.add_edge(g[a][b]['edge'], n, length=g[a][b]['length'] / 2 if length else 0)
     adj = np.zeros((n_node + n_edge, n_node + n_edge))
+    if length:
+        sigma = np.std(lengths)
+        for n in range(n_node + n_edge):
+            for a, dist in nx.single_source_dijkstra_path_length(ex, n, weight='length', cutoff=length).items():
+                adj[n, a] = np.exp(-(dist / (sigma + 1e-5)) ** 2)
+        return adj
     for n in range(n_node + n_edge):
         for a in (list(nx.dfs_preorder_nodes(ex, n, order)) if order > 0 else [n]):
             adj[n, a] = 1

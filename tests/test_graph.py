@@ -148,5 +148,16 @@ def test_graph_base_adjacencies_match_the_networkx_oracle(networks, name):
             b = G.edge_based_adj_csr(e, None, directed, order)
             assert np.array_equal(b.to_dense(), OG.edge_based_adjacency(e, directed, order))
             assert a.n_rows == b.n_rows == int(e.max()) + 1 + len(e)
-    with pytest.raises(NotImplementedError):
+    # length > 0: Gaussian kernel over the Dijkstra ball of the combined graph (base.py:479-487,526-529), CSR == networkx
+    rng = np.random.default_rng(3)
+    lengths = 20.0 + 200.0 * rng.random(len(e))
+    for directed in (False, True):
+        for cutoff in (60.0, 250.0):
+            a = G.node_based_adj_csr(e, None, directed, 1, cutoff, lengths)
+            ra = OG.node_based_adjacency(e, directed, 1, cutoff, lengths)
+            assert np.array_equal(a.to_dense() > 0, ra > 0) and np.allclose(a.to_dense(), ra, rtol=1e-12, atol=0)
+            b = G.edge_based_adj_csr(e, None, directed, 1, cutoff, lengths)
+            rb = OG.edge_based_adjacency(e, directed, 1, cutoff, lengths)
+            assert np.array_equal(b.to_dense() > 0, rb > 0) and np.allclose(b.to_dense(), rb, rtol=1e-12, atol=0)
+    with pytest.raises(ValueError):
         G.node_based_adj_csr(e, None, False, 1, length=100.0)
