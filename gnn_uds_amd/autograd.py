@@ -35,6 +35,22 @@ def act_grad(y, gy, act):
     raise ValueError('unknown activation %r' % (act,))
 
 
+def apply_activation(x, act):
+    """The layer activations as differentiable tensor ops (used where no fused kernel applies them)."""
+    act = act or 'linear'
+    if act == 'linear':
+        return x
+    if act == 'relu':
+        return torch.relu(x)
+    if act == 'tanh':
+        return torch.tanh(x)
+    if act == 'sigmoid':
+        return torch.sigmoid(x)
+    if act == 'hard_sigmoid':
+        return torch.clamp(0.2 * x + 0.5, 0.0, 1.0)
+    raise ValueError('unknown activation %r' % (act,))
+
+
 def rows_matmul(x, w, precision='bf16x3'):
     """x (..., K) @ w (K, M) on the HIP row-GEMM kernels (matrix cores where the shape allows, in <= 64-column pieces)."""
     x = x.contiguous()

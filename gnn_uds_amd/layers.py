@@ -213,6 +213,7 @@ class GCNConv(nn.Module):
     def __init__(self, channels, activation=None, use_bias=True, in_channels=None, generator=None):
         super().__init__()
         self.channels, self.activation, self.use_bias = int(channels), activation or 'linear', use_bias
+        self.units, self.precision = self.channels, 'fp32'      # what autograd.DenseFn reads from its module (exact-fp32 kernels)
         self._gen = generator
         self._cache = {}
         self.kernel = self.bias = None
@@ -248,10 +249,17 @@ class GCNConv(nn.Module):
         x, a = inputs
         if self.kernel is None:
             self.build(x.shape[-1], x.device)
-        if _ag.grad_on(x, self.kernel, self.bias):
-            raise NotImplementedError('training through GCNConv is not built (GAT is)')
         h, val = self._filter(a, x.device)
         xs, lead = _flatten_snapshots(x)
+        if _ag.grad_on(x, self.kernel, self.bias):
+            # training: x @ kernel and the propagation a_hat @ (.) through their autograd Functions (the filter values are
+            # constants: no gradient), bias + activation as tensor ops
+            hx = _ag.DenseFn.apply(xs, self.kernel, None, self, 'linear')
+            out = _ag.SpmmFn.apply(val, hx, h)
+            if self.bias is not None:
+                out = out + self.bias
+            out = _ag.apply_activation(out, self.activation)
+            return out.reshape(lead + out.shape[-2:])
         hx = _lib.dense_act(xs, self.kernel, None, 'linear')
         out = _lib.csr_spmm(h, val, hx, self.bias, self.activation)
         return out.reshape(lead + out.shape[-2:])
@@ -436,8 +444,6 @@ class SpatialLayer(nn.Module):
         xbs = None if xb is None else _flatten_snapshots(xb)[0]
         ebs = None if eb is None else _flatten_snapshots(eb)[0]
         if self.conv == 'GCN':     # a_hat @ ([x | agg] W) + b: unfused composition of the Dense / NodeEdge / spmm kernels
-            if _ag.grad_on(xs, es, *self.parameters()):
-                raise NotImplementedError('training through the GCN spatial layer is not built (GAT is)')
             x_e, e_x = self.dense_xe(es), self.dense_ex(xs)
             ox = self.gcn_x([torch.cat([xs, self.node_edge_n(x_e)], dim=-1), self.filters[0]])
             oe = self.gcn_e([torch.cat([es, self.node_edge_e(e_x)], dim=-1), self.filters[1]])

@@ -152,7 +152,11 @@ def emulator_param_pairs(emul, flat):
                 m = m[int(part)]
             elif part == 'gat' and not hasattr(m, 'gat'):
                 pass                              # graph_base: the layer IS the conv
+            elif part in ('gat_x', 'gat_e') and not hasattr(m, part):
+                m = getattr(m, part.replace('gat', 'gcn'))      # conv = GCN: the oracle keeps the key, the module is gcn_x / gcn_e
             else:
                 m = getattr(m, part)
+        if parts[-1].startswith('attn_kernel') and not hasattr(m, parts[-1]):
+            continue                              # conv = GCN: the oracle's parameter tree keeps the (unused) attention vectors
         out.append((name, getattr(m, parts[-1]), t))
     return out
