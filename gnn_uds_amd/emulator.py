@@ -616,8 +616,6 @@ class Emulator(nn.Module):
         """One training (fit=True) or evaluation step on NORMALISED tensors (emulator.py:457-484): forward through
         `_model`, node MSE (+ weighted flood BCE) + link MSE, reverse mode through the HIP operators (autograd.py), Adam with
         per-variable clipnorm=1.  Returns [node_loss, (flood_loss,) edge_loss] as 0-d tensors."""
-        if self.gradnorm:
-            raise NotImplementedError('gradnorm multi-task weighting (emulator.py:486-519) is not built')
         params = [p for p in self.parameters()]
         if fit:
             for p in params:
@@ -631,10 +629,13 @@ class Emulator(nn.Module):
             edge_loss = self._mse(ey, edge_preds, lw['ewei'])
             if fit:
                 loss = node_loss + edge_loss
+                if self.gradnorm:                    # GradNorm task weights (emulator.py:470-473): constants for this step
+                    alpha = self._alphas(preds.device)
+                    loss = alpha[0].detach() * loss
                 if self.if_flood:
                     if fl_loss is None:
                         raise NotImplementedError('if_flood with balance: the reference leaves fl_loss undefined here (emulator.py:466,473)')
-                    loss = loss + fl_loss
+                    loss = loss + (alpha[1].detach() * fl_loss if self.gradnorm else fl_loss)
                 if not bool(torch.isfinite(loss)):
                     raise FloatingPointError('Loss contains NaN or Inf values.')
                 for p in params:
@@ -647,6 +648,52 @@ class Emulator(nn.Module):
                 self._optimizer.step()
         out = [node_loss.detach()] + ([fl_loss.detach()] if self.if_flood and fl_loss is not None else []) + [edge_loss.detach()]
         return out
+
+    # ------------------------------------------------------------------ GradNorm (:118-125,486-519)
+    def _alphas(self, device):
+        """[alpha_reg, alpha_cls]: the two trainable task weights (initially 1, kept at sum 2), with their own Adam(1e-4)."""
+        if getattr(self, '_alpha', None) is None or self._alpha.device != device:
+            self._alpha = torch.ones(2, device=device, dtype=torch.float32, requires_grad=True)
+            self._alpha_optimizer = KerasAdam([self._alpha], 1e-4)
+        return self._alpha
+
+    def fit_grad_norm(self, x, a, b, y, ex, ey, ini_loss):
+        """One GradNorm update of the task weights (`fit_grad_norm` / `_get_grad_norm`, emulator.py:486-519): the norms of
+        alpha_task * d loss_task / d W at the shared layer W = `dense_resx` kernel are pulled (mean absolute error) towards
+        mean(norms) * (relative inverse training rate) ** 0.5; one Adam(1e-4) step on the alphas, then they are rescaled to
+        sum 2.  ini_loss = [node, flood, edge] losses of the first step.  Returns the alpha loss (0-d tensor)."""
+        if not self.gradnorm:
+            raise ValueError('fit_grad_norm needs args.gradnorm = True')
+        if not self.if_flood:
+            raise ValueError('GradNorm balances the regression and the flood-classification task: it needs if_flood')
+        W = self.res_x.kernel
+        flags = [(p, p.requires_grad) for p in self.parameters()]
+        for p, _ in flags:
+            p.requires_grad_(p is W)
+        try:
+            with torch.enable_grad():
+                ae = self.get_edge_action(a, True) if self.act else None
+                preds, edge_preds = self._model(x, a, b, ex, ae, None)
+                lw = self._loss_setup(preds.device)
+                reg_loss = self.get_node_loss(y, b, preds) + self._mse(ey, edge_preds, lw['ewei'])
+                fl_loss = self.get_flood_loss(y, preds)
+                g_reg, = torch.autograd.grad(reg_loss, W, retain_graph=True)
+                g_cls, = torch.autograd.grad(fl_loss, W)
+                alpha = self._alphas(preds.device)
+                norms = torch.stack([(alpha[0] * g_reg.detach()).norm(), (alpha[1] * g_cls.detach()).norm()])
+                ini = [float(v) for v in ini_loss]
+                r = torch.stack([reg_loss.detach() / (ini[0] + ini[-1]), fl_loss.detach() / ini[1]])
+                target = norms.detach().mean() * (r / r.mean()) ** 0.5
+                alpha_loss = (target - norms).abs().mean()
+                alpha.grad = None
+                alpha_loss.backward()
+            self._alpha_optimizer.step()
+            with torch.no_grad():
+                alpha.mul_(2.0 / alpha.sum())
+        finally:
+            for p, f in flags:
+                p.requires_grad_(f)
+        return alpha_loss.detach()
 
     # ------------------------------------------------------------------ Keras checkpoints (:814-852, SURVEY.md Appendix B)
     def keras_layer_map(self):

@@ -119,3 +119,30 @@ class Adam:
                 m.mul_(self.b1).add_(g, alpha=1 - self.b1)
                 v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
                 p.sub_(lr_t * m / (v.sqrt() + self.eps))
+
+
+def grad_norm_step(args, params, norms, x, a, b, y, ex, ey, ini_loss, alpha, opt):
+    """`fit_grad_norm` + `_get_grad_norm` (emulator.py:486-519) on the oracle: alpha = tensor([alpha_reg, alpha_cls]) (updated
+    in place: one Adam(1e-4) step of `opt`, then rescaled to sum 2); returns the alpha loss.  W = dense_resx kernel = params['res_x']."""
+    c = ER.config(args)
+    lw = loss_weights(args, x.dtype)
+    W = params['res_x']['kernel']
+    W.requires_grad_(True)
+    preds, edge_preds = model(args, params, norms, x, a, b, ex)
+    reg = mse(y[..., :3] * lw['nwei'], preds[..., :3] * lw['nwei']) + mse(ey, edge_preds, lw['ewei'])
+    weight = lw['poswei'] * y[..., -2] + lw['nwei'][:, -1] * (1 - y[..., -2])
+    fl = bce(y[..., -2:-1], preds[..., -1:], weight)
+    g_reg, = torch.autograd.grad(reg, W, retain_graph=True)
+    g_cls, = torch.autograd.grad(fl, W)
+    W.requires_grad_(False)
+    alpha.requires_grad_(True)
+    nrm = torch.stack([(alpha[0] * g_reg).norm(), (alpha[1] * g_cls).norm()])
+    r = torch.stack([reg.detach() / (ini_loss[0] + ini_loss[-1]), fl.detach() / ini_loss[1]])
+    target = nrm.detach().mean() * (r / r.mean()) ** 0.5
+    loss = (target - nrm).abs().mean()
+    g, = torch.autograd.grad(loss, alpha)
+    alpha.requires_grad_(False)
+    opt.step([('alpha', alpha)], {'alpha': g})
+    with torch.no_grad():
+        alpha.mul_(2.0 / alpha.sum())
+    return loss.detach()

@@ -282,6 +282,26 @@ def test_fit_eval_steps_match_oracle_adam(dev, networks):
     assert len(ev) == 3 and all(np.isfinite(float(v)) for v in ev)
 
 
+def test_grad_norm_task_weights_match_the_oracle(dev, networks):
+    """GradNorm (`fit_grad_norm`, emulator.py:486-519): two updates of [alpha_reg, alpha_cls] against the fp64 restatement
+    (oracle.train_ref.grad_norm_step); the weights stay at sum 2 and the weighted training step still runs."""
+    args, norms, params, emul, cpu_in, dev_in = _problem(networks, 'astlingen', dev, embed_size=64, n_sp_layer=1, gradnorm=True)
+    x, a, b, y, ex, ey = cpu_in
+    ini_ref = [float(l) for l in OT.losses(args, params, norms, x, a, b, y, ex, ey)]
+    ini = [float(l) for l in emul.fit_eval(*dev_in, fit=False)]
+    assert np.allclose(ini, ini_ref, rtol=2e-3, atol=1e-6)
+    alpha = torch.ones(2, dtype=torch.float64)
+    opt = OT.Adam(lr=1e-4, clipnorm=None)
+    for _ in range(2):
+        ref_loss = OT.grad_norm_step(args, params, norms, x, a, b, y, ex, ey, ini_ref, alpha, opt)
+        got_loss = emul.fit_grad_norm(*dev_in, ini_ref)
+        assert abs(float(got_loss) - float(ref_loss)) <= 2e-3 * abs(float(ref_loss)) + 1e-9
+        got = emul._alphas(dev).detach().double().cpu()
+        assert abs(float(got.sum()) - 2.0) < 1e-6 and torch.allclose(got, alpha, rtol=0, atol=2e-6), (got, alpha)
+    ls = emul.fit_eval(*dev_in)                                  # the alpha-weighted step
+    assert len(ls) == 3 and all(np.isfinite(float(v)) for v in ls)
+
+
 def test_fit_eval_reduces_the_loss(dev, networks):
     args, norms, params, emul, cpu_in, dev_in = _problem(networks, 'hague', dev, n_sp_layer=2, learning_rate=2e-3)
     first = sum(float(v) for v in emul.fit_eval(*dev_in))
