@@ -165,7 +165,7 @@ def bench_c4(args, U, dist, world, rank, dev):
         dist.barrier()
     wall = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        t = torch.tensor([wall], device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     if rank == 0:
@@ -232,7 +232,7 @@ def bench_c5(args, U, dist, world, rank, dev):
         dist.barrier()
     wall = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        t = torch.tensor([wall], device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     if rank == 0:
@@ -277,13 +277,21 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the engine has no CPU path')
+    # UDS_DIST_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks share the cards, the timing
+    # reduction goes through the host); the driver's runs use the default: one rank per GPU over RCCL
+    backend = os.environ.get('UDS_DIST_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import gnn_uds_amd as U
 
@@ -321,7 +329,7 @@ def main():
         dist.barrier()
     wall = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        t = torch.tensor([wall], device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     dev_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))      # device time of one step
