@@ -11,9 +11,10 @@ import numpy as np
 import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the runtime we bind to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libuds_hip.so')
+# UDS_LIB_PATH: a differently built copy of the same library (kernel experiments: tools/variant_bench.py)
+LIB_PATH = os.environ.get('UDS_LIB_PATH') or os.path.join(_HERE, 'libuds_hip.so')
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
 PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
 
@@ -62,7 +63,7 @@ SYMBOLS = {
     'uds_tile_plan_destroy': (_c_int, [_c_ptr]),
     'uds_tile_plan_sizes': (_c_int, [_c_ptr, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64), _c_ptr]),
     'uds_tile_plan_copy': (_c_int, [_c_ptr, _c_ptr, _c_ptr]),
-    'uds_tile_plan_schedule': (_c_int, [_c_ptr, _c_ptr, _c_ptr]),
+    'uds_tile_plan_blocks': (_c_int, [_c_ptr, _c_ptr, ctypes.POINTER(_c_i64)]),
     'uds_roll_update': (_c_int, [_c_ptr] * 7 + [_c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'uds_spatial_workspace_floats': (_c_i64, [_c_ptr, _c_i64, _c_i64, _c_i64]),
     'uds_spatial_packed_bytes': (_c_i64, []),
@@ -241,11 +242,11 @@ class NetworkHandle:
             _lib.uds_network_destroy(h)
 
 
-def tile_plan(graph, t_node=48, t_link=48, p_limit=0, q_limit=0, schedule=False):
+def tile_plan(graph, t_node=48, t_link=48, p_limit=0, q_limit=0, blocks=False):
     """Host-only tile plan of a DrainageGraph (no GPU needed): returns (hdr (T,8) int32, pool int32, caps).
     hdr columns: n_own, n_prim, n_sec, n_inc, n_adj, pool_off, side, meta_len (csrc/tile_plan.hpp).
-    schedule=True adds caps['schedule']: the balanced static schedule, (workgroups, ints per record) int32, or None when
-    a workgroup would need too many pieces (include/uds_hip.h: uds_tile_plan_schedule)."""
+    blocks=True adds caps['blocks']: the (T, stride) int32 tile blocks the fused d = 64 kernel fetches (fixed-width index
+    lists; include/uds_hip.h: uds_tile_plan_blocks), or None when a tile exceeds the byte-wide local indices."""
     lib = load()
     arrs = []
     for c in (graph.adj, graph.edge_adj, graph.inc_n, graph.inc_e):
@@ -260,18 +261,17 @@ def tile_plan(graph, t_node=48, t_link=48, p_limit=0, q_limit=0, schedule=False)
         hdr = np.zeros((nt.value, 8), dtype=np.int32)
         pool = np.zeros(pl.value, dtype=np.int32)
         _check(lib.uds_tile_plan_copy(h, hdr.ctypes.data, pool.ctypes.data), 'uds_tile_plan_copy')
-        sched = None
-        if schedule:
-            dims = np.zeros(3, dtype=np.int32)
-            _check(lib.uds_tile_plan_schedule(h, None, dims.ctypes.data), 'uds_tile_plan_schedule')
-            sched = np.zeros((int(dims[0]), int(dims[1])), dtype=np.int32)
-            if lib.uds_tile_plan_schedule(h, sched.ctypes.data, dims.ctypes.data) != 0:
-                sched = None
+        blk = None
+        if blocks:
+            stride = _c_i64()
+            if lib.uds_tile_plan_blocks(h, None, ctypes.byref(stride)) == 0:
+                blk = np.zeros((nt.value, stride.value), dtype=np.int32)
+                _check(lib.uds_tile_plan_blocks(h, blk.ctypes.data, ctypes.byref(stride)), 'uds_tile_plan_blocks')
     finally:
         lib.uds_tile_plan_destroy(h)
     out = dict(p_cap=int(caps[0]), q_cap=int(caps[1]), meta_cap=int(caps[2]))
-    if schedule:
-        out['schedule'] = sched
+    if blocks:
+        out['blocks'] = blk
     return hdr, pool, out
 
 

@@ -58,8 +58,7 @@ struct FusedSide {
 struct FusedArgs {
   FusedSide side[2];
   const int32_t *hdr, *pool;
-  const int32_t *blocks;     // k_fused_tile: per tile of the list one block [header 8 | metadata | pad] of meta_cap ints
-  const int32_t *sched;      // balanced static schedule (tile_plan.hpp: build_schedule), or nullptr: workgroup = (tile, chunk)
+  const int32_t *blocks;     // k_fused_tile: per tile of the list one block [header 8 | fixed-width index lists] of meta_cap ints (tile_plan.hpp)
   int n_tiles, S, chunk, p_cap, q_cap, meta_cap, act, side_mask;
   unsigned long long *dbg;   // diagnostic builds only (UDS_PHASE_TIMING): 8 cycle sums per wave
 };
@@ -234,6 +233,23 @@ __device__ __forceinline__ void wait_all_but(int n) {
     default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
   }
 }
+// Counted wait with a wave-uniform run-time count: all but the n youngest vector-memory operations of this wave are done.
+// gfx950 has no register form of s_waitcnt, so the count is rounded DOWN to an even number <= 24 (waiting for more than
+// asked is always safe) and picked by a four-level tree of scalar compares.
+__device__ __forceinline__ void wait_vm(int n) {
+#define UDS_VMC(k) asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory")
+  if (n >= 16) {
+    if (n >= 20) { if (n >= 24) UDS_VMC(24); else if (n >= 22) UDS_VMC(22); else UDS_VMC(20); }
+    else { if (n >= 18) UDS_VMC(18); else UDS_VMC(16); }
+  } else if (n >= 8) {
+    if (n >= 12) { if (n >= 14) UDS_VMC(14); else UDS_VMC(12); }
+    else { if (n >= 10) UDS_VMC(10); else UDS_VMC(8); }
+  } else {
+    if (n >= 4) { if (n >= 6) UDS_VMC(6); else UDS_VMC(4); }
+    else { if (n >= 2) UDS_VMC(2); else UDS_VMC(0); }
+  }
+#undef UDS_VMC
+}
 
 // One 16-B-per-lane LDS-DMA piece (1 KiB per wave): global `src` (per lane) -> LDS `lds_byte` + lane * 16 (wave-
 // uniform base in M0).  Written as inline asm on purpose: hipcc orders every later LDS read behind a DMA it can see
@@ -328,48 +344,32 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, qd = lane >> 4;
+  const int c16 = r16, rs = qd;                  // P3 mapping: 16 lanes x float4 per output row, 4 rows per group
 
   // XCD-aware bijective remap: workgroups b, b+8, b+16.. share an XCD (round-robin dispatch), give each XCD
   // a contiguous range of work items so neighbouring tiles of one snapshot chunk meet in one L2.
   const int W = gridDim.x, b = blockIdx.x;
   const int q8 = W / 8, r8 = W % 8, xcd = b % 8;
   const int w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
-  // Work of this workgroup: with a schedule, up to SCHED_MAX_SEG pieces (tile, snapshot range) of equal total cost per
-  // workgroup; else one piece, (tile, chunk) from the grid index.
-  const int32_t *sg = a.sched ? a.sched + w * SCHED_INTS : nullptr;
-  const int n_seg = sg ? sg[0] : 1;
-  bool ran = false;
-  for (int seg = 0; seg < n_seg; ++seg) {
-  int tile, s_begin, s_end;
-  if (sg) {
-    tile = sg[1 + 3 * seg];
-    s_begin = (int)(((int64_t)a.S * sg[2 + 3 * seg] + 32768) >> 16);
-    s_end = (int)(((int64_t)a.S * sg[3 + 3 * seg] + 32768) >> 16);
-    if (s_begin >= s_end) continue;
-    if (ran) __syncthreads();      // the previous piece's readers of meta / hx / the stage are done before they are rewritten
-    ran = true;
-  } else {
-    tile = w % a.n_tiles;
-    const int chunk_id = w / a.n_tiles;
-    s_begin = chunk_id * a.chunk;
-    s_end = min(a.S, (chunk_id + 1) * a.chunk);
-  }
-  // Set-up is two dependent round trips, ~4 and ~5 us under load (tools/tile_cost_fit.py): (1) everything that needs no
-  // metadata -- the side's weight fragments, attention vectors, biases -- together with the tile's block (header +
-  // metadata at a fixed stride, so nothing has to be known before the fetch); (2) the first snapshot's rows and the
-  // NodeEdge values the metadata points at.  The side comes from the (scalar-cached) header array.
+  const int tile = w % a.n_tiles;
+  const int chunk_id = w / a.n_tiles;
+  const int s_begin = chunk_id * a.chunk;
+  const int s_end = min(a.S, (chunk_id + 1) * a.chunk);
+  // Set-up is two dependent round trips: (1) everything that needs no metadata -- the side's weight fragments, attention
+  // vectors, biases -- together with the tile's block (header + index lists at a fixed stride, so nothing has to be known
+  // before the fetch); (2) the first snapshot's rows and the NodeEdge values the lists point at.  The side comes from the
+  // (scalar-cached) header array.
   const int sd = __builtin_amdgcn_readfirstlane(a.hdr[tile * TILE_HDR_INTS + 6]);
   if (!((a.side_mask >> sd) & 1)) return;
   const FusedSide &S_ = a.side[sd];
   constexpr bool COLD_X = FP > 64, COLD_S = FS > 64 || SMALL_IN_LDS;
   constexpr int T_COLD_X = KT_X - 1, T_COLD_S = SMALL_IN_LDS ? 0 : KT_S - 1;     // first k-step that lives in LDS
   constexpr int N_COLD_S = (KT_S - T_COLD_S) * MB_S * 2 * 64;
-  const int c16 = lane & 15, rs = lane >> 4;     // P3 mapping: 16 lanes x float4 per output row, 4 rows per group
   float *s_self = reinterpret_cast<float *>(smem + a.meta_cap);
   float *s_nbr = s_self + a.p_cap;
-  float *attn = s_nbr + a.p_cap;                 // a_self[64] | a_nbr[64]
+  float *attn = s_nbr + a.p_cap;                 // a_self[64] | a_nbr[64] | b_small[32]
   // 96-wide inputs: the weight fragments of the third 32-wide k-step stay in LDS ("cold": read per 16-row block) so
-  // that the register-resident set is the same as for 64-wide inputs (no spills)
+  // that the register-resident set is the same as for 64-wide inputs
   uint4 *cold_b = reinterpret_cast<uint4 *>(attn + 2 * FUSED_D + FUSED_H);     // MB_B x 2 fragments x 64 lanes
   uint4 *cold_s = cold_b + (COLD_X ? MB_B * 2 * 64 : 0);                        // (KT_S - T_COLD_S) x MB_S x 2 fragments x 64 lanes
   // weight fragments straight from global memory into registers (every wave reads the same 22-45 KB: L2 / L1 hits after the first)
@@ -409,97 +409,124 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
     if (tid < FUSED_H) attn[2 * FUSED_D + tid] = S_.b_small ? S_.b_small[tid] : 0.f;
   }
   __syncthreads();
-  UDS_STAMP(7);   // tile block (header + metadata) fetched
+  UDS_STAMP(7);   // tile block (header + index lists) fetched
   const int n_own = __builtin_amdgcn_readfirstlane(smem[0]), n_prim = __builtin_amdgcn_readfirstlane(smem[1]),
-            n_sec = __builtin_amdgcn_readfirstlane(smem[2]), n_inc = __builtin_amdgcn_readfirstlane(smem[3]);
+            n_sec = __builtin_amdgcn_readfirstlane(smem[2]), flags = __builtin_amdgcn_readfirstlane(smem[3]),
+            n_ovf = __builtin_amdgcn_readfirstlane(smem[4]), n_adj = __builtin_amdgcn_readfirstlane(smem[5]),
+            inc_width = __builtin_amdgcn_readfirstlane(smem[7]);
+  const EllOffsets off = ell_offsets(n_own, n_prim, n_sec, flags, n_ovf, n_adj);      // section offsets inside the block (tile_plan.hpp)
 
-  int32_t *meta = smem + TILE_HDR_INTS;
   float *sec = reinterpret_cast<float *>(cold_s + (COLD_S ? N_COLD_S : 0));
   float *hx = sec + a.q_cap * SEC_STRIDE;
   float *stage_s = hx + a.p_cap * FUSED_D;       // (q_cap/16) blocks x KT_S x 2 pieces x 1 KiB, fragment order
   float *stage_p = stage_s + a.q_cap * FS;       // (p_cap/16) blocks x KT_X x 2 pieces x 1 KiB
 
-  const int32_t *prim_ids = meta;
-  const int32_t *sec_ids = prim_ids + n_prim;
-  const int32_t *inc_ptr = sec_ids + n_sec;
-  const int32_t *inc_loc = inc_ptr + n_prim + 1;
-  int32_t *inc_w = const_cast<int32_t *>(inc_loc) + n_inc;
-  const int32_t *adj_ptr = inc_w + n_inc;
-  const int32_t *adj_loc = adj_ptr + n_own + 1;
-  const float *inc_val = reinterpret_cast<const float *>(inc_w);
+  const int32_t *prim_ids = smem + off.prim;
+  const int32_t *sec_ids = smem + off.sec;
+  const uint32_t *inc_loc = reinterpret_cast<const uint32_t *>(smem + off.inc_loc);      // 4 x u8 local secondary rows per primary row
+  int32_t *inc_w = smem + off.inc_w;                                                      // 4 value positions per primary row -> 4 values
+  const f32x4 *inc_val4 = reinterpret_cast<const f32x4 *>(inc_w);
+  const unsigned char *adj_b = reinterpret_cast<const unsigned char *>(smem + off.adj);   // 16 x u8 neighbours per own row (0xFF = none)
+  const int32_t *ovf_ptr = smem + off.ovf_ptr, *ovf_loc = smem + off.ovf_loc;            // flags & ELL_FLAG_INC_OVF
+  int32_t *ovf_w = smem + off.ovf_w;
+  const int32_t *adj_ptr = smem + off.adj_ptr, *adj_loc = smem + off.adj_loc;            // flags & ELL_FLAG_LONG_ROWS
   // LDS-DMA of one 16-row block in fragment order: piece (t, i) of lane (r16, qd) = floats 32t + 16i + 4qd .. +3
   // of row r16 of the block.  The destination is wave-uniform (base + lane * 16 B is implicit).  Row offsets do not
-  // change from snapshot to snapshot, so a wave keeps those of its first two P1 blocks and first P2 block in registers.
+  // change from snapshot to snapshot, so a wave keeps those of its first two P1 blocks and first P2 block in registers;
+  // the snapshot only moves a scalar base (sec_next / prim_next: the rows of the NEXT snapshot to fetch).
   auto sec_row = [&](int blk) { return sec_ids[min(blk * 16 + r16, n_sec - 1)]; };      // row * width < 2^31 floats
   auto prim_row = [&](int blk) { return prim_ids[min(blk * 16 + r16, n_prim - 1)]; };
   const int srow0 = wave * 16 < n_sec ? sec_row(wave) : 0, srow1 = (wave + NW) * 16 < n_sec ? sec_row(wave + NW) : 0;
   const int prow0 = wave * 16 < n_prim ? prim_row(wave) : 0;
   const bool sec_split = FS == 96 && S_.sec_in2 != nullptr, prim_split = FP == 96 && S_.prim_in2 != nullptr;
-  auto dma_sec = [&](int blk, int s) {
+  const int64_t sec_stride = (int64_t)S_.n_sec_glob * (sec_split ? 64 : FS), sec_stride2 = (int64_t)S_.n_sec_glob * 32;       // floats per snapshot
+  const int64_t prim_stride = (int64_t)S_.n_prim_glob * (prim_split ? 64 : FP), prim_stride2 = (int64_t)S_.n_prim_glob * 32;
+  const float *sec_next = S_.sec_in + s_begin * sec_stride, *sec_next2 = sec_split ? S_.sec_in2 + s_begin * sec_stride2 : nullptr;
+  const float *prim_next = S_.prim_in + s_begin * prim_stride, *prim_next2 = prim_split ? S_.prim_in2 + s_begin * prim_stride2 : nullptr;
+  auto dma_sec = [&](int blk) {      // secondary block blk of the snapshot sec_next points at
     const unsigned row = (unsigned)(blk == wave ? srow0 : (blk == wave + NW ? srow1 : sec_row(blk)));
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(stage_s) + (unsigned)blk * (KT_S * 2 * 1024));
     if (sec_split) {      // 96 floats from two tensors: 64 (four pieces) + 32 (two pieces)
-      glds16_run_s<4>(S_.sec_in + (int64_t)s * S_.n_sec_glob * 64, row * 256u + 16u * qd, dst);
-      glds16_run_s<2>(S_.sec_in2 + (int64_t)s * S_.n_sec_glob * 32, row * 128u + 16u * qd, dst + 4096u);
+      glds16_run_s<4>(sec_next, row * 256u + 16u * qd, dst);
+      glds16_run_s<2>(sec_next2, row * 128u + 16u * qd, dst + 4096u);
     } else {              // piece (t, i) = floats 32t + 16i = 16 * (2t + i) of the row
-      glds16_run_s<2 * KT_S>(S_.sec_in + (int64_t)s * S_.n_sec_glob * FS, row * (unsigned)(FS * 4) + 16u * qd, dst);
+      glds16_run_s<2 * KT_S>(sec_next, row * (unsigned)(FS * 4) + 16u * qd, dst);
     }
   };
-  auto dma_prim = [&](int blk, int s) {
+  auto dma_prim = [&](int blk) {
     const unsigned row = (unsigned)(blk == wave ? prow0 : prim_row(blk));
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(stage_p) + (unsigned)blk * (KT_X * 2 * 1024));
     if (prim_split) {
-      glds16_run_s<4>(S_.prim_in + (int64_t)s * S_.n_prim_glob * 64, row * 256u + 16u * qd, dst);
-      glds16_run_s<2>(S_.prim_in2 + (int64_t)s * S_.n_prim_glob * 32, row * 128u + 16u * qd, dst + 4096u);
+      glds16_run_s<4>(prim_next, row * 256u + 16u * qd, dst);
+      glds16_run_s<2>(prim_next2, row * 128u + 16u * qd, dst + 4096u);
     } else {
-      glds16_run_s<2 * KT_X>(S_.prim_in + (int64_t)s * S_.n_prim_glob * FP, row * (unsigned)(FP * 4) + 16u * qd, dst);
+      glds16_run_s<2 * KT_X>(prim_next, row * (unsigned)(FP * 4) + 16u * qd, dst);
     }
   };
+  auto sec_advance = [&]() { sec_next += sec_stride; if (sec_split) sec_next2 += sec_stride2; };
+  auto prim_advance = [&]() { prim_next += prim_stride; if (prim_split) prim_next2 += prim_stride2; };
 
   // P3 (the planner keeps n_own <= 4*NW*U, so one trip covers the tile: row = wave*4 + 4*NW*u + rs): the (wave-
-  // uniform) largest degree of each of this wave's row groups never changes, keep it in SGPRs
+  // uniform) largest degree of each of this wave's row groups never changes, keep it in SGPRs.  Degrees come from the
+  // fixed-width lists (valid bytes of a row), for tiles with long rows from the full lists.
   int p3_dmax[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int i = wave * 4 + 4 * NW * u + rs;
     const int ic = min(i, n_own - 1);
-    int dmx = i < n_own ? adj_ptr[ic + 1] - adj_ptr[ic] : 0;
+    int dmx;
+    if (flags & ELL_FLAG_LONG_ROWS) {
+      dmx = i < n_own ? adj_ptr[ic + 1] - adj_ptr[ic] : 0;
+    } else {
+      const unsigned long long m = __ballot(i < n_own && adj_b[ic * ELL_ADJ + c16] != 0xFF);
+      dmx = __builtin_popcountll((m >> (16 * rs)) & 0xffffull);
+    }
     dmx = max(dmx, __shfl_xor(dmx, 16));
     dmx = max(dmx, __shfl_xor(dmx, 32));
     p3_dmax[u] = __builtin_amdgcn_readfirstlane(dmx);
   }
 
+  // Counted waits: vmcnt retires vector-memory operations in issue order (DMA pieces and output stores alike), so a
+  // phase waits for "all but the operations this wave issued after the batch it needs".  Two running counts (wave-
+  // uniform): operations issued since the last secondary-row batch / since the last primary-row batch.
+  const int np_sec = sec_split ? 6 : 2 * KT_S, np_prim = prim_split ? 6 : 2 * KT_X;      // DMA pieces per 16-row block
+  int vm_since_sec = 0, vm_since_prim = 0;
   if (s_begin < s_end) {
-    for (int blk = wave; blk * 16 < n_sec; blk += NW) dma_sec(blk, s_begin);
-    for (int blk = wave; blk * 16 < n_prim; blk += NW) dma_prim(blk, s_begin);
+    for (int blk = wave; blk * 16 < n_sec; blk += NW) dma_sec(blk);
+    for (int blk = wave; blk * 16 < n_prim; blk += NW) {
+      dma_prim(blk);
+      vm_since_sec += np_prim;
+    }
+    sec_advance();
+    prim_advance();
   }
   // everything below overlaps with the first snapshot's DMA
 #ifdef UDS_PHASE_TIMING
   const unsigned long long t_dma_issued_ = clock64();
 #endif
-  for (int i = tid; i < n_inc; i += NT) reinterpret_cast<float *>(inc_w)[i] = S_.ne_val[inc_w[i]];
-
-
+  for (int i = tid; i < ELL_INC * n_prim; i += NT) {      // NodeEdge values of the fixed-width lists (0 for padding)
+    const int k = inc_w[i];
+    reinterpret_cast<float *>(inc_w)[i] = k >= 0 ? S_.ne_val[k] : 0.f;
+  }
+  if (flags & ELL_FLAG_INC_OVF)
+    for (int i = tid; i < n_ovf; i += NT) reinterpret_cast<float *>(ovf_w)[i] = S_.ne_val[ovf_w[i]];
+  const float *ovf_val = reinterpret_cast<const float *>(ovf_w);
 #ifdef UDS_PHASE_TIMING
   const unsigned long long t_loads_issued_ = clock64();
 #endif
   __syncthreads();   // NodeEdge values, attention vectors and bias are in LDS
-  int n_st = 0;   // output-store instructions this wave issued in the previous P3 (still in flight, younger than the DMA)
   UDS_STAMP(0);   // setup: metadata, first DMA issue, weights
 
-  for (int s = s_begin; s < s_end; ++s) {
-    wait_all_but(n_st);    // this wave's stage slots for snapshot s have landed
+  // ---------------- P1: secondary MLP -> LDS ----------------
+  auto phase1 = [&](int s) {
+    if (wave * 16 < n_sec) wait_vm(vm_since_sec);      // this wave's secondary-row slots for snapshot s have landed
     UDS_STAMP(1);
-    // ---------------- P1: secondary MLP -> LDS ----------------
+    const bool more = s + 1 < s_end;
     for (int blk = wave; blk * 16 < n_sec; blk += NW) {
       const float4 *st = reinterpret_cast<const float4 *>(stage_s + blk * (KT_S * 2 * 256)) + lane;
       bf16x8 dh[KT_S], dl[KT_S];
 #pragma unroll
       for (int t = 0; t < KT_S; ++t) split8(st[(2 * t) * 64], st[(2 * t + 1) * 64], dh[t], dl[t]);
-      if (s + 1 < s_end) {   // slot consumed (values are in VGPRs): refill it with the next snapshot's rows
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        dma_sec(blk, s + 1);
-      }
       const int lrow = blk * 16 + r16;
       f32x4 acc[MB_S];
 #pragma unroll
@@ -514,6 +541,17 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
           else
             acc[m] = mfma3(wsh[t][m], wsl[t][m], dh[t], dl[t], acc[m]);
         }
+      // The slot is consumed (its values went through the split): refill it with the next snapshot's rows.  Issued BEHIND
+      // the MFMAs on purpose: a DMA piece holds the wave at issue for 100+ cycles under load, and here the matrix pipe
+      // works through the chain meanwhile (issued ahead of them, as at first, the pipe idled through the stall).
+      if (more) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dma_sec(blk);
+        vm_since_prim += np_sec;
+        vm_since_sec = 0;
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (lrow < n_sec) {
 #pragma unroll
         for (int m = 0; m < MB_S; ++m) {
@@ -524,38 +562,26 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
         }
       }
     }
-    // index lists do not depend on the data: fetch the head of this wave's first P2 incidence list now, so the
-    // reads are back by the time the barrier releases (loads on clamped indices, no branches)
-    const int lr0 = min(wave * 16 + r16, n_prim - 1);
-    const int ag_beg = inc_ptr[lr0], ag_end = inc_ptr[lr0 + 1];
-    const int ag_i0 = min(ag_beg, n_inc - 1), ag_i1 = min(ag_beg + 1, n_inc - 1);
-    const int ag_l0r = inc_loc[ag_i0], ag_l1r = inc_loc[ag_i1];
-    const float ag_w0r = inc_val[ag_i0], ag_w1r = inc_val[ag_i1];
+    if (more) sec_advance();
     UDS_STAMP(2);
-    lds_barrier();
-    UDS_STAMP(3);
-    const int ag_l0 = ag_beg < ag_end ? ag_l0r : 0, ag_l1 = ag_beg + 1 < ag_end ? ag_l1r : 0;
-    const float ag_w0 = ag_beg < ag_end ? ag_w0r : 0.f, ag_w1 = ag_beg + 1 < ag_end ? ag_w1r : 0.f;
-    // ---------------- P2: [prim | agg] @ Wbig -> hx, attention scalars -> LDS ----------------
-    int p3_deg[U], p3_jn[U], p3_row[U];   // P3 index lists (they do not depend on the data): fetched inside P2
+  };
+
+  unsigned p3_jb[U];      // P3: this lane's neighbour byte of each row group (static per tile; fetched at the end of P2)
+  // ---------------- P2: [prim | agg] @ Wbig -> hx, attention scalars -> LDS ----------------
+  auto phase2 = [&](int s, unsigned ag_locs, f32x4 ag_vals) {
+    if (wave * 16 < n_prim) wait_vm(vm_since_prim);     // this wave's primary-row slots for snapshot s have landed
+    const bool more = s + 1 < s_end;
     for (int blk = wave; blk * 16 < n_prim; blk += NW) {
       const float4 *st = reinterpret_cast<const float4 *>(stage_p + blk * (KT_X * 2 * 256)) + lane;
       bf16x8 dh[KT_B], dl[KT_B];
 #pragma unroll
       for (int t = 0; t < KT_X; ++t) split8(st[(2 * t) * 64], st[(2 * t + 1) * 64], dh[t], dl[t]);
       UDS_STAMP(8);    // P2a: stage read + split
-#ifndef UDS_LATE_PRIM_DMA
-      if (s + 1 < s_end) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        dma_prim(blk, s + 1);
-      }
-#endif
-      UDS_STAMP(9);    // P2b: DMA issue
       const int lrow = blk * 16 + r16;
       const bool valid = lrow < n_prim;
       const int lr = min(lrow, n_prim - 1);
       // the k-steps over the row's own features do not need the aggregate: issue their MFMAs first, the matrix pipe
-      // works on them while this wave gathers the incident secondary rows below
+      // works on them while this wave refills the stage slot and gathers the incident secondary rows below
       f32x4 acc[MB_B];
 #pragma unroll
       for (int m = 0; m < MB_B; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -569,38 +595,49 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
           else
             acc[m] = mfma3(wbh[t][m], wbl[t][m], dh[t], dl[t], acc[m]);
         }
+      // aggregation operands of this row: up to four (local secondary row, NodeEdge value) pairs at fixed width, read
+      // with two independent LDS reads (the wave's first block has them since before the barrier)
+      unsigned locs = ag_locs;
+      f32x4 vals = ag_vals;
+      if (blk != wave) {
+        locs = inc_loc[lr];
+        vals = inc_val4[lr];
+      }
+      if (more) {      // refill the consumed stage slot (behind the MFMAs: see P1)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dma_prim(blk);
+        vm_since_sec += np_prim;
+        vm_since_prim = 0;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      UDS_STAMP(9);    // P2b: x-part MFMA issue + DMA issue
       float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;   // this lane's 8 aggregate features (fragment shape)
-      auto add_row = [&](int loc, float wv) {
-        const float *row = sec + loc * SEC_STRIDE + 4 * qd;
-        const float4 u0 = *reinterpret_cast<const float4 *>(row);
-        const float4 u1 = *reinterpret_cast<const float4 *>(row + 16);
+      auto fma_row = [&](float wv, const float4 &u0, const float4 &u1) {
         g0.x = fmaf(wv, u0.x, g0.x); g0.y = fmaf(wv, u0.y, g0.y); g0.z = fmaf(wv, u0.z, g0.z); g0.w = fmaf(wv, u0.w, g0.w);
         g1.x = fmaf(wv, u1.x, g1.x); g1.y = fmaf(wv, u1.y, g1.y); g1.z = fmaf(wv, u1.z, g1.z); g1.w = fmaf(wv, u1.w, g1.w);
       };
-      if (blk == wave) {   // list head is in registers: both rows are fetched together (weight 0 / row 0 pad short lists)
-        add_row(ag_l0, ag_w0);
-        add_row(ag_l1, ag_w1);
-        for (int p = ag_beg + 2; p < ag_end; ++p) add_row(inc_loc[p], inc_val[p]);
-      } else {
-        for (int p = inc_ptr[lr]; p < inc_ptr[lr + 1]; ++p) add_row(inc_loc[p], inc_val[p]);
-      }
-      split8(g0, g1, dh[KT_X], dl[KT_X]);
-      UDS_STAMP(10);   // P2c: x-part MFMA issue + aggregation
-      // the index reads P3 needs are issued now, ahead of the last MFMAs, so they land in their shadow
-      if (blk == wave) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int i = wave * 4 + 4 * NW * u + rs;
-          const int ic = min(i, n_own - 1);
-          const int b0 = adj_ptr[ic];
-          p3_deg[u] = i < n_own ? adj_ptr[ic + 1] - b0 : 0;
-          p3_jn[u] = adj_loc[b0 + min(c16, max(p3_deg[u] - 1, 0))];
-          p3_row[u] = prim_ids[ic];
+      auto add2 = [&](unsigned la, float wa, unsigned lb, float wb) {      // two rows: four reads in flight, then the FMAs
+        const float *ra = sec + la * SEC_STRIDE + 4 * qd, *rb = sec + lb * SEC_STRIDE + 4 * qd;
+        const float4 a0 = *reinterpret_cast<const float4 *>(ra), a1 = *reinterpret_cast<const float4 *>(ra + 16);
+        const float4 b0 = *reinterpret_cast<const float4 *>(rb), b1 = *reinterpret_cast<const float4 *>(rb + 16);
+        fma_row(wa, a0, a1);
+        fma_row(wb, b0, b1);
+      };
+#ifndef UDS_ABL_NO_AGG
+      add2(locs & 0xffu, vals[0], (locs >> 8) & 0xffu, vals[1]);
+      if (inc_width > 2) add2((locs >> 16) & 0xffu, vals[2], locs >> 24, vals[3]);
+      if (flags & ELL_FLAG_INC_OVF)      // rows with more than four incident rows (a junction of five or more conduits)
+        for (int p = ovf_ptr[lr]; p < ovf_ptr[lr + 1]; ++p) {
+          const float *ra = sec + ovf_loc[p] * SEC_STRIDE + 4 * qd;
+          fma_row(ovf_val[p], *reinterpret_cast<const float4 *>(ra), *reinterpret_cast<const float4 *>(ra + 16));
         }
-      }
+#endif
+      split8(g0, g1, dh[KT_X], dl[KT_X]);
+      UDS_STAMP(10);   // P2c: aggregation
 #pragma unroll
       for (int m = 0; m < MB_B; ++m) acc[m] = mfma3(wbh[KT_X][m], wbl[KT_X][m], dh[KT_X], dl[KT_X], acc[m]);
-      UDS_STAMP(11);   // P2d: index prefetch + MFMA chain
+      UDS_STAMP(11);   // P2d: MFMA chain of the aggregate
       // <hx row, a_self>, <hx row, a_nbr>: even and odd columns in the two halves of packed FMAs (16 v_pk_fma_f32 instead of
       // 32 dependent v_fmac_f32), halves added, then the four lanes that share the row
       typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -626,48 +663,38 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
           *reinterpret_cast<f32x4 *>(hx + lrow * FUSED_D + (((4 * m + qd) ^ (lrow & 7)) << 2)) = acc[m];
       }
     }
-    if (!(wave * 16 < n_prim)) {   // waves without a P2 block fetch their P3 index lists here
+    if (more) prim_advance();
+    // P3's neighbour bytes: static, one independent read per row group, back before the barrier releases
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = wave * 4 + 4 * NW * u + rs;
-        const int ic = min(i, n_own - 1);
-        const int b0 = adj_ptr[ic];
-        p3_deg[u] = i < n_own ? adj_ptr[ic + 1] - b0 : 0;
-        p3_jn[u] = adj_loc[b0 + min(c16, max(p3_deg[u] - 1, 0))];
-        p3_row[u] = prim_ids[ic];
-      }
-    }
+    for (int u = 0; u < U; ++u) p3_jb[u] = adj_b[min(wave * 4 + 4 * NW * u + rs, n_own - 1) * ELL_ADJ + c16];
     UDS_STAMP(4);
-    lds_barrier();
-    UDS_STAMP(5);
-#ifdef UDS_LATE_PRIM_DMA
-    // the primary rows of the next snapshot are fetched from here: their stage slots were consumed before the barrier,
-    // and the eight waves no longer queue on the DMA path in the middle of P2
-    if (s + 1 < s_end)
-      for (int blk = wave; blk * 16 < n_prim; blk += NW) dma_prim(blk, s + 1);
-#endif
-    // ---------------- P3: segmented softmax + neighbour sum -> HBM ----------------
-    // 16 lanes per output row, U row groups (4*U rows) per wave in flight at once so the dependent LDS reads of
-    // one group hide behind the others.  Lane c scores neighbour c (one exp per neighbour, not per lane); the row
-    // max / sum are DPP all-reduces inside the 16-lane group; weights and neighbour indices are then broadcast
-    // lane by lane while every lane accumulates its own float4 feature chunk.
-    n_st = 0;
+  };
+
+  // ---------------- P3: segmented softmax + neighbour sum -> HBM ----------------
+  // 16 lanes per output row, U row groups (4*U rows) per wave in flight at once so the dependent LDS reads of
+  // one group hide behind the others.  Lane c scores neighbour c (one exp per neighbour, not per lane); the row
+  // max / sum are DPP all-reduces inside the 16-lane group; weights and neighbour indices are then broadcast
+  // lane by lane while every lane accumulates its own float4 feature chunk.
+  auto phase3 = [&](int s) {
+#ifndef UDS_ABL_NO_P3
+    int n_st = 0;      // output-store instructions of this phase
     // rows are degree-sorted inside the tile; 4-row groups are dealt round-robin to the waves (group g -> wave g % NW),
     // so every wave gets the same mix of degrees and its groups come in descending degree
     {   // the planner keeps n_own <= 4*NW*U (= p_limit 128), so one trip covers the tile: row = wave*4 + 4*NW*u + rs
-      constexpr int i0 = 0;
-      int deg[U], jn[U], dmax[U], orow[U];
+      int jn[U], dmax[U], orow[U];
       float ss[U], lg[U], wgt[U], den[U];
-      bool ok[U];
+      bool ok[U], has[U];
       int dm = 0;
 #pragma unroll
       for (int u = 0; u < U; ++u) {   // unconditional loads on clamped indices: the four groups' reads overlap
         const int i = wave * 4 + 4 * NW * u + rs;
         const int ic = min(i, n_own - 1);
         ok[u] = i < n_own;
-        deg[u] = p3_deg[u]; jn[u] = c16 < p3_deg[u] ? p3_jn[u] : 0; dmax[u] = p3_dmax[u];
+        has[u] = ok[u] && p3_jb[u] != 0xFFu;      // neighbour slot c16 of this row exists (slots fill from 0)
+        jn[u] = has[u] ? (int)p3_jb[u] : 0;
+        dmax[u] = p3_dmax[u];
         ss[u] = s_self[ic];
-        orow[u] = p3_row[u] * FUSED_D + 4 * c16;
+        orow[u] = prim_ids[ic] * FUSED_D + 4 * c16;
         dm = max(dm, dmax[u]);
       }
       f32x4 acc[U];
@@ -678,7 +705,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
         for (int u = 0; u < U; ++u) {
           const float sv = ss[u] + s_nbr[jn[u]];
           const float sc = fmaxf(sv, 0.2f * sv);      // leaky_relu(0.2): the larger of v and 0.2 v, for either sign (2 ops, not 3)
-          lg[u] = c16 < deg[u] ? sc : -INFINITY;
+          lg[u] = has[u] ? sc : -INFINITY;
         }
         int joff[U];      // byte offset of the neighbour's hx row with its swizzle key in bits 4-6: j*256 + (j&7)*16
         static_assert(U == 4, "the four-at-once reductions below");
@@ -687,10 +714,11 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const float ex = __builtin_amdgcn_exp2f(lg[u] - mx[u]);      // logits are in base-2 units (see the set-up)
-          wgt[u] = c16 < deg[u] ? ex : 0.f;     // rows past the tile have degree 0: every weight 0, the NaN of -inf - -inf dropped
+          wgt[u] = has[u] ? ex : 0.f;     // rows past the tile have no slots: every weight 0, the NaN of -inf - -inf dropped
           joff[u] = jn[u] * (FUSED_D * 4) + ((jn[u] & 7) << 4);
         }
         row16_sum4(wgt, den);
+#ifndef UDS_ABL_NO_P3_STEPS
         // Lane c of a 16-lane row group holds (weight, offset) of neighbour c.  Neighbour K reaches the row's other
         // lanes by a DPP row broadcast (v_mov_b32_dpp row_newbcast:K): no LDS round trip for the pairs.  The XOR with
         // the lane's own chunk offset (c16 << 4) applies the hx swizzle: bits 4-6 key ^ chunk, bits >= 8 the row.
@@ -737,15 +765,20 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
             more = e0 > K + P3_SLOTS;
           }
         });
-      } else {   // some row has more than 16 neighbours: every lane walks its row's whole list
+#else
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = f32x4{wgt[u], __int_as_float(joff[u]), wgt[u], wgt[u]};
+#endif
+      } else {   // some row has more than 16 neighbours: every lane walks its row's whole list (tiles with ELL_FLAG_LONG_ROWS)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int i = i0 + wave * 4 + 4 * NW * u + rs;
+          const int i = wave * 4 + 4 * NW * u + rs;
           const int b0 = i < n_own ? adj_ptr[i] : 0;
+          const int dg = i < n_own ? adj_ptr[i + 1] - b0 : 0;
           float mx = -INFINITY;
-          for (int p = b0; p < b0 + deg[u]; ++p) mx = fmaxf(mx, leaky02(ss[u] + s_nbr[adj_loc[p]]));
+          for (int p = b0; p < b0 + dg; ++p) mx = fmaxf(mx, leaky02(ss[u] + s_nbr[adj_loc[p]]));
           den[u] = 0.f;
-          for (int p = b0; p < b0 + deg[u]; ++p) {
+          for (int p = b0; p < b0 + dg; ++p) {
             const int jj = adj_loc[p];
             const float wv = __builtin_amdgcn_exp2f(leaky02(ss[u] + s_nbr[jj]) - mx);
             const f32x4 hv = *reinterpret_cast<const f32x4 *>(hx + jj * FUSED_D + ((c16 ^ (jj & 7)) << 2));
@@ -763,14 +796,45 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
           f32x4 o;
 #pragma unroll
           for (int q = 0; q < 4; ++q) o[q] = fused_act<ACT>(fmaf(acc[u][q], inv, bo[q]), a.act);
+#ifndef UDS_ABL_NO_STORE
           *reinterpret_cast<f32x4 *>(S_.out + ((int64_t)s * S_.n_prim_glob * FUSED_D + orow[u])) = o;
+#else
+          asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(orow[u]));
+#endif
         }
       }
     }
+#ifndef UDS_ABL_NO_STORE
+    vm_since_sec += n_st;
+    vm_since_prim += n_st;
+#endif
+#endif
     UDS_STAMP(6);
-    // no barrier needed here: the next snapshot's P1 only writes `sec`, whose readers (P2) all passed the barrier
-    // above; its P2 writes hx / s_* only after the next P1->P2 barrier, which every wave reaches after its own P3.
+  };
+
+#ifdef UDS_ABL_NO_BAR
+#define UDS_BAR() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define UDS_BAR() lds_barrier()
+#endif
+  if (s_begin < s_end) phase1(s_begin);
+  for (int s = s_begin; s < s_end; ++s) {
+    // index lists do not depend on the data: fetch the aggregation operands of this wave's first P2 block now, so the
+    // reads are back by the time the barrier releases (loads on clamped indices, no branches)
+    const int lr0 = min(wave * 16 + r16, n_prim - 1);
+    const unsigned ag_locs = inc_loc[lr0];
+    const f32x4 ag_vals = inc_val4[lr0];
+    UDS_BAR();      // every secondary row of snapshot s is in LDS
+    UDS_STAMP(3);
+    phase2(s, ag_locs, ag_vals);
+    UDS_BAR();      // hx and the attention scalars of snapshot s are in LDS; nobody reads `sec` any more
+    UDS_STAMP(5);
+    // P3 of this snapshot and P1 of the next touch disjoint LDS (hx / scores vs the stage and `sec`).  No barrier after
+    // them: the next P2 writes hx / scores only behind the next barrier, which every wave reaches after its own P3.
+    phase3(s);
+    if (s + 1 < s_end) phase1(s + 1);
   }
+#undef UDS_BAR
 #ifdef UDS_PHASE_TIMING
   if (a.dbg && lane == 0) {
     unsigned long long *o = a.dbg + ((size_t)blockIdx.x * NW + wave) * 16;
@@ -783,7 +847,6 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
            ((unsigned long long)n_sec << 48);
   }
 #endif
-  }   // pieces of the schedule
 }
 
 }  // namespace uds

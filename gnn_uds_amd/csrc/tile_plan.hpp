@@ -347,6 +347,146 @@ inline SidePlan build_side_plan(const HostCsr &adj, const HostCsr &inc, int t_ma
   return plan;
 }
 
+// ---- Tile blocks of k_fused_tile: fixed-width ("ELL") index lists -------------------------------------------------------
+// The kernel walks a tile's index lists once per snapshot.  In CSR form every list costs a chain of dependent LDS reads
+// (pointer -> entries -> rows); drainage networks have tiny degrees (a junction joins 2-4 conduits, a conduit has two
+// ends), so the block a workgroup fetches stores them at fixed width instead -- one independent read per row:
+//   hdr[8]              n_own, n_prim, n_sec, flags, n_ovf, n_adj (long-list tiles only), side, inc_width
+//   prim[n_prim]        global primary rows (own rows first)
+//   sec[n_sec]          global secondary rows
+//   inc_loc[n_prim]     4 x u8: local secondary rows of a primary row's first four incident rows (0 = padding)
+//   inc_w[4 n_prim]     their positions in the global NodeEdge value array, -1 = padding (the kernel puts the VALUES here)
+//   adj[4 n_own]        16 x u8: local primary rows of an own row's first sixteen neighbours, 0xFF = none
+//   flags & 1 (a primary row with more than four incident rows):    ovf_ptr[n_prim + 1], ovf_loc[n_ovf], ovf_w[n_ovf]
+//   flags & 2 (an own row with more than sixteen neighbours):       adj_ptr[n_own + 1], adj_loc[n_adj]  (the whole lists)
+// Every section starts on a multiple of four ints (16-byte LDS reads).  Local indices are bytes: tiles are limited to
+// 255 primary / 256 secondary rows (ell_fits).
+#ifdef __HIPCC__
+#define UDS_HD __host__ __device__
+#else
+#define UDS_HD
+#endif
+constexpr int ELL_INC = 4, ELL_ADJ = 16;
+constexpr int ELL_FLAG_INC_OVF = 1, ELL_FLAG_LONG_ROWS = 2;
+UDS_HD inline int a4(int x) { return (x + 3) & ~3; }
+
+struct EllOffsets {
+  int prim, sec, inc_loc, inc_w, adj, ovf_ptr, ovf_loc, ovf_w, adj_ptr, adj_loc, len;
+};
+UDS_HD inline EllOffsets ell_offsets(int n_own, int n_prim, int n_sec, int flags, int n_ovf, int n_adj) {
+  EllOffsets o{};
+  int p = TILE_HDR_INTS;
+  o.prim = p; p = a4(p + n_prim);
+  o.sec = p; p = a4(p + n_sec);
+  o.inc_loc = p; p = a4(p + n_prim);
+  o.inc_w = p; p += ELL_INC * n_prim;
+  o.adj = p; p += (ELL_ADJ / 4) * n_own;
+  if (flags & ELL_FLAG_INC_OVF) {
+    o.ovf_ptr = p; p = a4(p + n_prim + 1);
+    o.ovf_loc = p; p = a4(p + n_ovf);
+    o.ovf_w = p; p = a4(p + n_ovf);
+  }
+  if (flags & ELL_FLAG_LONG_ROWS) {
+    o.adj_ptr = p; p = a4(p + n_own + 1);
+    o.adj_loc = p; p = a4(p + n_adj);
+  }
+  o.len = p;
+  return o;
+}
+
+// views of one tile inside a plan's pool (the CSR form build_side_plan writes)
+struct TileView {
+  int n_own, n_prim, n_sec, n_inc, n_adj, side;
+  const int32_t *prim, *sec, *inc_ptr, *inc_loc, *inc_w, *adj_ptr, *adj_loc;
+};
+inline TileView tile_view(const int32_t *hd, const int32_t *pool) {
+  TileView v{hd[0], hd[1], hd[2], hd[3], hd[4], hd[6], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  v.prim = pool + hd[5];
+  v.sec = v.prim + v.n_prim;
+  v.inc_ptr = v.sec + v.n_sec;
+  v.inc_loc = v.inc_ptr + v.n_prim + 1;
+  v.inc_w = v.inc_loc + v.n_inc;
+  v.adj_ptr = v.inc_w + v.n_inc;
+  v.adj_loc = v.adj_ptr + v.n_own + 1;
+  return v;
+}
+inline void ell_shape(const TileView &v, int &flags, int &n_ovf, int &inc_width) {
+  flags = 0; n_ovf = 0; inc_width = 0;
+  for (int i = 0; i < v.n_prim; ++i) {
+    const int d = v.inc_ptr[i + 1] - v.inc_ptr[i];
+    inc_width = std::max(inc_width, std::min(d, ELL_INC));
+    if (d > ELL_INC) { flags |= ELL_FLAG_INC_OVF; n_ovf += d - ELL_INC; }
+  }
+  for (int i = 0; i < v.n_own; ++i)
+    if (v.adj_ptr[i + 1] - v.adj_ptr[i] > ELL_ADJ) flags |= ELL_FLAG_LONG_ROWS;
+}
+inline bool ell_fits(const int32_t *hd) { return hd[1] <= 255 && hd[2] <= 256; }
+inline int ell_block_len(const int32_t *hd, const int32_t *pool) {
+  const TileView v = tile_view(hd, pool);
+  int flags, n_ovf, w;
+  ell_shape(v, flags, n_ovf, w);
+  return ell_offsets(v.n_own, v.n_prim, v.n_sec, flags, n_ovf, v.n_adj).len;
+}
+// largest block of a tile list (ints, a multiple of 4); -1 if some tile does not fit the byte-wide local indices
+inline int ell_block_cap(const std::vector<int32_t> &hdr, const std::vector<int32_t> &pool, int n_tiles) {
+  int cap = 4;
+  for (int t = 0; t < n_tiles; ++t) {
+    const int32_t *hd = hdr.data() + (size_t)t * TILE_HDR_INTS;
+    if (!ell_fits(hd)) return -1;
+    cap = std::max(cap, ell_block_len(hd, pool.data()));
+  }
+  return cap;
+}
+// blocks of a tile list at a fixed stride (>= ell_block_cap), zero padded
+inline void build_ell_blocks(const std::vector<int32_t> &hdr, const std::vector<int32_t> &pool, int n_tiles, int stride,
+                             std::vector<int32_t> &out) {
+  out.assign(std::max<size_t>((size_t)stride * n_tiles, 4), 0);
+  for (int t = 0; t < n_tiles; ++t) {
+    const int32_t *hd = hdr.data() + (size_t)t * TILE_HDR_INTS;
+    const TileView v = tile_view(hd, pool.data());
+    int flags, n_ovf, w;
+    ell_shape(v, flags, n_ovf, w);
+    const EllOffsets o = ell_offsets(v.n_own, v.n_prim, v.n_sec, flags, n_ovf, v.n_adj);
+    int32_t *b = out.data() + (size_t)stride * t;
+    const int32_t h[TILE_HDR_INTS] = {v.n_own, v.n_prim, v.n_sec, flags, n_ovf, (flags & ELL_FLAG_LONG_ROWS) ? v.n_adj : 0, v.side, w};
+    std::copy(h, h + TILE_HDR_INTS, b);
+    std::copy(v.prim, v.prim + v.n_prim, b + o.prim);
+    std::copy(v.sec, v.sec + v.n_sec, b + o.sec);
+    int q = 0;
+    if (flags & ELL_FLAG_INC_OVF) b[o.ovf_ptr] = 0;
+    for (int i = 0; i < v.n_prim; ++i) {
+      uint32_t locs = 0;
+      for (int k = 0; k < ELL_INC; ++k) {
+        const int p = v.inc_ptr[i] + k;
+        const bool has = p < v.inc_ptr[i + 1];
+        if (has) locs |= (uint32_t)v.inc_loc[p] << (8 * k);
+        b[o.inc_w + ELL_INC * i + k] = has ? v.inc_w[p] : -1;
+      }
+      b[o.inc_loc + i] = (int32_t)locs;
+      if (flags & ELL_FLAG_INC_OVF) {
+        for (int p = v.inc_ptr[i] + ELL_INC; p < v.inc_ptr[i + 1]; ++p, ++q) {
+          b[o.ovf_loc + q] = v.inc_loc[p];
+          b[o.ovf_w + q] = v.inc_w[p];
+        }
+        b[o.ovf_ptr + i + 1] = q;
+      }
+    }
+    for (int i = 0; i < v.n_own; ++i)
+      for (int c = 0; c < ELL_ADJ / 4; ++c) {
+        uint32_t word = 0;
+        for (int k = 0; k < 4; ++k) {
+          const int p = v.adj_ptr[i] + 4 * c + k;
+          word |= (uint32_t)(p < v.adj_ptr[i + 1] ? v.adj_loc[p] : 0xFF) << (8 * k);
+        }
+        b[o.adj + (ELL_ADJ / 4) * i + c] = (int32_t)word;
+      }
+    if (flags & ELL_FLAG_LONG_ROWS) {
+      std::copy(v.adj_ptr, v.adj_ptr + v.n_own + 1, b + o.adj_ptr);
+      std::copy(v.adj_loc, v.adj_loc + v.n_adj, b + o.adj_loc);
+    }
+  }
+}
+
 // LDS bytes the fused kernel needs for a plan: meta + s_self/s_nbr + attention vectors + sec rows (h+4 stride) +
 // hx rows + the DMA stage (raw secondary rows of width fs and raw primary rows of width fp of the NEXT snapshot,
 // at least as large as the packed weights that pass through it once at workgroup start).
@@ -359,59 +499,6 @@ inline int64_t fused_lds_bytes(int p_cap, int q_cap, int meta_cap, int h, int d,
   const int64_t cold = (fp > 64 ? (d / 16) * 2 * 1024 : 0) + (fs > 64 ? (h / 16) * 2 * 1024 : 0);   // LDS-resident third k-step
 #endif
   return 4 * ((int64_t)meta_cap + 2 * p_cap + 2 * d + h + (int64_t)q_cap * (h + 4) + (int64_t)p_cap * d) + cold + stage;
-}
-
-// Balanced static schedule of a fused launch.  Snapshots are independent and a tile costs the same for every snapshot,
-// so the work of a launch is the sequence tile 0 x S snapshots, tile 1 x S snapshots, ... with a per-snapshot cost per
-// tile; it is cut into SCHED_WGS ranges of equal cost, one per workgroup (one workgroup per CU, every CU busy for the
-// same time, metadata / weights set up once per range piece instead of once per (tile, chunk)).  A range is stored as
-// up to SCHED_MAX_SEG pieces (tile, from, to) with from / to as fractions of S in 1/65536 -- independent of S, so the
-// schedule is built once per plan.  Record of workgroup w: sched[w * SCHED_INTS] = n_seg, then n_seg x (tile, from, to).
-constexpr int SCHED_WGS = 256, SCHED_MAX_SEG = 24, SCHED_INTS = 1 + 3 * SCHED_MAX_SEG + 3;
-
-// per-snapshot cost of a tile in arbitrary units, from the phase shares measured on full tiles (tools/phase_timing.py):
-// fixed part (barriers, loop) 14, secondary MLP 0.85 per 16-row block, primary GEMM 4 per block, aggregation 29 / 128 rows
-inline double tile_cost(const int32_t *hd) {
-  return 14.0 + 0.85 * ((hd[2] + 15) / 16) + 4.0 * ((hd[1] + 15) / 16) + 29.0 * hd[0] / 128.0;
-}
-
-// false: some workgroup would need more than SCHED_MAX_SEG pieces (many small tiles) -> the (tile, chunk) grid is used
-inline bool build_schedule(const std::vector<int32_t> &hdr, int n_tiles, std::vector<int32_t> &out) {
-  out.assign((size_t)SCHED_WGS * SCHED_INTS, 0);
-  if (n_tiles <= 0) return false;
-  std::vector<double> start(n_tiles + 1, 0.0);
-  for (int t = 0; t < n_tiles; ++t) start[t + 1] = start[t] + tile_cost(hdr.data() + (size_t)t * TILE_HDR_INTS);
-  const double total = start[n_tiles];
-  auto frac = [&](int t, double c) {      // position c inside tile t as a fraction of its snapshots, 0 .. 65536
-    const double f = (c - start[t]) / (start[t + 1] - start[t]);
-    return (int32_t)std::lround(65536.0 * std::min(1.0, std::max(0.0, f)));
-  };
-  int t = 0;
-  int32_t from = 0;                       // where the previous range stopped inside tile t
-  for (int w = 0; w < SCHED_WGS; ++w) {
-    const double hi = w + 1 == SCHED_WGS ? total : total * (w + 1) / SCHED_WGS;
-    int32_t *rec = out.data() + (size_t)w * SCHED_INTS;
-    int n = 0;
-    while (t < n_tiles) {
-      const bool whole = w + 1 == SCHED_WGS || start[t + 1] <= hi;
-      const int32_t to = whole ? 65536 : frac(t, hi);
-      if (to > from) {
-        if (n == SCHED_MAX_SEG) return false;
-        rec[1 + 3 * n] = t;
-        rec[2 + 3 * n] = from;
-        rec[3 + 3 * n] = to;
-        ++n;
-      }
-      if (!whole) {
-        from = to;
-        break;
-      }
-      ++t;
-      from = 0;
-    }
-    rec[0] = n;
-  }
-  return true;
 }
 
 // Both sides of a network merged into one tile list ordered by locality key, so that the node tile and

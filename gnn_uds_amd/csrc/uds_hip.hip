@@ -74,10 +74,10 @@ struct uds_plan_slot {
   uds::NetworkPlan plan;
   int32_t *d_hdr = nullptr, *d_pool = nullptr;
   int32_t *d_hdr_side[2] = {nullptr, nullptr};   // headers of one side's tiles only (same pool): single-side launches
-  int32_t *d_sched = nullptr, *d_sched_side[2] = {nullptr, nullptr};   // balanced schedules of the three tile lists (nullptr: none)
   // k_fused_tile: header + metadata of every tile as one fixed-stride block (tile_block_ints(meta_cap) ints), so a workgroup
   // fetches both in ONE round trip without knowing the header first; one array per tile list
   int32_t *d_blocks = nullptr, *d_blocks_side[2] = {nullptr, nullptr};
+  int blk_cap = 0;                // ints per tile block of k_fused_tile (tile_plan.hpp: ell_block_cap)
   int64_t lds_bytes = 0;
 };
 
@@ -100,7 +100,7 @@ inline int slot_index(int fp, int fs) {
 // DMA stage) under the LDS budget: fix the footprint limits (primary / secondary rows staged per tile, multiples of 16)
 // first; the planner then fills them (tile_plan.hpp: merge_clusters).
 bool plan_network(const uds::HostCsr &adj, const uds::HostCsr &eadj, const uds::HostCsr &inc_n, const uds::HostCsr &inc_e,
-                  int fp, int fs, uds::NetworkPlan &out, int64_t &lds) {
+                  int fp, int fs, uds::NetworkPlan &out, int64_t &lds, int &blk_cap) {
   // candidate (p_limit, q_limit) pairs, largest first; meta is bounded by the limits (checked after planning)
   const int cand[][2] = {{128, 208}, {128, 192}, {128, 176}, {128, 160}, {128, 144}, {112, 160}, {112, 144}, {96, 144}, {96, 128},
                          {80, 128}, {64, 96}, {48, 64}, {32, 48}, {16, 32}};
@@ -109,7 +109,9 @@ bool plan_network(const uds::HostCsr &adj, const uds::HostCsr &eadj, const uds::
     if (uds::fused_lds_bytes(p_lim, q_lim, 0, uds::FUSED_H, uds::FUSED_D, fp, fs) > FUSED_LDS_BUDGET) continue;
     const int t = std::min(p_lim, 4 * uds::FUSED_WAVES * uds::FUSED_U);        // own rows: P3 covers a tile in one trip
     out = uds::build_network_plan(adj, eadj, inc_n, inc_e, t, t, p_lim, q_lim);
-    lds = uds::fused_lds_bytes(out.p_cap, out.q_cap, uds::tile_block_ints(out.meta_cap), uds::FUSED_H, uds::FUSED_D, fp, fs);
+    blk_cap = uds::ell_block_cap(out.hdr, out.pool, out.n_tiles);      // the kernel's tile blocks: fixed-width index lists
+    if (blk_cap < 0) continue;                                           // a tile beyond the byte-wide local indices (a hub row)
+    lds = uds::fused_lds_bytes(out.p_cap, out.q_cap, blk_cap, uds::FUSED_H, uds::FUSED_D, fp, fs);
     if (lds <= FUSED_LDS_BUDGET && out.p_cap <= 4 * uds::FUSED_WAVES * uds::FUSED_U) return true;   // P3 covers a tile in one trip
   }
   return false;
@@ -596,7 +598,7 @@ static int build_slot(uds_network *n, int fp, int fs) {
   sl.fp = fp;
   sl.fs = fs;
   if ((fp == 128 || fs == 128) ? !plan_network128(n->adj->host, n->edge_adj->host, n->inc_n->host, n->inc_e->host, fp, fs, sl.plan, sl.lds_bytes)
-                : !plan_network(n->adj->host, n->edge_adj->host, n->inc_n->host, n->inc_e->host, fp, fs, sl.plan, sl.lds_bytes))
+                : !plan_network(n->adj->host, n->edge_adj->host, n->inc_n->host, n->inc_e->host, fp, fs, sl.plan, sl.lds_bytes, sl.blk_cap))
     return UDS_OK;
   hipError_t e;
   if ((e = hipMalloc(&sl.d_hdr, sizeof(int32_t) * sl.plan.hdr.size())) != hipSuccess ||
@@ -604,25 +606,10 @@ static int build_slot(uds_network *n, int fp, int fs) {
       (e = hipMemcpy(sl.d_hdr, sl.plan.hdr.data(), sizeof(int32_t) * sl.plan.hdr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
       (e = hipMemcpy(sl.d_pool, sl.plan.pool.data(), sizeof(int32_t) * sl.plan.pool.size(), hipMemcpyHostToDevice)) != hipSuccess)
     return fail(UDS_ENOMEM, "tile plan upload -> %s", hipGetErrorString(e));
-  // balanced static schedule of a tile list (k_fused_tile only), uploaded next to it
-  auto upload_schedule = [&](const std::vector<int32_t> &hdr, int n_tiles, int32_t **dst) -> hipError_t {
-    std::vector<int32_t> sc;
-    if (fp == 128 || fs == 128 || !uds::build_schedule(hdr, n_tiles, sc)) return hipSuccess;
-    hipError_t e2 = hipMalloc(dst, sizeof(int32_t) * sc.size());
-    if (e2 != hipSuccess) return e2;
-    return hipMemcpy(*dst, sc.data(), sizeof(int32_t) * sc.size(), hipMemcpyHostToDevice);
-  };
-  if ((e = upload_schedule(sl.plan.hdr, sl.plan.n_tiles, &sl.d_sched)) != hipSuccess)
-    return fail(UDS_ENOMEM, "schedule upload -> %s", hipGetErrorString(e));
   auto upload_blocks = [&](const std::vector<int32_t> &hdr, int n_tiles, int32_t **dst) -> hipError_t {
     if (fp == 128 || fs == 128) return hipSuccess;
-    const size_t stride = (size_t)uds::tile_block_ints(sl.plan.meta_cap);
-    std::vector<int32_t> bl(std::max<size_t>(stride * n_tiles, 4), 0);
-    for (int t = 0; t < n_tiles; ++t) {
-      const int32_t *hd = hdr.data() + (size_t)t * uds::TILE_HDR_INTS;
-      std::copy(hd, hd + uds::TILE_HDR_INTS, bl.begin() + stride * t);
-      std::copy(sl.plan.pool.begin() + hd[5], sl.plan.pool.begin() + hd[5] + hd[7], bl.begin() + stride * t + uds::TILE_HDR_INTS);
-    }
+    std::vector<int32_t> bl;
+    uds::build_ell_blocks(hdr, sl.plan.pool, n_tiles, sl.blk_cap, bl);
     hipError_t e2 = hipMalloc(dst, sizeof(int32_t) * bl.size());
     if (e2 != hipSuccess) return e2;
     return hipMemcpy(*dst, bl.data(), sizeof(int32_t) * bl.size(), hipMemcpyHostToDevice);
@@ -637,8 +624,6 @@ static int build_slot(uds_network *n, int fp, int fs) {
     if ((e = hipMalloc(&sl.d_hdr_side[side], sizeof(int32_t) * std::max<size_t>(hs.size(), 1))) != hipSuccess ||
         (!hs.empty() && (e = hipMemcpy(sl.d_hdr_side[side], hs.data(), sizeof(int32_t) * hs.size(), hipMemcpyHostToDevice)) != hipSuccess))
       return fail(UDS_ENOMEM, "tile plan upload -> %s", hipGetErrorString(e));
-    if ((e = upload_schedule(hs, (int)(hs.size() / uds::TILE_HDR_INTS), &sl.d_sched_side[side])) != hipSuccess)
-      return fail(UDS_ENOMEM, "schedule upload -> %s", hipGetErrorString(e));
     if ((e = upload_blocks(hs, (int)(hs.size() / uds::TILE_HDR_INTS), &sl.d_blocks_side[side])) != hipSuccess)
       return fail(UDS_ENOMEM, "tile block upload -> %s", hipGetErrorString(e));
   }
@@ -713,9 +698,6 @@ int uds_network_destroy(uds_network_t *net) {
     hipFree(sl.d_pool);
     hipFree(sl.d_hdr_side[0]);
     hipFree(sl.d_hdr_side[1]);
-    hipFree(sl.d_sched);
-    hipFree(sl.d_sched_side[0]);
-    hipFree(sl.d_sched_side[1]);
     hipFree(sl.d_blocks);
     hipFree(sl.d_blocks_side[0]);
     hipFree(sl.d_blocks_side[1]);
@@ -733,7 +715,7 @@ int uds_network_plan_info(const uds_network_t *net, int32_t *info8) {
   info8[2] = sl.plan.side[1].n_tiles;
   info8[3] = sl.plan.p_cap;
   info8[4] = sl.plan.q_cap;
-  info8[5] = sl.plan.meta_cap;
+  info8[5] = sl.blk_cap ? sl.blk_cap : sl.plan.meta_cap;
   info8[6] = (int32_t)sl.lds_bytes;
   info8[7] = sl.plan.t_max[0] * 1000 + sl.plan.t_max[1];
   return UDS_OK;
@@ -789,18 +771,15 @@ int uds_tile_plan_copy(const uds_tile_plan_t *tp, int32_t *hdr_out, int32_t *poo
   return UDS_OK;
 }
 
-int uds_tile_plan_schedule(const uds_tile_plan_t *tp, int32_t *sched_out, int32_t *dims3) {
-  UDS_REQUIRE(tp != nullptr, "uds_tile_plan_schedule: NULL plan");
-  if (dims3) {
-    dims3[0] = uds::SCHED_WGS;
-    dims3[1] = uds::SCHED_INTS;
-    dims3[2] = uds::SCHED_MAX_SEG;
-  }
-  if (!sched_out) return UDS_OK;
-  std::vector<int32_t> sc;
-  UDS_REQUIRE(uds::build_schedule(tp->plan.hdr, tp->plan.n_tiles, sc), "uds_tile_plan_schedule: a workgroup would need more than %d pieces",
-              uds::SCHED_MAX_SEG);
-  std::memcpy(sched_out, sc.data(), sizeof(int32_t) * sc.size());
+int uds_tile_plan_blocks(const uds_tile_plan_t *tp, int32_t *blocks_out, int64_t *stride_out) {
+  UDS_REQUIRE(tp != nullptr, "uds_tile_plan_blocks: NULL plan");
+  const int cap = uds::ell_block_cap(tp->plan.hdr, tp->plan.pool, tp->plan.n_tiles);
+  UDS_REQUIRE(cap >= 0, "uds_tile_plan_blocks: a tile has more than 255 primary / 256 secondary rows (byte-wide local indices)");
+  if (stride_out) *stride_out = cap;
+  if (!blocks_out) return UDS_OK;
+  std::vector<int32_t> bl;
+  uds::build_ell_blocks(tp->plan.hdr, tp->plan.pool, tp->plan.n_tiles, cap, bl);
+  std::memcpy(blocks_out, bl.data(), sizeof(int32_t) * (size_t)cap * tp->plan.n_tiles);
   return UDS_OK;
 }
 
@@ -881,7 +860,6 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
       UDS_REQUIRE(aligned16(wq), "uds_spatial_layer_forward: packed weights must be 16-byte aligned");
     }
     uds::FusedArgs a;
-    a.sched = nullptr;
     a.blocks = nullptr;
     a.side[0] = uds::FusedSide{x, e, nullptr, nullptr, out_x, wq, wq + 2048, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
     a.side[1] = uds::FusedSide{e, x, nullptr, nullptr, out_e, wq + 8192, wq + 10240, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};
@@ -934,7 +912,6 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
       wq = reinterpret_cast<const uint4 *>(ws);
     }
     uds::FusedArgs a;
-    a.sched = nullptr;
     a.blocks = nullptr;
     a.side[0] = uds::FusedSide{x, e, nullptr, nullptr, out_x, wq, wq + 768, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
     a.side[1] = uds::FusedSide{e, x, nullptr, nullptr, out_e, wq + 768 + 2048, wq + 2 * 768 + 2048, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val,
@@ -990,27 +967,19 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
     }
     const uint4 *w_small_n = wq, *w_big_n = wq + 768, *w_small_e = wq + 768 + 2048, *w_big_e = wq + 2 * 768 + 2048;
     uds::FusedArgs a;
-    a.sched = nullptr;
     a.blocks = nullptr;
     a.side[0] = uds::FusedSide{x, e, xb, eb, out_x, w_small_n, w_big_n, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
     a.side[1] = uds::FusedSide{e, x, eb, xb, out_e, w_small_e, w_big_e, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};
     int64_t lds_need = 0;
-    // The balanced static schedule is an experiment knob (UDS_SCHED=1), off by default: measured 314 us per launch against 281
-    // for the (tile, chunk) grid on the headline.  Tiles cost 8.4k cycles per snapshot +-4 % whatever their size, but ~4 % of
-    // the workgroups run 25 % slower for no structural reason (tools/tile_cost_fit.py), and a static range that lands on one
-    // of them sets the launch time; the hardware's dynamic dispatch of ~4 short workgroups per CU absorbs them.
-    static const bool no_sched = std::getenv("UDS_SCHED") == nullptr;
     auto use_plan = [&](const uds_plan_slot &u, int side) {     // side < 0: both sides (merged tile list), else that side's tiles only
       a.hdr = side < 0 ? u.d_hdr : u.d_hdr_side[side];
       a.pool = u.d_pool;
       a.n_tiles = side < 0 ? u.plan.n_tiles : u.plan.side[side].n_tiles;
       a.p_cap = u.plan.p_cap;
       a.q_cap = u.plan.q_cap;
-      a.meta_cap = uds::tile_block_ints(u.plan.meta_cap);      // LDS ints of the tile block (header + metadata)
+      a.meta_cap = u.blk_cap;      // LDS ints of the tile block (header + fixed-width index lists)
       a.blocks = side < 0 ? u.d_blocks : u.d_blocks_side[side];
       lds_need = u.lds_bytes;
-      // the balanced schedule pays when every workgroup gets several tile-snapshots; tiny launches keep one piece each
-      a.sched = (!no_sched && (int64_t)a.n_tiles * S >= 4 * uds::SCHED_WGS) ? (side < 0 ? u.d_sched : u.d_sched_side[side]) : nullptr;
     };
     use_plan(sl, -1);
     a.S = (int)S;
@@ -1036,7 +1005,6 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
       }
       if (const char *ov = std::getenv("UDS_CHUNK")) chunk = std::max<int64_t>(1, std::min<int64_t>(S, std::atoll(ov)));   // experiment knob
       a.chunk = (int)chunk;
-      if (a.sched) return uds::SCHED_WGS;
       return (int)(((S + chunk - 1) / chunk) * a.n_tiles);
     };
     if (fx == fe) {

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 6
+#define UDS_ABI_VERSION 7
 
 enum {
   UDS_OK = 0,
@@ -222,13 +222,11 @@ int uds_tile_plan_create(const int32_t *adj_rowptr, const int32_t *adj_col, cons
 int uds_tile_plan_destroy(uds_tile_plan_t *plan);
 int uds_tile_plan_sizes(const uds_tile_plan_t *plan, int64_t *n_tiles, int64_t *pool_len, int32_t *caps3);
 int uds_tile_plan_copy(const uds_tile_plan_t *plan, int32_t *hdr_out, int32_t *pool_out);
-/* Balanced static schedule of one fused launch over the plan's merged tile list (host-only, integer bookkeeping): the
- * sequence tile 0 x S snapshots, tile 1 x S snapshots, ... is cut into dims3[0] workgroup ranges of equal estimated
- * cost; record w = sched_out[w * dims3[1] ..]: n_pieces, then n_pieces x (tile, from, to) with from / to fractions of S
- * in 1/65536 (snapshot range [round(S from / 65536), round(S to / 65536))).  dims3 = {workgroups, ints per record, max
- * pieces}; pass sched_out = NULL to query dims3 only.  Returns UDS_EINVAL when a workgroup would need more than the
- * maximum number of pieces (the launch then uses the (tile, chunk) grid). */
-int uds_tile_plan_schedule(const uds_tile_plan_t *plan, int32_t *sched_out, int32_t *dims3);
+/* The tile blocks the fused d = 64 kernel fetches (host-only, integer bookkeeping): one block per tile of the merged
+ * list at a fixed stride of *stride_out ints, [8-int header | fixed-width index lists] (layout:
+ * gnn_uds_amd/csrc/tile_plan.hpp, "Tile blocks of k_fused_tile").  Pass blocks_out = NULL to query the stride.  Returns
+ * UDS_EINVAL when a tile exceeds the byte-wide local indices (255 primary / 256 secondary rows). */
+int uds_tile_plan_blocks(const uds_tile_plan_t *plan, int32_t *blocks_out, int64_t *stride_out);
 
 typedef struct uds_spatial_params {
   const float *xe_k, *xe_b; /* Dense(h) on e -> x_e : (fe, h), (h)            emulator.py:225 */

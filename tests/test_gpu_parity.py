@@ -392,31 +392,3 @@ def test_cpu_tensors_are_refused(dev):
     layer = U.Dense(4, 'relu', in_features=4)
     with pytest.raises(_lib.UdsError):
         layer(torch.zeros(2, 4))
-
-
-@pytest.mark.gpu
-def test_balanced_schedule_knob_gives_identical_results(dev, tmp_path):
-    """UDS_SCHED=1 (experiment knob: static balanced ranges instead of the (tile, chunk) grid) must not change a bit: the
-    same tiles run the same code, only the workgroup -> (tile, snapshots) assignment differs.  The knob is read once per
-    process, so the second run is a child process."""
-    import subprocess, sys, os
-    script = (
-        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
-        "import gnn_uds_amd as U\n"
-        "g = U.DrainageGraph.from_edges(U.synthetic_drainage_network(10000, 12000, 0))\n"
-        "layer = U.SpatialLayer(g, 64, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1)).to('cuda:0')\n"
-        "gen = torch.Generator().manual_seed(5)\n"
-        "x, e = torch.rand(7, 10000, 64, generator=gen).to('cuda:0'), torch.rand(7, 12000, 64, generator=gen).to('cuda:0')\n"
-        "ox, oe = layer(x, e)\n"
-        "np.save(sys.argv[1], np.concatenate([ox.cpu().numpy().ravel(), oe.cpu().numpy().ravel()]))\n"
-    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for knob in ('0', '1'):
-        env = dict(os.environ)
-        env.pop('UDS_SCHED', None)
-        if knob == '1':
-            env['UDS_SCHED'] = '1'
-        path = str(tmp_path / ('out%s.npy' % knob))
-        subprocess.run([sys.executable, '-c', script, path], check=True, env=env, timeout=300)
-        outs.append(np.load(path))
-    assert np.array_equal(outs[0], outs[1])

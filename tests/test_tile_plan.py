@@ -93,25 +93,74 @@ def test_headline_plan_fits_the_cu_lds():
     assert np.array_equal(a, hdr) and np.array_equal(b, pool)   # deterministic
 
 
-def test_balanced_schedule_covers_every_tile_snapshot_once():
-    """uds_tile_plan_schedule: for any S every (tile, snapshot) belongs to exactly one workgroup piece, pieces are in tile
-    order, and the estimated cost per workgroup is level (within one tile-snapshot of the mean)."""
+def a4(x):
+    return (x + 3) & ~3
+
+
+def check_blocks(hdr, pool, blocks):
+    """The tile blocks of k_fused_tile (fixed-width index lists) hold exactly the plan's CSR lists."""
+    for t in range(len(hdr)):
+        d = decode(hdr, pool, t)
+        b = blocks[t]
+        n_own, n_prim, n_sec, flags, n_ovf, n_adj, side, width = (int(v) for v in b[:8])
+        assert (n_own, n_prim, n_sec, side) == (d['n_own'], len(d['prim']), len(d['sec']), d['side'])
+        p = 8
+        assert np.array_equal(b[p:p + n_prim], d['prim']); p = a4(p + n_prim)
+        assert np.array_equal(b[p:p + n_sec], d['sec']); p = a4(p + n_sec)
+        locs = b[p:p + n_prim].view(np.uint32); p = a4(p + n_prim)
+        w = b[p:p + 4 * n_prim].reshape(n_prim, 4); p += 4 * n_prim
+        adj = b[p:p + 4 * n_own].view(np.uint8).reshape(n_own, 16); p += 4 * n_own
+        inc_deg = np.diff(d['inc_ptr'])
+        adj_deg = np.diff(d['adj_ptr'])
+        assert width == min(4, inc_deg.max(initial=0))
+        assert bool(flags & 1) == bool((inc_deg > 4).any()) and bool(flags & 2) == bool((adj_deg > 16).any())
+        assert n_ovf == int(np.maximum(inc_deg - 4, 0).sum())
+        if flags & 1:
+            ovf_ptr = b[p:p + n_prim + 1]; p = a4(p + n_prim + 1)
+            ovf_loc = b[p:p + n_ovf]; p = a4(p + n_ovf)
+            ovf_w = b[p:p + n_ovf]; p = a4(p + n_ovf)
+        for i in range(n_prim):
+            lo, hi = d['inc_ptr'][i], d['inc_ptr'][i + 1]
+            k = min(4, hi - lo)
+            got = [(int(locs[i]) >> (8 * j)) & 0xff for j in range(4)]
+            assert got[:k] == d['inc_loc'][lo:lo + k].tolist() and got[k:] == [0] * (4 - k)
+            assert w[i, :k].tolist() == d['inc_w'][lo:lo + k].tolist() and (w[i, k:] == -1).all()
+            if flags & 1:
+                assert np.array_equal(ovf_loc[ovf_ptr[i]:ovf_ptr[i + 1]], d['inc_loc'][lo + k:hi])
+                assert np.array_equal(ovf_w[ovf_ptr[i]:ovf_ptr[i + 1]], d['inc_w'][lo + k:hi])
+        for i in range(n_own):
+            lo, hi = d['adj_ptr'][i], d['adj_ptr'][i + 1]
+            k = min(16, hi - lo)
+            assert adj[i, :k].tolist() == d['adj_loc'][lo:lo + k].tolist() and (adj[i, k:] == 0xFF).all()
+        if flags & 2:
+            assert n_adj == len(d['adj_loc'])
+            assert np.array_equal(b[p:p + n_own + 1], d['adj_ptr']); p = a4(p + n_own + 1)
+            assert np.array_equal(b[p:p + n_adj], d['adj_loc']); p = a4(p + n_adj)
+        assert p <= blocks.shape[1] and not b[p:].any()
+
+
+@pytest.mark.parametrize('name', ['astlingen', 'shunqing', 'chaohu', 'hague', 'RedChicoSur'])
+def test_tile_blocks_on_real_networks(networks, name):
+    net = networks[name]
+    g = U.DrainageGraph.from_edges(np.array(net['edges']), net['n_node'])
+    for t, p_lim, q_lim in ((128, 128, 208), (16, 32, 48)):
+        hdr, pool, caps = _lib.tile_plan(g, t, t, p_lim, q_lim, blocks=True)
+        check_blocks(hdr, pool, caps['blocks'])
+
+
+def test_tile_blocks_headline_and_hub():
     g = U.DrainageGraph.from_edges(U.synthetic_drainage_network(10000, 12000, 0))
-    hdr, pool, caps = _lib.tile_plan(g, 128, 128, 128, 208, schedule=True)
-    sched = caps['schedule']
-    assert sched is not None and sched.shape[0] == 256
-    cost = 14.0 + 0.85 * ((hdr[:, 2] + 15) // 16) + 4.0 * ((hdr[:, 1] + 15) // 16) + 29.0 * hdr[:, 0] / 128.0
-    for S in (1, 6, 60, 61, 257):
-        seen = np.zeros((hdr.shape[0], S), dtype=np.int32)
-        load = np.zeros(sched.shape[0])
-        for w, rec in enumerate(sched):
-            last = -1
-            for k in range(rec[0]):
-                t, a, b = rec[1 + 3 * k: 4 + 3 * k]
-                assert t >= last and 0 <= a < b <= 65536
-                last = t
-                s0, s1 = (S * int(a) + 32768) >> 16, (S * int(b) + 32768) >> 16
-                seen[t, s0:s1] += 1
-                load[w] += (s1 - s0) * cost[t]
-        assert (seen == 1).all()
-        assert load.max() - load.min() <= 2 * cost.max() + 1e-9
+    hdr, pool, caps = _lib.tile_plan(g, 128, 128, 128, 208, blocks=True)
+    check_blocks(hdr, pool, caps['blocks'])
+    assert caps['blocks'].shape[1] <= caps['meta_cap'] + 8          # no larger than the CSR form of the same lists
+    # a hub junction (30 conduits) + chain: overflow of the four-wide incidence lists and rows with more than 16 neighbours
+    edges = np.array([[0, i] for i in range(1, 31)] + [[i, i + 1] for i in range(30, 90)])
+    g = U.DrainageGraph.from_edges(edges)
+    hdr, pool, caps = _lib.tile_plan(g, 128, 128, 128, 208, blocks=True)
+    check_blocks(hdr, pool, caps['blocks'])
+    assert (caps['blocks'][:, 3] & 1).any() and (caps['blocks'][:, 3] & 2).any()
+    # a tile beyond the byte-wide local indices: no blocks (the layer then runs the unfused kernels)
+    star = np.array([[0, i] for i in range(1, 400)])
+    g = U.DrainageGraph.from_edges(star)
+    hdr, pool, caps = _lib.tile_plan(g, 128, 128, 128, 208, blocks=True)
+    assert caps['blocks'] is None
