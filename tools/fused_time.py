@@ -26,7 +26,7 @@ for a, b in ev:
     a.record(); layer(x, e); b.record()
 torch.cuda.synchronize()
 t = np.array([a.elapsed_time(b) for a, b in ev]) * 1e3
-sl = slice(0, S, max(1, S // 4))
+sl = slice(0, S, max(1, S // 2))
 torch.save({'x': ox[sl].cpu(), 'e': oe[sl].cpu()}, out_path)
 print(json.dumps({'lib': os.environ.get('UDS_LIB_PATH', 'default'), 'us_median': float(np.median(t)), 'us_min': float(t.min()),
                   'us_mean': float(t.mean()), 'plan': layer.network().plan_info()}))

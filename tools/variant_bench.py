@@ -31,6 +31,7 @@ for r in range(rounds):
         o = torch.load(out)
         if ref is None:
             ref = o
+        os.remove(out)
         rec['max_abs_diff_vs_first'] = max(float((o['x'] - ref['x']).abs().max()), float((o['e'] - ref['e']).abs().max()))
         res[l].append(rec)
         print('%-40s round %d: median %.1f us  min %.1f us  diff %.3g  tiles %s+%s' % (os.path.basename(l), r, rec['us_median'], rec['us_min'],
