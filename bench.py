@@ -104,36 +104,91 @@ def rollout_autoregressive(U, dev, steps=100):
     return out
 
 
-def cpu_baseline(g, block_params, d, budget_s=12.0, S=2):
-    """The oracle (sparse-CSR PyTorch-CPU restatement of the reference forward, kind 'port': the
-    reference's TF path cannot run here) timed on this host's cores on a bounded sample."""
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for line in fh:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _median_time(fn, warmup=3, reps=10, budget_s=10.0):
+    """Median wall time of fn(): `warmup` untimed calls, then at least `reps` timed ones (more while the budget lasts)."""
+    for _ in range(warmup):
+        fn()
+    ts, t_all = [], time.perf_counter()
+    while len(ts) < reps or (time.perf_counter() - t_all < budget_s and len(ts) < 200):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), len(ts)
+
+
+def cpu_baseline(U, g, block_params, d, gpu_out=None, gpu_in=None):
+    """The oracle (the build's PyTorch-CPU restatement of the reference forward, kind 'port': the reference's TF path
+    cannot run here) timed on this host's cores on a bounded sample, SURVEY.md section 8d: (i) the sparse-CSR form on the
+    benchmark network, (ii) the dense-masked form -- what the reference computes -- on a C2-size network (N = 2 000: the
+    dense logits of the headline network would be 400 MB per snapshot); fp32, median of >= 10 repetitions after 3
+    warm-ups.  Also the observed error of the GPU result on one snapshot of the timed configuration against the same
+    oracle in fp64 (`parity_err_vs_fp64`): what backs the `dtype` claim of the bench line."""
     from oracle import sparse_csr as OS
+    from oracle import spektral_dense as OD
     cores = min(os.cpu_count() or 1, 16)      # a 1-GPU box's CPU share is 16 cores; more threads only thrash
     torch.set_num_threads(cores)
+    L, S = len(block_params), 2
     gen = torch.Generator().manual_seed(2)
     x = torch.rand(S, g.n_node, d, generator=gen)
     e = torch.rand(S, g.n_edge, d, generator=gen)
     adj, eadj = (g.adj.rowptr, g.adj.col), (g.edge_adj.rowptr, g.edge_adj.col)
     inc_n, inc_e = (g.inc_n.rowptr, g.inc_n.col), (g.inc_e.rowptr, g.inc_e.col)
 
-    def one_pass():
-        xx, ee = x, e
-        for p in block_params:
+    def sparse_pass(xx=x, ee=e, params=block_params):
+        for p in params:
             xx, ee = OS.spatial_layer_csr(xx, ee, p, adj, eadj, inc_n, inc_e)
+        return xx, ee
+
+    t_sparse, n_sparse = _median_time(sparse_pass)
+    out = {'value': L * S / t_sparse, 'unit': 'graph-steps/s', 'cores': cores, 'kind': 'port', 'cpu_model': _cpu_model(),
+           'sample': 'median of %d passes (after 3 warm-ups) of the %d-layer block on S=%d snapshots of the same network, sparse-CSR '
+                     'torch-CPU fp32 oracle (%.3f s per pass)' % (n_sparse, L, S, t_sparse)}
+    # (ii) the dense-masked formulation (Spektral's, i.e. the reference's) on a C2-size network
+    g2 = U.DrainageGraph.from_edges(U.synthetic_drainage_network(2000, 2500, seed=0))
+    A, EA, NE = (torch.from_numpy(m.to_dense()).float() for m in (g2.adj, g2.edge_adj, g2.inc_n))
+    blk = U.SpatialBlock(g2, d, L, 'relu', sparse_params=False, generator=torch.Generator().manual_seed(1))     # CPU parameters only
+    p2 = [ly.export_params() for ly in blk.layers]
+    x2, e2 = torch.rand(S, 2000, d, generator=gen), torch.rand(S, 2500, d, generator=gen)
+
+    def dense_pass():
+        xx, ee = x2, e2
+        for p in p2:
+            xx, ee = OD.spatial_layer_dense(xx, ee, p, A, EA, NE)
         return xx
 
-    one_pass()
-    n, t0 = 0, time.perf_counter()
-    while True:
-        one_pass()
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or n >= 400:
-            break
-    steps = n * len(block_params) * S
-    return {'value': steps / el, 'unit': 'graph-steps/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d passes of the %d-layer block on S=%d snapshots of the same network (sparse-CSR torch-CPU fp32 oracle, %.1f s)'
-                      % (n, len(block_params), S, el)}
+    t_dense, n_dense = _median_time(dense_pass, budget_s=6.0)
+    p2s = [U.SpatialLayer(g2, d, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1)).export_params() for _ in range(L)]
+    adj2, eadj2 = (g2.adj.rowptr, g2.adj.col), (g2.edge_adj.rowptr, g2.edge_adj.col)
+    incn2, ince2 = (g2.inc_n.rowptr, g2.inc_n.col), (g2.inc_e.rowptr, g2.inc_e.col)
+
+    def sparse2_pass():
+        xx, ee = x2, e2
+        for p in p2s:
+            xx, ee = OS.spatial_layer_csr(xx, ee, p, adj2, eadj2, incn2, ince2)
+        return xx
+
+    t_sp2, _ = _median_time(sparse2_pass, budget_s=3.0)
+    out['dense_masked_c2'] = {'value': L * S / t_dense, 'unit': 'graph-steps/s', 'sample': 'median of %d passes, N=2000 E=2500 d=%d, %d layers, S=%d, '
+                              'dense-masked (Spektral) torch-CPU fp32 oracle' % (n_dense, d, L, S), 'sparse_csr_same_network': L * S / t_sp2}
+    if gpu_out is not None:      # observed error of the timed GPU block on its first snapshot against the fp64 oracle
+        x64, e64 = gpu_in[0][:1].double().cpu(), gpu_in[1][:1].double().cpu()
+        p64 = [{k: (v.double() if isinstance(v, torch.Tensor) else v) for k, v in p.items()} for p in block_params]
+        rx, re = sparse_pass(x64, e64, p64)
+        ex = float((gpu_out[0][:1].double().cpu() - rx).abs().max()) / max(1.0, float(rx.abs().max()))
+        ee = float((gpu_out[1][:1].double().cpu() - re).abs().max()) / max(1.0, float(re.abs().max()))
+        out['parity_err_vs_fp64'] = max(ex, ee)
+    return out
 
 
 def bench_c4(args, U, dist, world, rank, dev):
@@ -355,14 +410,18 @@ def main():
                          'kernel': ('k_fused_cs<128,128,128,8,relu>' if d == 128 else 'k_fused_tile<64,64,relu>') +
                                    ' (one launch per layer over S snapshots)' if args.precision == 'bf16x3' else
                                    'uds_spatial_layer_forward, unfused (8 launches per layer over S snapshots)',
-                         'algorithmic_bytes_per_graph_step': bytes_gs, 'device_ms_per_step': dev_ms},
+                         'algorithmic_bytes_per_graph_step': bytes_gs, 'device_ms_per_step': dev_ms,
+                         'timed_region_ms': wall * 1e3, 'run_to_run_spread': '2-3 % between boxes and runs (DESIGN.md section 7)'},
         }
         if world == 1 and args.embed == 64:
             out['rollout'] = rollout_forward(U, g, args, dev)
             if args.autoregressive:
                 out['rollout']['autoregressive'] = rollout_autoregressive(U, dev)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(g, params, d)
+            cb = cpu_baseline(U, g, params, d, gpu_out=step(), gpu_in=(x, e))
+            # max |GPU - fp64 oracle| / max(1, max|oracle|) over all rows of the first snapshot after the whole L-layer block
+            out['roofline']['parity_err_vs_fp64'] = cb.pop('parity_err_vs_fp64', None)
+            out['cpu_baseline'] = cb
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

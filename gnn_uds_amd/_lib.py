@@ -214,7 +214,7 @@ class NetworkHandle:
         _check(lib.uds_network_create(self.adj.ptr, self.edge_adj.ptr, self.inc_n.ptr, self.inc_e.ptr, ctypes.byref(h)),
                'uds_network_create')
         self._h = h
-        self._prepared = set() if os.environ.get('UDS_CS64') else {(64, 64)}
+        self._prepared = {(64, 64)}
 
     @property
     def ptr(self):

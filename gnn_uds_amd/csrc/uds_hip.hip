@@ -83,7 +83,7 @@ struct uds_plan_slot {
 
 struct uds_network {
   const uds_csr *adj = nullptr, *edge_adj = nullptr, *inc_n = nullptr, *inc_e = nullptr;
-  uds_plan_slot slot[8];          // d = 64 variants <FP, FS>: [0] <64,64>, [1] <64,96>, [2] <96,64>, [3] <96,96>; d = 128: [4] <128,128>, [5] <128,64>, [6] <64,128>; [7] d = 64 column-split 16-wave kernel <64,64>
+  uds_plan_slot slot[7];          // d = 64 variants <FP, FS>: [0] <64,64>, [1] <64,96>, [2] <96,64>, [3] <96,96>; d = 128: [4] <128,128>, [5] <128,64>, [6] <64,128>
 };
 
 namespace {
@@ -132,38 +132,9 @@ bool plan_network128(const uds::HostCsr &adj, const uds::HostCsr &eadj, const ud
   return false;
 }
 
-// Tile plan of the 16-wave column-split d = 64 kernel (k_fused_cs<64, ..>): <= 128 own rows (16 waves x 2 groups x 4 rows).
-bool plan_network_cs64(const uds::HostCsr &adj, const uds::HostCsr &eadj, const uds::HostCsr &inc_n, const uds::HostCsr &inc_e, int fp, int fs,
-                       uds::NetworkPlan &out, int64_t &lds) {
-  const int cand[][2] = {{128, 208}, {128, 192}, {128, 176}, {128, 160}, {128, 144}, {112, 160}, {112, 144}, {96, 144}, {96, 128},
-                         {80, 128}, {64, 96}, {48, 64}, {32, 48}, {16, 32}};
-  for (const auto &c : cand) {
-    const int p_lim = c[0], q_lim = c[1];
-    if (uds::fused_cs_lds_bytes(64, p_lim, q_lim, 0, fp, fs) > FUSED_LDS_BUDGET) continue;
-    const int t = std::min(p_lim, 4 * 16 * uds::F128_U);
-    out = uds::build_network_plan(adj, eadj, inc_n, inc_e, t, t, p_lim, q_lim);
-    lds = uds::fused_cs_lds_bytes(64, out.p_cap, out.q_cap, out.meta_cap, fp, fs);
-    if (lds <= FUSED_LDS_BUDGET && out.p_cap <= 4 * 16 * uds::F128_U) return true;
-  }
-  return false;
-}
-
 }  // namespace
 
 namespace {
-
-template <int ACT>
-hipError_t launch_fused_cs64_act(const uds::FusedArgs &a, int grid, int64_t lds, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&uds::k_fused_cs<64, 64, 64, 16, ACT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BUDGET);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((uds::k_fused_cs<64, 64, 64, 16, ACT>), dim3(grid), dim3(16 * 64), (size_t)lds, st, a);
-  return hipGetLastError();
-}
 
 template <int FP, int FS, int ACT>
 hipError_t launch_fused128_act(const uds::FusedArgs &a, int grid, int64_t lds, hipStream_t st) {
@@ -631,26 +602,9 @@ static int build_slot(uds_network *n, int fp, int fs) {
   return UDS_OK;
 }
 
-static int build_slot_cs64(uds_network *n) {
-  uds_plan_slot &sl = n->slot[7];
-  if (sl.built) return UDS_OK;
-  sl.built = true;
-  sl.fp = sl.fs = 64;
-  if (!plan_network_cs64(n->adj->host, n->edge_adj->host, n->inc_n->host, n->inc_e->host, 64, 64, sl.plan, sl.lds_bytes)) return UDS_OK;
-  hipError_t e;
-  if ((e = hipMalloc(&sl.d_hdr, sizeof(int32_t) * sl.plan.hdr.size())) != hipSuccess ||
-      (e = hipMalloc(&sl.d_pool, sizeof(int32_t) * sl.plan.pool.size())) != hipSuccess ||
-      (e = hipMemcpy(sl.d_hdr, sl.plan.hdr.data(), sizeof(int32_t) * sl.plan.hdr.size(), hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = hipMemcpy(sl.d_pool, sl.plan.pool.data(), sizeof(int32_t) * sl.plan.pool.size(), hipMemcpyHostToDevice)) != hipSuccess)
-    return fail(UDS_ENOMEM, "tile plan upload -> %s", hipGetErrorString(e));
-  sl.ok = true;
-  return UDS_OK;
-}
-
 int uds_network_prepare(uds_network_t *net, int64_t fx, int64_t fe) {
   UDS_REQUIRE(net != nullptr, "uds_network_prepare: NULL network");
   if (net->adj->n_rows == 0 || net->edge_adj->n_rows == 0) return UDS_OK;
-  if (fx == 64 && fe == 64 && std::getenv("UDS_CS64")) return build_slot_cs64(net);      // experimental 16-wave kernel
   if (fx == 128 && (fe == 128 || fe == 64)) {      // the d = 128 kernel: node tiles <fx, fe>, link tiles <fe, fx>
     int rc = build_slot(net, 128, (int)fe);
     if (rc == UDS_OK && fe == 64) rc = build_slot(net, 64, 128);
@@ -902,46 +856,6 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
     if (he != hipSuccess) return fail(UDS_EHIP, "uds_spatial_layer_forward: fused d=128 launch -> %s", hipGetErrorString(he));
     return UDS_OK;
   }
-  if (h == uds::FUSED_H && d == uds::FUSED_D && fx == 64 && fe == 64 && !xb && !eb && !(flags & UDS_FLAG_EXACT_FP32) && net->slot[7].ok &&
-      std::getenv("UDS_CS64")) {
-    const uds_plan_slot &u = net->slot[7];
-    const uint4 *wq = reinterpret_cast<const uint4 *>(p->packed);
-    if (!wq) {
-      int rc = uds_spatial_pack_weights(p, fx, fe, h, d, ws, stream);
-      if (rc != UDS_OK) return rc;
-      wq = reinterpret_cast<const uint4 *>(ws);
-    }
-    uds::FusedArgs a;
-    a.blocks = nullptr;
-    a.side[0] = uds::FusedSide{x, e, nullptr, nullptr, out_x, wq, wq + 768, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
-    a.side[1] = uds::FusedSide{e, x, nullptr, nullptr, out_e, wq + 768 + 2048, wq + 2 * 768 + 2048, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val,
-                               (int)E, (int)N};
-    a.hdr = u.d_hdr;
-    a.pool = u.d_pool;
-    a.n_tiles = u.plan.n_tiles;
-    a.p_cap = u.plan.p_cap;
-    a.q_cap = u.plan.q_cap;
-    a.meta_cap = u.plan.meta_cap;
-    a.S = (int)S;
-    a.act = act;
-    a.dbg = nullptr;
-    a.side_mask = 3;
-    int64_t chunk = S, best = INT64_MAX;
-    for (int64_t c = 1; c <= S; ++c) {
-      const int64_t rounds = (((S + c - 1) / c) * a.n_tiles + 255) / 256;
-      const int64_t cost = rounds * (3 + 2 * c);
-      if (cost < best || (cost == best && c < chunk)) {
-        best = cost;
-        chunk = c;
-      }
-    }
-    a.chunk = (int)chunk;
-    const int grid = (int)(((S + chunk - 1) / chunk) * a.n_tiles);
-    hipError_t he = act == UDS_ACT_RELU ? launch_fused_cs64_act<UDS_ACT_RELU>(a, grid, u.lds_bytes, st)
-                                        : launch_fused_cs64_act<-1>(a, grid, u.lds_bytes, st);
-    if (he != hipSuccess) return fail(UDS_EHIP, "uds_spatial_layer_forward: 16-wave d=64 launch -> %s", hipGetErrorString(he));
-    return UDS_OK;
-  }
   // (rows of one snapshot are addressed with a 32-bit byte offset from a per-snapshot base: N, E < 2^31 / 384)
   const bool shape_ok = h == uds::FUSED_H && d == uds::FUSED_D && (fx == 64 || fx == 96) && (fe == 64 || fe == 96) &&
                         std::max(N, E) * 384 < ((int64_t)1 << 31);
@@ -1003,7 +917,9 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
           chunk = c;
         }
       }
-      if (const char *ov = std::getenv("UDS_CHUNK")) chunk = std::max<int64_t>(1, std::min<int64_t>(S, std::atoll(ov)));   // experiment knob
+#ifdef UDS_KNOBS
+      if (const char *ov = std::getenv("UDS_CHUNK")) chunk = std::max<int64_t>(1, std::min<int64_t>(S, std::atoll(ov)));   // experiment builds only (UDS_DEFINES=-DUDS_KNOBS)
+#endif
       a.chunk = (int)chunk;
       return (int)(((S + chunk - 1) / chunk) * a.n_tiles);
     };

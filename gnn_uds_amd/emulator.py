@@ -195,7 +195,8 @@ class Emulator(nn.Module):
         # host-side facts about the constant buffers (the reference tests them per call, emulator.py:688,698,630): decided once,
         # so the forward path has no device -> host synchronisation (and can be captured into a HIP graph)
         self._has_offset = bool(float(self.offset.max()) > 0) if self.n_edge else False
-        self._has_pump = bool(float(self.pump.min()) > 0) if self.n_edge else False
+        self._has_pump = bool(float(self.pump.min()) > 0) if self.n_edge else False             # `self.pump.min() > 0` (:698)
+        self._has_link_pump = bool(float(self.pump.abs().max()) > 0) if self.n_edge else False   # any rated link pump (NumPy-mode override, :656-659)
         self._has_any_pump = bool(float(self.pump_in.sum() + self.pump_out.sum() + self.pump.sum()) > 0)
         self._idx_cache = {}
         self._norm_derived = {}
@@ -366,8 +367,22 @@ class Emulator(nn.Module):
         return q_in.reshape(lead + (self.n_node, 1)), q_out.reshape(lead + (self.n_node, 1))
 
     def post_proc_tf(self, preds, a, b):
+        """`post_proc_tf` (emulator.py:680-725): the graph-mode post-processing used by `predict_tf`, `_model`, MPC and MBRL."""
+        return self._post_proc(preds, a, b, False)
+
+    def post_proc(self, y, ey, a, b):
+        """`post_proc` (emulator.py:643-678): the NumPy twin used by `predict` and `simulate`.  NOT equivalent to
+        `post_proc_tf` where pumps are involved: the rated-pump override of the link flow is applied whenever the model has
+        actions (the graph-mode form only when EVERY link is a pump, `self.pump.min() > 0`, :698), and the node pumps of the
+        non-edge-fusion form open at depth > 0.01 instead of > 0 (:664-665 vs :710-711).  The offset gate is written without
+        its `offset.max() > 0` guard (:649-653 vs :688), which changes nothing: with no offsets the expression is the flow."""
+        return self._post_proc((y, ey), a, b, True)
+
+    def _post_proc(self, preds, a, b, np_form):
         preds, edge_preds = preds
-        if self.node_edge is None and (self._has_offset or (self.act and self._has_pump)):
+        pump_override = self._has_link_pump if np_form else self._has_pump      # :656-659 (always with actions) vs :698 (`pump.min() > 0`)
+        depth_gate = 0.01 if np_form else 0.0                                      # :664-665 vs :710-711
+        if self.node_edge is None and (self._has_offset or (self.act and pump_override)):
             raise NotImplementedError('offset / pump gating needs the dense incidence (`args.node_edge`), not built for CSR-only networks')
         pos = None if self.node_edge is None else self.node_edge.clamp(0, 1)
         if self.tide:
@@ -381,7 +396,7 @@ class Emulator(nn.Module):
             edge_preds = torch.cat([edge_preds[..., :-1], flow], dim=-1)
         if self.act:
             ne_ = self._norm('e', preds.device)
-            if self._has_pump:
+            if pump_override:
                 fl = self.pump * torch.matmul((preds[..., 0] > 0.01).float(), pos)
                 fl = fl * (ne_[0, :, 2] > 1e-3).float() / ne_[0, :, 2]
                 flow = (edge_preds[..., -1] * (fl == 0).float() + fl).unsqueeze(-1)
@@ -391,8 +406,8 @@ class Emulator(nn.Module):
             if not self.edge_fusion:
                 ny = self._norm('y', preds.device)
                 a_out, a_in = self.get_action(a[:, :self.seq_out], True)
-                fli = self.pump_in * (preds[..., 0] > 0).float() / ny[0, :, 1]
-                flo = self.pump_out * (preds[..., 0] > 0).float() / ny[0, :, 2]
+                fli = self.pump_in * (preds[..., 0] > depth_gate).float() / ny[0, :, 1]
+                flo = self.pump_out * (preds[..., 0] > depth_gate).float() / ny[0, :, 2]
                 inflow = preds[..., 1] * (fli == 0).float() + fli
                 outflow = preds[..., 2] * (flo == 0).float() + flo
                 preds = torch.cat([torch.stack([preds[..., 0], inflow * a_in, outflow * a_out], dim=-1), preds[..., 3:]], dim=-1)
@@ -424,13 +439,22 @@ class Emulator(nn.Module):
 
     # ------------------------------------------------------------------ inference entry points
     def predict_tf(self, states, b, a=None, edge_state=None):
+        """emulator.py:604-641 (graph mode: `post_proc_tf`)."""
+        return self._predict(states, b, a, edge_state, False)
+
+    def predict(self, states, b, a=None, edge_state=None):
+        """emulator.py:566-602: the NumPy-mode entry point (`post_proc`, see there for how it differs from `predict_tf`);
+        tensors stay on the device."""
+        return self._predict(states, b, a, edge_state, True)
+
+    def _predict(self, states, b, a, edge_state, np_form):
         x = states[:, -self.seq_in:]
         ex = edge_state[:, -self.seq_in:]
         assert b.shape[1] == self.seq_out
         ae = self.get_edge_action(a, True) if self.act else None
         nb_ = self.normalize(b, 'b')
         y, ey = self.forward(self.normalize(x, 'x'), nb_, self.normalize(ex, 'e'), ae)
-        y, ey = self.post_proc_tf((y, ey), a, nb_)
+        y, ey = self._post_proc((y, ey), a, nb_, np_form)
         ey = self.normalize(ey, 'e', True)
         ey = torch.cat([torch.minimum(ey[..., 0].clamp(min=0), self.ehmax).unsqueeze(-1), ey[..., 1:]], dim=-1)
         y = self.normalize(y, 'y', True)
@@ -446,8 +470,6 @@ class Emulator(nn.Module):
             y = torch.cat([(h * (1 - ps) + torch.stack(de, dim=1) * ps).unsqueeze(-1), y[..., 1:]], dim=-1)
         q_w, y = self.constrain_tf(y, b[..., :1], x[:, -1:, :, 0])
         return torch.cat([y, q_w.unsqueeze(-1)], dim=-1), ey
-
-    predict = predict_tf      # the reference's NumPy twin (`predict`, :566-602) differs only in host round trips
 
     def _model(self, x, a, b, ex, ae=None, adj=None, fit=False):
         """emulator.py:400-438 on normalised tensors; `roll` > 0 = autoregressive chunks of seq_out steps."""
@@ -563,7 +585,7 @@ class Emulator(nn.Module):
         """emulator.py:521-564, with every sliding window of the event batched into ONE forward (the reference loops
         over time steps with a host round trip each).  states (n,T_in,N,C), runoff (n,T_out,N,b_in) -> (n,T_out,N,5), (n,T_out,E,3)."""
         runoff = runoff[:, :self.seq_out]
-        return self.predict_tf(states, runoff, a, edge_states)
+        return self.predict(states, runoff, a, edge_states)      # (the reference's loop body is `predict` on one window: NumPy-mode `post_proc`)
 
     # ------------------------------------------------------------------ training step (:440-484)
     def _loss_setup(self, device):

@@ -8,6 +8,8 @@ Restates, on torch CPU tensors (fp64 or fp32), `surrogate/emulator.py` of the re
   post_proc          post_proc_tf                                              emulator.py:680-725
   constrain          constrain_tf                                              emulator.py:750-770
   predict            predict_tf                                                emulator.py:604-641
+  post_proc_np / predict_np / simulate   the NumPy-mode twins (`post_proc`, `predict`, `simulate`'s per-step loop)
+                                                                               emulator.py:643-678, 566-602, 521-564
   model_rollout      _model with roll > 0 (curriculum / autoregressive chunks) emulator.py:400-438
 
 `args` is any object with the reference's attribute names (`state_shape`, `edge_state_shape`, `seq_in`,
@@ -355,6 +357,90 @@ def predict(args, params, norms, states, b, a=None, edge_state=None):
         y = torch.cat([(h * (1 - ps) + de * ps).unsqueeze(-1), y[..., 1:]], dim=-1)
     q_w, y = constrain(args, y, b[..., :1])
     return torch.cat([y, q_w.unsqueeze(-1)], dim=-1), ey
+
+
+def post_proc_np(args, norms, y, ey, a, b):
+    """`post_proc` (emulator.py:643-678), the NumPy twin of `post_proc_tf` used by `predict` and `simulate`, restated in
+    NumPy op for op.  It is NOT the same function: the offset gate has no `offset.max() > 0` guard (:649-653), the rated-
+    pump override of the link flow is applied whenever the model has actions -- no `pump.min() > 0` guard (:656-659 vs
+    :698) -- and the node pumps of the non-edge-fusion form open at depth > 0.01 instead of > 0 (:664-665 vs :710-711)."""
+    c = config(args)
+    y, ey = np.array(y, dtype=np.float64), np.array(ey, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    N = {k: np.asarray(v, dtype=np.float64) for k, v in norms.items()}
+    nz = lambda dat, item, inv=False: (dat * (N[item][0, ..., :dat.shape[-1]] - N[item][1, ..., :dat.shape[-1]]) + N[item][1, ..., :dat.shape[-1]]) if inv \
+        else (dat - N[item][1, ..., :dat.shape[-1]]) / (N[item][0, ..., :dat.shape[-1]] - N[item][1, ..., :dat.shape[-1]])
+    ne = np.asarray(c.node_edge, dtype=np.float64)
+    if c.tide:                                                    # :645-647
+        h = y[..., 0] * (1 - c.is_outfall) + b[..., -1]
+        y = np.concatenate([np.expand_dims(h, -1), y[..., 1:]], axis=-1)
+    inoff = np.matmul(nz(y, 'y', True)[..., 0] - c.hmin, np.clip(ne, 0, 1))      # :649
+    flow = np.expand_dims(ey[..., -1] * (ey[..., -1] > 0) * (c.offset > 0) * (inoff > c.offset) +
+                          ey[..., -1] * (ey[..., -1] <= 0) * (c.offset > 0) + ey[..., -1] * (c.offset == 0), axis=-1)      # :650-652
+    ey = np.concatenate([ey[..., :-1], flow], axis=-1)
+    if c.act:                                                     # :654-671
+        at = torch.as_tensor(np.asarray(a), dtype=torch.float64)
+        ae = get_edge_action(c, at).numpy()
+        fl = c.pump * np.matmul((y[..., 0] > 0.01).astype(np.float64), np.clip(ne, 0, 1))      # :657
+        fl = fl * (N['e'][0, :, 2] > 1e-3) / N['e'][0, :, 2]
+        ey[..., -1] = ey[..., -1] * (fl == 0) + fl
+        ey[..., -1:] = ey[..., -1:] * ae
+        if not c.edge_fusion:
+            a_out, a_in = (t.numpy() for t in get_action(c, at[:, :c.seq_out]))
+            fli = c.pump_in * (y[..., 0] > 0.01) / N['y'][0, :, 1]
+            flo = c.pump_out * (y[..., 0] > 0.01) / N['y'][0, :, 2]
+            y[..., 1] = y[..., 1] * (fli == 0) + fli
+            y[..., 2] = y[..., 2] * (flo == 0) + flo
+            y[..., 2] = y[..., 2] * a_out
+            y[..., 1] = y[..., 1] * a_in
+    if c.edge_fusion:                                             # :672-677
+        efl = nz(ey, 'e', True)[..., -1:]
+        node_out = np.matmul(np.clip(ne, 0, 1), np.clip(efl, 0, np.inf)) + np.matmul(np.abs(np.clip(ne, -1, 0)), -np.clip(efl, -np.inf, 0))
+        node_in = np.matmul(np.abs(np.clip(ne, -1, 0)), np.clip(efl, 0, np.inf)) + np.matmul(np.clip(ne, 0, 1), -np.clip(efl, -np.inf, 0))
+        node_out = node_out * (N['y'][0, :, 2:3] > 1e-3) / N['y'][0, :, 2:3]
+        node_in = node_in * (N['y'][0, :, 1:2] > 1e-3) / N['y'][0, :, 1:2]
+        y = np.concatenate([y[..., :1], node_in, node_out, y[..., 1:]], axis=-1)
+    return y, ey
+
+
+def predict_np(args, params, norms, states, b, a=None, edge_state=None):
+    """`predict` (emulator.py:566-602): as `predict_tf` but through `post_proc` (NumPy mode) and the NumPy `constrain`."""
+    c = config(args)
+    dt = states.dtype
+    T = lambda v: torch.as_tensor(np.asarray(v), dtype=dt)
+    x = states[:, -c.seq_in:]
+    ex = edge_state[:, -c.seq_in:]
+    assert b.shape[1] == c.seq_out
+    ae = get_edge_action(c, a) if c.act else None
+    y, ey = forward(args, params, normalize(norms, x, 'x'), normalize(norms, b, 'b'), normalize(norms, ex, 'e'), ae)
+    y, ey = post_proc_np(args, norms, y.numpy(), ey.numpy(), None if a is None else a.numpy(), normalize(norms, b, 'b').numpy())
+    y, ey = T(y), T(ey)
+    y = normalize(norms, y, 'y', True)
+    ey = normalize(norms, ey, 'e', True)
+    ey = torch.cat([torch.minimum(ey[..., 0].clamp(min=0), T(c.ehmax)).unsqueeze(-1), ey[..., 1:]], dim=-1)   # :587
+    if c.pump_in.sum() + c.pump_out.sum() + c.pump.sum() > 0:     # :590-598
+        ps = ((T(c.area) * (T(c.node_edge).clamp(0, 1) @ T(c.pump))) > 0).to(dt)
+        h, qin, qout = y[..., 0], y[..., 1], y[..., 2]
+        de = []
+        for t in range(c.seq_out):
+            prev = x[:, -1, :, 0] if t == 0 else de[-1] + (qin - qout)[:, t] / (T(c.area) + 1e-6)
+            de.append(torch.minimum(torch.maximum(prev, T(c.hmin)), T(c.hmax)))
+        y = torch.cat([(h * (1 - ps) + torch.stack(de, dim=1) * ps).unsqueeze(-1), y[..., 1:]], dim=-1)
+    q_w, y = constrain(args, y, b[..., :1])                       # (`constrain` and `constrain_tf` agree, :727-770)
+    return torch.cat([y, q_w.unsqueeze(-1)], dim=-1), ey
+
+
+def simulate(args, params, norms, states, runoff, a=None, edge_states=None):
+    """`simulate` (emulator.py:521-564): the reference's per-time-step loop -- one un-batched forward per window,
+    NumPy-mode post-processing -- restated as that loop (the product batches the windows into one forward)."""
+    c = config(args)
+    preds, edge_preds = [], []
+    for idx in range(runoff.shape[0]):                            # :528
+        y, ey = predict_np(args, params, norms, states[idx:idx + 1], runoff[idx:idx + 1, :c.seq_out],
+                           None if a is None else a[idx:idx + 1], edge_states[idx:idx + 1])
+        preds.append(y[0])
+        edge_preds.append(ey[0])
+    return torch.stack(preds), torch.stack(edge_preds)
 
 
 def model_rollout(args, params, norms, x, a, b, ex):

@@ -1,6 +1,12 @@
 """GPU parity of the whole surrogate (`Emulator`) against the fp64 CPU oracle: network forward, predict_tf with its
 post-processing, autoregressive rollout, plus the three non-graph kernels it adds (causal Conv1D, resnet prefix sum,
-link->node flow balance).  Tolerances are stated per test; the oracle itself is "parity unpinned" (oracle/__init__.py)."""
+link->node flow balance).  The oracle itself is "parity unpinned" (oracle/__init__.py).
+
+Tolerances (relative to max(1, max|ref|); 3-6x above the largest error MEASURED over this file, UDS_TOL_REPORT=1):
+  single exact-fp32 kernels 5e-6 (prefix sums over T steps: x sqrt(T)); single split-bf16 row-GEMM kernels 1e-4
+  (measured <= 2.7e-5); whole forward 2e-5 with split-bf16 layers (measured <= 5e-6), 5e-6 exact fp32 (measured 6e-7)."""
+TOL_FWD = {'fp32': 5e-6, 'bf16x3': 2e-5}      # whole Emulator forward
+TOL_ROWGEMM = 1e-4
 import numpy as np
 import pytest
 import torch
@@ -9,7 +15,7 @@ import gnn_uds_amd as U
 from gnn_uds_amd import _lib
 from oracle import emulator_ref as OE
 from oracle import spektral_dense as OD
-from tests.util import emulator_args, emulator_norms, load_emulator
+from tests.util import close, emulator_args, emulator_norms, load_emulator
 
 pytestmark = pytest.mark.gpu
 
@@ -20,12 +26,6 @@ def dev():
     return torch.device('cuda', 0)
 
 
-def close(out, ref, tol):
-    out = out.detach().double().cpu()
-    assert out.shape == ref.shape, (out.shape, ref.shape)
-    err = float((out - ref).abs().max())
-    lim = tol * max(1.0, float(ref.abs().max()))
-    assert err <= lim, 'max abs err %.3e > %.3e' % (err, lim)
 
 
 def rnd(g, *shape):
@@ -38,7 +38,7 @@ def test_conv1d_causal(dev, B, T, R, F, H, dil, act):
     x, k, b = rnd(g, B, T, R, F) - 0.5, rnd(g, 3, F, H) - 0.5, rnd(g, H) - 0.5
     ref = OE.conv1d_causal(x.permute(0, 2, 1, 3).reshape(B * R, T, F), k, b, dil, act).reshape(B, R, T, H).permute(0, 2, 1, 3)
     f = lambda t: t.float().to(dev)
-    close(_lib.conv1d_causal(f(x), f(k), f(b), dil, act), ref, 2e-5)
+    close(_lib.conv1d_causal(f(x), f(k), f(b), dil, act), ref, 5e-6)
 
 
 @pytest.mark.parametrize('B,T,R,F,H,taps,dil,act', [(2, 5, 7, 64, 64, 3, 1, 'relu'), (1, 60, 3, 96, 64, 3, 4, 'relu'), (3, 4, 50, 64, 32, 3, 2, 'tanh'),
@@ -62,7 +62,7 @@ def test_rowgemm_mfma_dense_and_conv(dev, B, T, R, F, H, taps, dil, act):
         ref = OE.conv1d_causal(x.permute(0, 2, 1, 3).reshape(B * R, T, F), k, b, dil, act).reshape(B, R, T, H).permute(0, 2, 1, 3)
     f = lambda t: t.float().to(dev)
     packed = _lib.rowgemm_pack(f(k).reshape(taps * F, H))
-    close(_lib.rowgemm_forward(f(x), packed, f(b), H, act, taps=taps, dilation=dil), ref, 2e-4)
+    close(_lib.rowgemm_forward(f(x), packed, f(b), H, act, taps=taps, dilation=dil), ref, TOL_ROWGEMM)
     close(_lib.rowgemm_forward(f(x), packed, None, H, 'linear', taps=taps, dilation=dil) if taps == 1 else
           _lib.rowgemm_forward(f(x), packed, None, H, 'linear', taps=taps, dilation=dil),
           OD.dense(x, k[0], None) if taps == 1 else
@@ -82,8 +82,8 @@ def test_dense_cumsum_stream(dev, B, T, R, act, with_res):
     ref = OD.activation(act)(ref + res if with_res else ref)
     f = lambda t: None if t is None else t.float().to(dev)
     out = _lib.dense_cumsum(f(x), _lib.rowgemm_pack(f(k)), f(b), f(res), act)
-    close(out, ref, 2e-4 * max(1.0, T ** 0.5))
-    close(_lib.dense_cumsum(f(x), _lib.rowgemm_pack(f(k)), None, None, 'linear'), torch.cumsum(x @ k, dim=1), 2e-4 * max(1.0, T ** 0.5))
+    close(out, ref, TOL_ROWGEMM * max(1.0, T ** 0.5))
+    close(_lib.dense_cumsum(f(x), _lib.rowgemm_pack(f(k)), None, None, 'linear'), torch.cumsum(x @ k, dim=1), TOL_ROWGEMM * max(1.0, T ** 0.5))
 
 
 def test_cumsum_act_and_flow_balance(dev, networks):
@@ -126,7 +126,7 @@ def _inputs(args, B, seed=5, n_act=2):
     return X, Bd, Ex, a
 
 
-@pytest.mark.parametrize('precision,tol', [('fp32', 5e-5), ('bf16x3', 5e-4)])
+@pytest.mark.parametrize('precision,tol', [('fp32', TOL_FWD['fp32']), ('bf16x3', TOL_FWD['bf16x3'])])
 def test_network_forward(dev, networks, precision, tol):
     """build_network (emulator.py:166-341): GAT, edge fusion, actions, flood head, resnet; B*T = 10 snapshots."""
     args, params, emul, _ = _setup(networks, 'shunqing', dev, precision)
@@ -149,7 +149,7 @@ def test_network_forward_gcn_and_plain_variants(dev, networks):
     f = lambda t: t.float().to(dev)
     y, ey = emul(f(X), f(Bd), f(Ex))
     assert ry.shape == (3, 2, 30, 3)
-    close(y, ry, 5e-5); close(ey, rey, 5e-5)
+    close(y, ry, TOL_FWD['fp32']); close(ey, rey, TOL_FWD['fp32'])
 
 
 @pytest.mark.parametrize('variant', ['edge_fusion_act', 'pumps_offset_tide', 'plain'])
@@ -175,8 +175,50 @@ def test_predict_tf(dev, networks, variant):
     # compare the bulk tightly and allow a handful of flipped entries
     for out, ref in ((y, ry), (ey, rey)):
         d = (out.double().cpu() - ref).abs()
-        bad = int((d > 1e-4 * max(1.0, float(ref.abs().max()))).sum())
+        bad = int((d > 2e-5 * max(1.0, float(ref.abs().max()))).sum())
         assert bad <= max(2, ref.numel() // 500), (variant, bad, ref.numel(), float(d.max()))
+
+
+@pytest.mark.parametrize('variant', ['mixed_pumps_edge_fusion', 'mixed_pumps_node_gates', 'no_pumps'])
+def test_predict_and_simulate_numpy_mode(dev, networks, variant):
+    """`predict` / `simulate` (emulator.py:566-602, 521-564) go through the NumPy `post_proc` (:643-678), which is NOT
+    `post_proc_tf`: on a network where SOME links are pumps (the usual act = True case) the rated-pump override applies in
+    `post_proc` and not in `post_proc_tf` (`pump.min() > 0` is false), and the node pumps open at depth > 0.01 instead of
+    > 0.  Oracle: the reference's loop restated as a loop, one un-batched NumPy-mode forward per window
+    (oracle/emulator_ref.py: simulate); the product batches the windows into one forward."""
+    rng = np.random.default_rng(3)
+    net = networks['astlingen']
+    n, e = net['n_node'], len(net['edges'])
+    some = (rng.random(e) > 0.6)
+    if variant == 'mixed_pumps_edge_fusion':
+        over = dict(edge_fusion=True, act=True, pump=(0.1 + rng.random(e)) * some, area=rng.random(n), offset=rng.random(e) * (rng.random(e) > 0.5))
+    elif variant == 'mixed_pumps_node_gates':
+        over = dict(edge_fusion=False, act=True, tide=True, pump=(0.1 + rng.random(e)) * some, pump_in=rng.random(n) * (rng.random(n) > 0.7),
+                    pump_out=rng.random(n) * (rng.random(n) > 0.7), area=rng.random(n), epsilon=0.1)
+    else:
+        over = dict(edge_fusion=True, act=True)
+    args, params, emul, norms = _setup(networks, 'astlingen', dev, 'fp32', **over)
+    n_win = 4
+    X, Bd, Ex, a = _inputs(args, n_win)
+    f = lambda t: t.float().to(dev)
+    ry, rey = OE.simulate(args, params, norms, X, Bd, a, Ex)                    # the per-window loop
+    y, ey = emul.simulate(f(X), f(Bd), f(a), f(Ex))                             # all windows in one forward
+    py, pey = emul.predict(f(X), f(Bd), f(a), f(Ex))
+    assert torch.equal(y, py) and torch.equal(ey, pey)
+    assert tuple(y.shape) == tuple(ry.shape) and tuple(ey.shape) == tuple(rey.shape)
+    # hard thresholds (flood bit > 0.5, depth > 0.01, flow > 0 ...) can flip on values within rounding of the threshold:
+    # compare the bulk tightly and allow a handful of flipped entries
+    for out, ref in ((y, ry), (ey, rey)):
+        d = (out.double().cpu() - ref).abs()
+        bad = int((d > 2e-5 * max(1.0, float(ref.abs().max()))).sum())
+        assert bad <= max(2, ref.numel() // 500), (variant, bad, ref.numel(), float(d.max()))
+    # the two modes really differ where the reference's do: link flows on the mixed-pump networks
+    ty, tey = emul.predict_tf(f(X), f(Bd), f(a), f(Ex))
+    differs = float((tey - ey).abs().max()) > 1e-3
+    assert differs == (variant != 'no_pumps'), (variant, float((tey - ey).abs().max()))
+    rty, rtey = OE.predict(args, params, norms, X, Bd, a, Ex)                   # and predict_tf still matches ITS restatement
+    d = (tey.double().cpu() - rtey).abs()
+    assert int((d > 2e-5 * max(1.0, float(rtey.abs().max()))).sum()) <= max(2, rtey.numel() // 500)
 
 
 def test_model_rollout(dev, networks):
@@ -188,14 +230,15 @@ def test_model_rollout(dev, networks):
     y, ey = emul._model(f(X), f(a), f(Bd), f(Ex))
     assert ry.shape == (2, 6, 30, 4)
     d = (y.double().cpu() - ry).abs()
-    assert int((d > 2e-4).sum()) <= max(2, ry.numel() // 500), float(d.max())
-    assert float((ey.double().cpu() - rey).abs().max()) < 5e-3
+    assert int((d > 2e-5).sum()) <= max(2, ry.numel() // 500), float(d.max())
+    de = (ey.double().cpu() - rey).abs()
+    assert int((de > 2e-5 * max(1.0, float(rey.abs().max()))).sum()) <= max(2, rey.numel() // 500), float(de.max())
 
 
 @pytest.mark.parametrize('graph_base', [1, 2])
 def test_graph_base_variants(dev, networks, graph_base):
     """graph_base = 1 / 2 (`emulator.py:220-223,273-276`): one conv over the stacked node + link rows on the combined
-    graph of `get_node_based_adj` / `get_edge_based_adj`; forward parity with the oracle (exact-fp32 conv: 5e-5) from the
+    graph of `get_node_based_adj` / `get_edge_based_adj`; forward parity with the oracle from the
     dense `args.adj` AND from the CSR builders (`args.graph`)."""
     net = networks['astlingen']
     edges, n = np.array(net['edges']), net['n_node']
@@ -209,7 +252,7 @@ def test_graph_base_variants(dev, networks, graph_base):
     f = lambda t: t.float().to(dev)
     emul = load_emulator(U.Emulator(args.conv, args.resnet, args.recurrent, args), params, dev)
     y, ey = emul(f(X), f(Bd), f(Ex), f(AE))
-    close(y, ry, 5e-4); close(ey, re, 5e-4)
+    close(y, ry, TOL_FWD['bf16x3']); close(ey, re, TOL_FWD['bf16x3'])
     args2 = emulator_args(edges, n, graph_base=graph_base, n_sp_layer=2)
     args2.graph, args2.adj = U.DrainageGraph.from_edges(edges, n), None
     emul2 = load_emulator(U.Emulator(args2.conv, args2.resnet, args2.recurrent, args2), params, dev)
@@ -222,7 +265,7 @@ def test_graph_base_variants(dev, networks, graph_base):
 @pytest.mark.parametrize('graph_base,use_pred', [(0, False), (0, True), (1, False)])
 def test_rl_convnet_encoder(dev, networks, graph_base, use_pred):
     """`ConvNet` of the RL agents (agent.py:20-99): embeddings + the spatial block + GlobalAttnSumPool; batch of single
-    snapshots.  Tolerance 5e-4 * max(1, max|ref|) (fused split-bf16 layers)."""
+    snapshots.  Tolerance TOL_FWD['bf16x3'] (fused split-bf16 layers)."""
     from oracle import emulator_ref as ER
     net = networks['shunqing']
     edges, n = np.array(net['edges']), net['n_node']
@@ -263,13 +306,13 @@ def test_rl_convnet_encoder(dev, networks, graph_base, use_pred):
                 mod.attn_kernel_self.data, mod.attn_kernel_neighs.data = f32(q[key]['attn_kernel_self']), f32(q[key]['attn_kernel_neighs'])
     out = m(f32(X), f32(E), f32(Bd) if use_pred else None)
     assert tuple(out.shape) == (Bn, 64)
-    close(out, ref, 5e-4)
+    close(out, ref, TOL_FWD['bf16x3'])
 
 
 def test_emulator_at_the_reference_default_sizes(dev, networks):
     """embed_size 128, hidden_dim 64, n_sp_layer 2, n_tp_layer 2, seq_in 6, seq_out 1 (utils/config.yaml): the d = 128 fused
     kernel (block 1, later layers of block 2), the 64-column-block row GEMM for 128-wide Dense outputs, the 3 x 128 -> 64
-    Conv1D.  Whole-forward tolerance 5e-4 * max(1, max|ref|) as for d = 64; a batch large enough (rows >= 4096) to take
+    Conv1D.  Whole-forward tolerance as for d = 64; a batch large enough (rows >= 4096) to take
     the matrix-core paths."""
     net = networks['RedChicoSur']
     edges, n = np.array(net['edges']), net['n_node']
@@ -284,7 +327,7 @@ def test_emulator_at_the_reference_default_sizes(dev, networks):
     f = lambda t: t.float().to(dev)
     emul = load_emulator(U.Emulator(args.conv, args.resnet, args.recurrent, args), params, dev)
     y, ey = emul(f(X), f(Bd), f(Ex), f(AE))
-    close(y, ry, 5e-4); close(ey, re, 5e-4)
+    close(y, ry, TOL_FWD['bf16x3']); close(ey, re, TOL_FWD['bf16x3'])
     assert emul.block1.layers[0].network().plan_info()['fused'] & 8
 
 

@@ -1,7 +1,11 @@
 """GPU parity: the HIP path (through the C ABI) vs the CPU oracle on identical seeded inputs.
 
-Tolerance (stated, fp32 path): every output element within 2e-5 * max(1, max|ref|) of the fp64
-oracle -- the kernels use exact fp32 fmaf arithmetic, so the gap is fp32 rounding plus expf.
+Tolerances (stated; relative to max(1, max|ref|), every output element, against the fp64 oracle).  They sit 3-6x above
+the largest error the kernels were MEASURED at over this whole file (UDS_TOL_REPORT=1 prints observed / allowed per
+call), not orders of magnitude above it, so that an indexing or accumulation slip of 1e-5 fails:
+  exact-fp32 kernels            5e-6   (measured <= 1.5e-6: fp32 rounding of K <= 192 term sums, plus expf / tanhf)
+  fused split-bf16 kernels      1e-5   (measured <= 1.6e-6: ~2^-16 per product, fp32 accumulation)
+  row-GEMM split-bf16 kernels   1e-4   (measured <= 2.7e-5: K up to 384, products summed in MFMA order)
 Index bookkeeping (row schedules) is compared bit for bit.  The reference itself holds no
 fixtures for this path: the oracle is "parity unpinned" (oracle/__init__.py)."""
 import numpy as np
@@ -12,12 +16,18 @@ import gnn_uds_amd as U
 from gnn_uds_amd import _lib
 from oracle import sparse_csr as OS
 from oracle import spektral_dense as OD
+from tests import util
 from tests.util import cast, load_spatial_layer, spatial_params
 
 pytestmark = pytest.mark.gpu
-TOL = 2e-5          # exact-fp32 kernels
-TOL_BF16X3 = 2e-4   # fused kernel: GEMM operands split into bf16 hi+lo, 3 products, fp32 accumulate (~2^-16/product)
+TOL = 5e-6          # exact-fp32 kernels
+TOL_BF16X3 = 1e-5   # fused kernels: GEMM operands split into bf16 hi+lo, 3 products, fp32 accumulate (~2^-16/product)
+TOL_ROWGEMM = 1e-4  # Dense / Conv1D on the matrix-core row GEMM (split-bf16)
 PREC_TOL = {'fp32': TOL, 'bf16x3': TOL_BF16X3}
+
+
+def close(out, ref, tol=TOL):
+    return util.close(out, ref, tol, _depth=2)
 
 
 @pytest.fixture(scope='module')
@@ -27,13 +37,6 @@ def dev():
     return torch.device('cuda', 0)
 
 
-def close(out, ref, tol=TOL):
-    out = out.detach().double().cpu()
-    err = float((out - ref).abs().max()) if ref.numel() else 0.0
-    lim = tol * max(1.0, float(ref.abs().max()) if ref.numel() else 1.0)
-    assert out.shape == ref.shape, (out.shape, ref.shape)
-    assert err <= lim, 'max abs err %.3e > %.3e' % (err, lim)
-    return err
 
 
 def rnd(gen, *shape):
@@ -170,7 +173,7 @@ def test_spatial_layer_vs_dense_masked_oracle(dev, networks, name, d, S, precisi
     rx, re = OD.spatial_layer_dense(x, e, p, torch.from_numpy(gph.adj.to_dense()), torch.from_numpy(gph.edge_adj.to_dense()), ne)
     load_spatial_layer(layer, p, dev)
     ox, oe = layer(x.float().to(dev), e.float().to(dev))
-    close(ox, rx, 5e-5); close(oe, re, 5e-5)
+    close(ox, rx, TOL); close(oe, re, TOL)
 
 
 def test_spatial_block_c1_wide_first_layer(dev):
@@ -216,7 +219,7 @@ def test_spatial_layer_c2_size_vs_sparse_oracle(dev, precision, fx, fe):
 
 def test_wide_layer_d128_matrix_core_unfused_path(dev):
     """d = 128 (the reference's default embed_size, utils/config.yaml): no fused kernel; with precision='bf16x3' the dense
-    parts run on the matrix-core row GEMM + uds_gat_aggregate.  Tolerance 2e-4 * max(1, max|ref|) as for the fused layer."""
+    parts run on the matrix-core row GEMM + uds_gat_aggregate."""
     gph = U.DrainageGraph.from_edges(U.synthetic_drainage_network(2000, 2500, 0))
     d, S = 128, 3
     p = spatial_params(2000, 2500, d, d, d, seed=5, dense_ne=False, nnz_n=gph.inc_n.nnz, nnz_e=gph.inc_e.nnz)
@@ -256,7 +259,7 @@ def test_dense_wide_outputs_column_blocks(dev):
         x, k, b = rnd(g, 3, 1500, fi) - 0.5, rnd(g, fi, fo) - 0.5, rnd(g, fo) - 0.5
         m = U.Dense(fo, act, in_features=fi, precision='bf16x3').to(dev)
         m.kernel.data, m.bias.data = k.float().to(dev), b.float().to(dev)
-        close(m(x.float().to(dev)), OD.dense(x, k, b, act), TOL_BF16X3)
+        close(m(x.float().to(dev)), OD.dense(x, k, b, act), TOL_ROWGEMM)
 
 
 @pytest.mark.parametrize('case', ['hub', 'astlingen', 'chaohu', 'tanh', 'c3'])
@@ -285,7 +288,7 @@ def test_fused_d128_kernel_cases(dev, networks, case):
     layer = load_spatial_layer(U.SpatialLayer(gph, d, act, sparse_params=True, precision='bf16x3'), p, dev)
     ox, oe = layer(x.float().to(dev), e.float().to(dev))
     assert layer.network().plan_info()['fused'] & 8             # the d = 128 tile plan exists: the fused kernel ran
-    tol = 4e-4 if case == 'c3' else TOL_BF16X3                  # c3: fp32 oracle (the fp64 one needs minutes at this size)
+    tol = 2e-5 if case == 'c3' else TOL_BF16X3                  # c3: fp32 oracle (the fp64 one needs minutes at this size)
     close(ox, rx.double(), tol); close(oe, re.double(), tol)
     ox2, oe2 = layer(x.float().to(dev), e.float().to(dev))
     assert torch.equal(ox, ox2) and torch.equal(oe, oe2)
@@ -322,7 +325,8 @@ def test_headline_size_properties(dev):
     """Full BASELINE size (10k / 12k, d=64): size-independent properties instead of the slow oracle.
     (1) snapshots are independent: running one snapshot alone gives the same bits;
     (2) two runs are bitwise identical (no atomics anywhere);
-    (3) a spot check of 64 rows against the fp64 sparse oracle on that snapshot."""
+    (3) TWO full snapshots -- one inside the first chunk of snapshots a workgroup handles, the last one of the launch --
+        against the fp64 sparse oracle (all rows of both sides)."""
     gph = U.DrainageGraph.from_edges(U.synthetic_drainage_network(10000, 12000, 0))
     d, S = 64, 9
     layer = U.SpatialLayer(gph, d, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1)).to(dev)
@@ -334,16 +338,17 @@ def test_headline_size_properties(dev):
     o3x, o3e = layer(x[3:4].contiguous(), e[3:4].contiguous())
     assert torch.equal(o3x[0], ox[3]) and torch.equal(o3e[0], oe[3])
     p = cast(layer.export_params(), torch.float64)
-    rx, re = OS.spatial_layer_csr(x[3:4].double().cpu(), e[3:4].double().cpu(), p, (gph.adj.rowptr, gph.adj.col),
+    sel = [3, S - 1]
+    rx, re = OS.spatial_layer_csr(x[sel].double().cpu(), e[sel].double().cpu(), p, (gph.adj.rowptr, gph.adj.col),
                                   (gph.edge_adj.rowptr, gph.edge_adj.col), (gph.inc_n.rowptr, gph.inc_n.col),
                                   (gph.inc_e.rowptr, gph.inc_e.col))
-    close(ox[3:4], rx, TOL_BF16X3); close(oe[3:4], re, TOL_BF16X3)
+    close(ox[sel], rx, TOL_BF16X3); close(oe[sel], re, TOL_BF16X3)
     assert bool(torch.isfinite(ox).all()) and bool((ox >= 0).all())
     # (4) the fused split-bf16 kernel and the exact-fp32 unfused kernels agree on the FULL tensors
     exact = U.SpatialLayer(gph, d, 'relu', sparse_params=True, precision='fp32').to(dev)
     exact.load_state_dict(layer.state_dict())
     fx_, fe_ = exact(x, e)
-    close(fx_[3:4], rx); close(fe_[3:4], re)
+    close(fx_[sel], rx); close(fe_[sel], re)
     assert float((fx_ - ox).abs().max()) <= TOL_BF16X3 * max(1.0, float(fx_.abs().max()))
     assert float((fe_ - oe).abs().max()) <= TOL_BF16X3 * max(1.0, float(fe_.abs().max()))
 
@@ -382,10 +387,11 @@ def test_c3_size_properties(dev):
     o1x, o1e = layer(x[1:2].contiguous(), e[1:2].contiguous())
     assert torch.equal(o1x[0], ox[1]) and torch.equal(o1e[0], oe[1])          # snapshots independent
     p = cast(layer.export_params(), torch.float64)
-    rx, re = OS.spatial_layer_csr(x[1:2].double().cpu(), e[1:2].double().cpu(), p, (gph.adj.rowptr, gph.adj.col),
+    sel = [1, S - 1]
+    rx, re = OS.spatial_layer_csr(x[sel].double().cpu(), e[sel].double().cpu(), p, (gph.adj.rowptr, gph.adj.col),
                                   (gph.edge_adj.rowptr, gph.edge_adj.col), (gph.inc_n.rowptr, gph.inc_n.col),
                                   (gph.inc_e.rowptr, gph.inc_e.col))
-    close(ox[1:2], rx, TOL_BF16X3); close(oe[1:2], re, TOL_BF16X3)
+    close(ox[sel], rx, TOL_BF16X3); close(oe[sel], re, TOL_BF16X3)      # two full snapshots against the fp64 oracle
 
 
 def test_cpu_tensors_are_refused(dev):

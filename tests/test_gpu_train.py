@@ -4,11 +4,15 @@ parameters, and the parameters after Adam steps.  The oracle is "parity unpinned
 holds no gradients or trained weights to pin it.
 
 Stated tolerances (relative to max(1, max|reference tensor|) unless said otherwise):
-  exact-fp32 kernels ('fp32')         2e-5 per operator
-  split-bf16 MFMA kernels ('bf16x3')  2e-4 per operator
-  whole-model gradients               1e-2 * max|grad of that tensor| + 1e-10 * max|grad of any tensor| (measured: <= 5e-3;
-                                      first-layer gradients are cancelling sums through up to 12 split-bf16 GEMMs)
+  exact-fp32 kernels ('fp32')         5e-6 per operator   (measured <= 4e-7)
+  split-bf16 MFMA kernels ('bf16x3')  4e-5 per operator   (measured <= 2.2e-5)
+  whole-model gradients               GRAD_TOL * max|grad of that tensor| + 1e-7 * max|grad of any tensor|: 1e-3 for the GAT models
+                                      (measured <= 4e-4), 5e-3 for conv = GCN (measured <= 2.3e-3: the NodeEdge / Dense gradients there
+                                      are 1e-6 of the largest gradient, i.e. at the split-bf16 noise floor of the sums they come from)
+(UDS_TOL_REPORT=1 prints observed / allowed for every check.)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -20,9 +24,10 @@ from oracle import emulator_ref as OE
 from oracle import sparse_csr as OS
 from oracle import spektral_dense as OD
 from oracle import train_ref as OT
-from tests.util import emulator_args, emulator_norms, emulator_param_pairs, load_emulator
+from tests.util import close, emulator_args, emulator_norms, emulator_param_pairs, load_emulator
 
 pytestmark = pytest.mark.gpu
+GRAD_TOL = {'GAT': 1e-3, 'GCN': 5e-3}      # whole-model gradients, relative to the tensor's largest gradient
 
 
 @pytest.fixture(scope='module')
@@ -32,12 +37,6 @@ def dev():
     return torch.device('cuda', 0)
 
 
-def close(out, ref, tol):
-    out = out.detach().double().cpu()
-    assert out.shape == ref.shape, (out.shape, ref.shape)
-    err = float((out - ref).abs().max()) if ref.numel() else 0.0
-    lim = tol * max(1.0, float(ref.abs().max()) if ref.numel() else 1.0)
-    assert err <= lim, 'max abs err %.3e > %.3e' % (err, lim)
 
 
 def rnd(g, *shape):
@@ -70,7 +69,7 @@ def test_dense_backward(dev, rows, fi, fo, act, prec):
     xd, kd, bd = dev_leaf(x, dev), dev_leaf(k, dev), dev_leaf(b, dev)
     m = _Mod(precision=prec, units=fo, kernel=kd)
     (AG.DenseFn.apply(xd, kd, bd, m, act) * gy.float().to(dev)).sum().backward()
-    tol = 2e-5 if prec == 'fp32' else 2e-4
+    tol = 5e-6 if prec == 'fp32' else 4e-5
     close(xd.grad, xr.grad, tol)
     close(kd.grad, kr.grad, tol)
     close(bd.grad, br.grad, tol)
@@ -80,12 +79,12 @@ def test_dense_backward(dev, rows, fi, fo, act, prec):
                                                   (1, 1, 4000, 128, 64, 0, False), (2, 9, 40, 64, 64, 2, False), (1, 5, 33, 64, 3, 4, True),
                                                   (1, 1, 31, 1, 32, 0, True), (1, 3, 20000, 32, 16, 1, True)])
 def test_wgrad_kernel(dev, B, T, R, F, H, shift, bias):
-    """Split-K MFMA weight gradient (split-bf16, 3 products): 2e-4 * max(1, max|ref|) * sqrt(rows / 1000) (fp32 sums over rows)."""
+    """Split-K MFMA weight gradient (split-bf16, 3 products): 4e-5 * max(1, max|ref|) * sqrt(rows / 1000) (fp32 sums over rows)."""
     g = torch.Generator().manual_seed(R + F)
     a, gz = rnd(g, B, T, R, F) - 0.5, rnd(g, B, T, R, H) - 0.5
     ref = a[:, :T - shift].reshape(-1, F).t() @ gz[:, shift:].reshape(-1, H) if shift < T else torch.zeros(F, H, dtype=torch.float64)
     dk, db = _lib.wgrad(a.float().to(dev), gz.float().to(dev), shift, bias)
-    tol = 2e-4 * max(1.0, (B * T * R / 1000) ** 0.5)
+    tol = 4e-5 * max(1.0, (B * T * R / 1000) ** 0.5)
     close(dk, ref, tol)
     if bias:
         close(db, gz.reshape(-1, H).sum(0), tol)
@@ -107,7 +106,7 @@ def test_conv1d_backward(dev, B, T, R, F, H, dil, act, prec):
     xd, kd, bd = dev_leaf(x, dev), dev_leaf(k, dev), dev_leaf(b, dev)
     m = _Mod(precision=prec, activation=act, dilation_rate=dil, kernel=kd)
     (AG.Conv1DFn.apply(xd, kd, bd, m) * gy.float().to(dev)).sum().backward()
-    tol = 2e-5 if prec == 'fp32' else 2e-4
+    tol = 5e-6 if prec == 'fp32' else 4e-5
     close(xd.grad, xr.grad, tol)
     close(kd.grad, kr.grad, tol * (10 if R > 1000 else 1))       # sums over B*T*R rows
     close(bd.grad, br.grad, tol * (10 if R > 1000 else 1))
@@ -136,7 +135,7 @@ def test_gat_backward(dev, networks, name, d, fb, act):
         out = AG.GatFn.apply(dv[0], dv[5] if fb else None, dv[1], dv[2], dv[3], dv[4], act, h, 'fp32')
         (out * gy.float().to(dev)).sum().backward()
         for got, ref in zip(dv, ref_in):
-            close(got.grad, ref.grad, 5e-5)
+            close(got.grad, ref.grad, 1e-5)
 
 
 def test_gat_backward_transposed_pattern_directed(dev):
@@ -156,7 +155,7 @@ def test_gat_backward_transposed_pattern_directed(dev):
     assert ht.n_rows == 4 and perm.cpu().tolist() == [0, 3, 2, 4, 1, 5, 6]       # column-major walk of the entries
     (AG.GatFn.apply(dv[0], None, dv[1], dv[2], dv[3], dv[4], 'relu', h, 'fp32') * gy.float().to(dev)).sum().backward()
     for got, ref in zip(dv, ref_in):
-        close(got.grad, ref.grad, 5e-5)
+        close(got.grad, ref.grad, 1e-5)
 
 
 @pytest.mark.parametrize('name,F', [('chaohu', 32), ('hague', 8)])
@@ -172,8 +171,8 @@ def test_spmm_backward_and_sddmm(dev, networks, name, F):
         vd, xd = dev_leaf(val, dev), dev_leaf(x, dev)
         h = _lib.CsrHandle(csr)
         (AG.SpmmFn.apply(vd, xd, h) * gy.float().to(dev)).sum().backward()
-        close(xd.grad, xr.grad, 2e-5)
-        close(vd.grad, vr.grad, 2e-5)
+        close(xd.grad, xr.grad, 5e-6)
+        close(vd.grad, vr.grad, 5e-6)
 
 
 def test_cumsum_and_flow_balance_backward(dev, networks):
@@ -183,8 +182,8 @@ def test_cumsum_and_flow_balance_backward(dev, networks):
     (torch.relu(torch.cumsum(xr, 1) + rr) * gy).sum().backward()
     xd, rd = dev_leaf(x, dev), dev_leaf(res, dev)
     (AG.CumsumActFn.apply(xd, rd, 'relu') * gy.float().to(dev)).sum().backward()
-    close(xd.grad, xr.grad, 1e-5)
-    close(rd.grad, rr.grad, 1e-5)
+    close(xd.grad, xr.grad, 2e-6)
+    close(rd.grad, rr.grad, 2e-6)
 
     net = networks['chaohu']
     edges = np.array(net['edges'])
@@ -203,7 +202,7 @@ def test_cumsum_and_flow_balance_backward(dev, networks):
     qi, qo = AG.FlowBalanceFn.apply(fd, _lib.CsrHandle(gph.inc_n), f32(torch.as_tensor(gph.inc_n.val)), f32(s_in), f32(s_out),
                                     torch.as_tensor(edges, dtype=torch.int64, device=dev))
     ((qi * f32(g_in)).sum() + (qo * f32(g_out)).sum()).backward()
-    close(fd.grad, fr.grad, 1e-5)
+    close(fd.grad, fr.grad, 2e-6)
 
 
 def _problem(networks, name, dev, seed=3, B=2, **over):
@@ -243,7 +242,7 @@ def test_emulator_gradients(dev, networks, name, over):
     lw = emul._loss_setup(dev)
     ls = [emul.get_node_loss(yd, bd, preds)] + ([emul.get_flood_loss(yd, preds)] if emul.if_flood else []) + [emul._mse(eyd, edge_preds, lw['ewei'])]
     for got, ref in zip(ls, ref_losses):
-        close(got, ref, 5e-4)
+        close(got, ref, 2e-5)
     sum(ls).backward()
     n_checked = 0
     gmax = max(float(t.abs().max()) for t in ref_grads.values())
@@ -256,7 +255,10 @@ def test_emulator_gradients(dev, networks, name, over):
         # relative to the tensor's own largest gradient; the absolute floor (fp32 epsilon of the LARGEST gradient of the model)
         # matters for attn_kernel_self, whose gradient is ~1e-24 (softmax is shift-invariant in s_self: exactly zero where
         # leaky_relu is linear), and for the NodeEdge weights under GCN (1e-6 of the largest gradient: split-bf16 noise)
-        assert err <= 1e-2 * scale + 1e-7 * gmax, '%s: grad err %.3e vs max|grad| %.3e' % (pname, err, scale)
+        if os.environ.get('UDS_TOL_REPORT'):
+            from tests.util import OBSERVED
+            OBSERVED.append((os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0] + ':' + pname, 0, err, GRAD_TOL[args.conv] * scale + 1e-7 * gmax))
+        assert err <= GRAD_TOL[args.conv] * scale + 1e-7 * gmax, '%s: grad err %.3e vs max|grad| %.3e' % (pname, err, scale)
         n_checked += 1
     assert n_checked == len(list(emul.parameters()))
 
@@ -350,8 +352,11 @@ def test_mpc_objective_and_gradient(dev, networks, chunks):
     tgd = {k: (v.to(dev) if v.dtype == torch.int64 else f(v)) for k, v in tg.items()}
     obj, grad = M.objective_and_gradient(emul, f(y), f(state), f(runoff), f(edge_state), n_step, n_act, r_step, tgd, f(gamma))
     assert tuple(obj.shape) == (pop,) and tuple(grad.shape) == tuple(y.shape)
-    close(obj, ref.detach(), 5e-4)
+    close(obj, ref.detach(), 2e-5)
     gmax = float(gref.abs().max())
     assert gmax > 0
     err = float((grad.double().cpu() - gref).abs().max())
-    assert err <= 1e-2 * gmax, 'gradient err %.3e vs max|grad| %.3e' % (err, gmax)
+    if os.environ.get('UDS_TOL_REPORT'):
+        from tests.util import OBSERVED
+        OBSERVED.append((os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0] + ':gradient', 0, err, 2e-3 * gmax))
+    assert err <= 2e-3 * gmax, 'gradient err %.3e vs max|grad| %.3e' % (err, gmax)

@@ -1,6 +1,27 @@
 """Shared helpers for the tests: seeded parameters in the oracle's (Keras-shaped) format."""
+import inspect
+import os
+
 import numpy as np
 import torch
+
+# (test name, observed max abs error, allowed) of every close() call of the session: tests/conftest.py prints the largest
+# observed / allowed ratios when UDS_TOL_REPORT is set, so that tolerances can be kept a stated factor above what the
+# kernels actually achieve instead of orders of magnitude above it
+OBSERVED = []
+
+
+def close(out, ref, tol, _depth=1):
+    """max|out - ref| <= tol * max(1, max|ref|); returns the observed error."""
+    out = out.detach().double().cpu()
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    err = float((out - ref).abs().max()) if ref.numel() else 0.0
+    lim = tol * max(1.0, float(ref.abs().max()) if ref.numel() else 1.0)
+    if os.environ.get('UDS_TOL_REPORT'):
+        fr = inspect.stack()[_depth]
+        OBSERVED.append((os.environ.get('PYTEST_CURRENT_TEST', fr.function).split(' ')[0], fr.lineno, err, lim))
+    assert err <= lim, 'max abs err %.3e > %.3e' % (err, lim)
+    return err
 
 
 def glorot(gen, shape, dtype):

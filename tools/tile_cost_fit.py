@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gnn_uds_amd as U
 from gnn_uds_amd import _lib
 
-assert not os.environ.get('UDS_SCHED') and os.environ.get('UDS_CHUNK') == '60'
+assert os.environ.get('UDS_CHUNK') == '60'      # (a library built with UDS_DEFINES='-DUDS_KNOBS -DUDS_PHASE_TIMING')
 dev = torch.device('cuda', 0)
 g = U.DrainageGraph.from_edges(U.synthetic_drainage_network(10000, 12000, 0))
 S = 60
