@@ -65,6 +65,19 @@ class KerasAdam:
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
 
+    def state_dict(self):
+        """Iteration count + first / second moments (what `optimizer.get_weights()` holds in Keras, emulator.py:826)."""
+        return {'t': self.t, 'm': [t.detach().cpu() for t in self.m], 'v': [t.detach().cpu() for t in self.v]}
+
+    def load_state_dict(self, sd):
+        if len(sd['m']) != len(self.params) or any(tuple(a.shape) != tuple(p.shape) for a, p in zip(sd['m'], self.params)):
+            raise ValueError('optimizer state does not match the model parameters')
+        self.t = int(sd['t'])
+        for dst, src in zip(self.m, sd['m']):
+            dst.copy_(src)
+        for dst, src in zip(self.v, sd['v']):
+            dst.copy_(src)
+
     @torch.no_grad()
     def step(self):
         self.t += 1
@@ -819,16 +832,48 @@ class Emulator(nn.Module):
 
     # ------------------------------------------------------------------ checkpoints (:814-852)
     def save(self, model_dir=None):
+        """emulator.py:814-831: weights, the five normalisers, the optimizer state (`optim.npy` there, `optim.pt` here) and,
+        with GradNorm, the task weights and THEIR optimizer (`gradnorm.ckpt` there, `gradnorm.pt` here).  A path ending in
+        `.pt` names the weight file itself, as `.h5` does in the reference."""
         model_dir = model_dir if model_dir is not None else self.model_dir
-        os.makedirs(model_dir, exist_ok=True)
-        torch.save(self.state_dict(), os.path.join(model_dir, 'model.pt'))
+        if model_dir.endswith('.pt'):
+            weights, model_dir = model_dir, os.path.dirname(model_dir)
+        else:
+            weights = os.path.join(model_dir, 'model.pt')
+        os.makedirs(model_dir or '.', exist_ok=True)
+        torch.save(self.state_dict(), weights)
         for item, t in self._norms.items():
             np.save(os.path.join(model_dir, 'norm_%s.npy' % item), t.cpu().numpy())
+        if self._optimizer is not None:
+            torch.save(self._optimizer.state_dict(), os.path.join(model_dir, 'optim.pt'))
+        if self.gradnorm and getattr(self, '_alpha', None) is not None:
+            torch.save({'alpha': self._alpha.detach().cpu(), 'optimizer': self._alpha_optimizer.state_dict()}, os.path.join(model_dir, 'gradnorm.pt'))
 
     def load(self, model_dir=None, retrain=False):
+        """emulator.py:833-852; `retrain=True` also restores the optimizer moments / step count and the GradNorm state, so
+        that training resumes where it stopped (`--load_model`, main.py:199-205)."""
         model_dir = model_dir if model_dir is not None else self.model_dir
-        self.load_state_dict(torch.load(os.path.join(model_dir, 'model.pt'), weights_only=True))
+        if model_dir.endswith('.h5'):
+            raise NotImplementedError('Keras HDF5 weights: convert with Emulator.load_keras_weights (h5py is not available here)')
+        if model_dir.endswith('.pt'):
+            weights, model_dir = model_dir, os.path.dirname(model_dir)
+        else:
+            weights = os.path.join(model_dir, 'model.pt')
+        self.load_state_dict(torch.load(weights, weights_only=True))
         for item in 'xbyre':
             path = os.path.join(model_dir, 'norm_%s.npy' % item)
             if os.path.exists(path):
                 self._norms[item] = torch.as_tensor(np.load(path), dtype=torch.float32)
+        dev = next(self.parameters()).device
+        path = os.path.join(model_dir, 'optim.pt')
+        if retrain and os.path.exists(path):
+            if self._optimizer is None:
+                self._optimizer = KerasAdam([p for p in self.parameters()], self.learning_rate, clipnorm=1.0)
+            self._optimizer.load_state_dict(torch.load(path, weights_only=True))
+        path = os.path.join(model_dir, 'gradnorm.pt')
+        if retrain and self.gradnorm and os.path.exists(path):
+            sd = torch.load(path, weights_only=True)
+            alpha = self._alphas(dev)
+            with torch.no_grad():
+                alpha.copy_(sd['alpha'])
+            self._alpha_optimizer.load_state_dict(sd['optimizer'])

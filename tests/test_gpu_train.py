@@ -304,6 +304,42 @@ def test_grad_norm_task_weights_match_the_oracle(dev, networks):
     assert len(ls) == 3 and all(np.isfinite(float(v)) for v in ls)
 
 
+def test_save_load_retrain_resumes_training(dev, networks, tmp_path):
+    """`save` / `load(retrain=True)` (emulator.py:814-852) keep the optimizer moments + step count and the GradNorm task
+    weights with their optimizer: two steps, save, two more -- against two steps, save, load into a FRESH emulator, two
+    more.  The resumed run must retrace the uninterrupted one (same kernels, same inputs: the same numbers); without the
+    optimizer state it would restart Adam's bias correction and differ in the first digit."""
+    over = dict(embed_size=64, n_sp_layer=1, learning_rate=1e-3, gradnorm=True)
+    args, norms, params, emul, cpu_in, dev_in = _problem(networks, 'astlingen', dev, **over)
+    ini = [float(l) for l in emul.fit_eval(*dev_in, fit=False)]
+    for _ in range(2):
+        emul.fit_eval(*dev_in)
+        emul.fit_grad_norm(*dev_in, ini)
+    emul.save(str(tmp_path))
+    for name in ('model.pt', 'optim.pt', 'gradnorm.pt', 'norm_x.npy', 'norm_e.npy'):
+        assert (tmp_path / name).exists(), name
+    cont = []
+    for _ in range(2):
+        cont.append([float(l) for l in emul.fit_eval(*dev_in)])
+        emul.fit_grad_norm(*dev_in, ini)
+    _, _, _, fresh, _, _ = _problem(networks, 'astlingen', dev, **over)
+    fresh.load(str(tmp_path), retrain=True)
+    assert fresh._optimizer.t == 2 and fresh._alpha_optimizer.t == 2
+    resumed = []
+    for _ in range(2):
+        resumed.append([float(l) for l in fresh.fit_eval(*dev_in)])
+        fresh.fit_grad_norm(*dev_in, ini)
+    assert np.allclose(resumed, cont, rtol=1e-6, atol=1e-9), (resumed, cont)
+    for (n1, p1), (n2, p2) in zip(emul.named_parameters(), fresh.named_parameters()):
+        assert torch.allclose(p1, p2, rtol=0, atol=1e-7), n1
+    assert torch.allclose(emul._alphas(dev), fresh._alphas(dev), rtol=0, atol=1e-7)
+    cold = _problem(networks, 'astlingen', dev, **over)[3]
+    cold.load(str(tmp_path))                                     # weights and norms only: a fresh optimizer
+    assert cold._optimizer is None
+    with pytest.raises(NotImplementedError):
+        cold.load(str(tmp_path / 'model.h5'))
+
+
 def test_fit_eval_reduces_the_loss(dev, networks):
     args, norms, params, emul, cpu_in, dev_in = _problem(networks, 'hague', dev, n_sp_layer=2, learning_rate=2e-3)
     first = sum(float(v) for v in emul.fit_eval(*dev_in))
