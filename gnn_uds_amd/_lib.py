@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # UDS_LIB_PATH: a differently built copy of the same library (kernel experiments: tools/variant_bench.py)
 LIB_PATH = os.environ.get('UDS_LIB_PATH') or os.path.join(_HERE, 'libuds_hip.so')
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
 PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
 
@@ -40,6 +40,10 @@ SYMBOLS = {
                                    _c_ptr]),
     'uds_rowgemm_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
     'uds_rowgemm_pack': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
+    'uds_remainder_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
+    'uds_remainder_pack': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
+    'uds_remainder_workspace_bytes': (_c_i64, [_c_i64, _c_i64, _c_i64]),
+    'uds_remainder_forward': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr]),
     'uds_rowgemm_forward': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_rowgemm_forward_cat': (_c_int, [_c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int,
                                          _c_ptr, _c_i64, _c_i64, _c_ptr]),
@@ -336,6 +340,36 @@ def rowgemm_pack(kernel2d):
         raise UdsError('rowgemm_pack: unsupported shape %r' % ((K, fo),))
     out = torch.empty(nbytes // 4, device=kernel2d.device, dtype=torch.float32)
     _check(lib.uds_rowgemm_pack(_dev(kernel2d, 'kernel'), K, fo, out.data_ptr(), _stream()), 'uds_rowgemm_pack')
+    return out
+
+
+def remainder_pack(rest):
+    """Pre-split the dense off-support part `rest` (R, M) of a trained NodeEdge into bf16 hi/lo planes (once per update)."""
+    lib = load()
+    if rest.dim() != 2 or rest.numel() == 0:
+        raise UdsError('remainder_pack: rest %r' % (tuple(rest.shape),))
+    R, M = rest.shape
+    out = torch.empty(lib.uds_remainder_packed_bytes(R, M) // 4, device=rest.device, dtype=torch.float32)
+    _check(lib.uds_remainder_pack(_dev(rest, 'rest'), R, M, out.data_ptr(), _stream()), 'uds_remainder_pack')
+    return out
+
+
+def remainder_forward(packed, shape, x):
+    """out[..., r, :] = sum_m rest[r, m] x[..., m, :] on the matrix cores (split-bf16): `packed` = remainder_pack(rest),
+    shape = rest.shape, x (..., M, h) with h % 4 == 0, h <= 64."""
+    lib = load()
+    R, M = shape
+    if x.dim() < 2 or x.shape[-2] != M:
+        raise UdsError('remainder_forward: x %r against rest (%d, %d)' % (tuple(x.shape), R, M))
+    h = x.shape[-1]
+    S = x.numel() // (M * h) if M * h else 0
+    out = torch.empty(tuple(x.shape[:-2]) + (R, h), device=x.device, dtype=torch.float32)
+    if S == 0:
+        _dev(x, 'x')
+        return out
+    ws = torch.empty(lib.uds_remainder_workspace_bytes(M, S, h) // 4, device=x.device, dtype=torch.float32)
+    _check(lib.uds_remainder_forward(packed.data_ptr(), R, M, _dev(x, 'x'), S, h, ws.data_ptr(), _dev(out, 'out'), _stream()),
+           'uds_remainder_forward')
     return out
 
 

@@ -1,0 +1,151 @@
+// Dense remainder of a trained NodeEdge layer (gfx950).
+//
+// The reference's NodeEdge is `(w * inci + b) @ x` with w and b DENSE trainable (R x M) matrices (emulator.py:34-45).  On
+// the incidence support the product is the fused kernel's CSR aggregation; a trained bias is non-zero everywhere else
+// too, and that part -- `rest @ x`, rest = b with the support zeroed -- is a true dense GEMM:
+//     rem[s][r][f] = sum_m rest[r][m] * x[s][m][f]          R x M  times  M x (S * h)
+// (R, M = nodes / links, h = d/2 = 32 features, S snapshots: 2 * R * M * S * h flops, 0.46 TFLOP per side at the headline
+// sizes -- ten times the rest of the layer; the reference pays it on every layer, trained or not).
+//
+// Here: split-bf16 MFMA as everywhere else (operands a = hi + lo in bf16, hi*hi + lo*hi + hi*lo accumulated in fp32, ~2^-16
+// per product).  `rest` is split ONCE per parameter update (k_split_rows_bf16: hi and lo planes, K padded to 32); the
+// activations are split and TRANSPOSED per call into (S*h) x M planes (k_split_transpose_bf16), so that both MFMA operands
+// read 8 consecutive k for one row / one column with one 16-byte load.  Kernel: 128 x 128 output tile per 256-thread
+// workgroup (4 waves, 64 x 64 each), k-steps of 32 through a double-buffered LDS image (80-byte rows: conflict-free
+// ds_read_b128), the next k-step's global loads in flight while the current one is multiplied, one barrier per step.  The
+// activations are the MFMA A operand, so that a lane ends up with 4 consecutive features of one output row (16-byte stores
+// into (S, R, h)).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels_fused.hpp"
+
+namespace uds {
+
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32, GEMM_LDS_ROW = 40;      // LDS row stride in bf16 (80 bytes)
+
+// fp32 (rows x K) -> bf16 hi / lo planes (rows x Kp), Kp = K rounded up to 32, zero padded
+__global__ void k_split_rows_bf16(const float *__restrict__ a, int64_t rows, int64_t K, int64_t Kp, __bf16 *__restrict__ hi,
+                                  __bf16 *__restrict__ lo) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per 8 consecutive k
+  const int64_t per_row = Kp / 8;
+  if (i >= rows * per_row) return;
+  const int64_t r = i / per_row, k0 = (i - r * per_row) * 8;
+  bf16x8 h, l;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = k0 + j < K ? a[r * K + k0 + j] : 0.f;
+    const __bf16 hh = (__bf16)v;
+    h[j] = hh;
+    l[j] = (__bf16)(v - (float)hh);
+  }
+  *reinterpret_cast<bf16x8 *>(hi + r * Kp + k0) = h;
+  *reinterpret_cast<bf16x8 *>(lo + r * Kp + k0) = l;
+}
+
+// x (S, M, h) fp32 -> bf16 hi / lo planes (S * h) x Mp with row (s, f) = x[s][:, f] (transposed), zero padded to Mp.
+// One workgroup per (s, 64 values of m): reads 64 x h floats coalesced, writes h runs of 64 bf16 (128 bytes).
+__global__ __launch_bounds__(256) void k_split_transpose_bf16(const float *__restrict__ x, int64_t M, int h, int64_t Mp,
+                                                              __bf16 *__restrict__ hi, __bf16 *__restrict__ lo) {
+  __shared__ float tile[64][65];      // h <= 64
+  const int64_t s = blockIdx.y, m0 = (int64_t)blockIdx.x * 64;
+  const float *src = x + (s * M + m0) * h;
+  for (int i = threadIdx.x; i < 64 * h; i += 256) {
+    const int m = i / h, f = i - m * h;
+    tile[m][f] = m0 + m < M ? src[(int64_t)m * h + f] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * h; i += 256) {
+    const int f = i / 64, m = i - f * 64;
+    if (m0 + m >= Mp) continue;
+    const float v = tile[m][f];
+    const __bf16 hh = (__bf16)v;
+    hi[(s * h + f) * Mp + m0 + m] = hh;
+    lo[(s * h + f) * Mp + m0 + m] = (__bf16)(v - (float)hh);
+  }
+}
+
+// out[s][r][f] = sum_k X[(s, f)][k] * W[r][k]:  X = transposed activations (Nc x Kp, Nc = S * h), W = rest (R x Kp), both
+// as hi / lo bf16 planes.  grid = (ceil(Nc / 128), ceil(R / 128)).
+__global__ __launch_bounds__(256, 2) void k_remainder_gemm(const __bf16 *__restrict__ Xh, const __bf16 *__restrict__ Xl,
+                                                          const __bf16 *__restrict__ Wh, const __bf16 *__restrict__ Wl, int64_t Nc, int64_t R,
+                                                          int64_t Kp, int h, float *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2][4][GEMM_BM * GEMM_LDS_ROW];      // [buffer][Xh, Xl, Wh, Wl][128 rows x 40]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;                   // wave tile: X rows (columns of the result) 64 wr.., W rows 64 wc..
+  const int64_t c0 = (int64_t)blockIdx.x * GEMM_BM, r0 = (int64_t)blockIdx.y * GEMM_BN;
+  // global -> register staging: the 128 x 32 bf16 tile of a plane is 512 16-byte chunks, two per thread
+  const int ch_row0 = tid >> 2, ch_k = (tid & 3) * 8;       // chunk rows tid/4 and tid/4 + 64, 8 bf16 at k offset ch_k
+  const int64_t xrow0 = min(c0 + ch_row0, Nc - 1), xrow1 = min(c0 + ch_row0 + 64, Nc - 1);      // rows past the matrix are clamped
+  const int64_t wrow0 = min(r0 + ch_row0, R - 1), wrow1 = min(r0 + ch_row0 + 64, R - 1);        // (their results are not stored)
+  const __bf16 *pxh0 = Xh + xrow0 * Kp + ch_k, *pxh1 = Xh + xrow1 * Kp + ch_k, *pxl0 = Xl + xrow0 * Kp + ch_k, *pxl1 = Xl + xrow1 * Kp + ch_k;
+  const __bf16 *pwh0 = Wh + wrow0 * Kp + ch_k, *pwh1 = Wh + wrow1 * Kp + ch_k, *pwl0 = Wl + wrow0 * Kp + ch_k, *pwl1 = Wl + wrow1 * Kp + ch_k;
+  uint4 g0, g1, g2, g3, g4, g5, g6, g7;
+  const int lo0 = ch_row0 * GEMM_LDS_ROW + ch_k, lo1 = lo0 + 64 * GEMM_LDS_ROW;
+#define UDS_GEMM_LOAD(k0)                                   \
+  g0 = *reinterpret_cast<const uint4 *>(pxh0 + (k0));       \
+  g1 = *reinterpret_cast<const uint4 *>(pxh1 + (k0));       \
+  g2 = *reinterpret_cast<const uint4 *>(pxl0 + (k0));       \
+  g3 = *reinterpret_cast<const uint4 *>(pxl1 + (k0));       \
+  g4 = *reinterpret_cast<const uint4 *>(pwh0 + (k0));       \
+  g5 = *reinterpret_cast<const uint4 *>(pwh1 + (k0));       \
+  g6 = *reinterpret_cast<const uint4 *>(pwl0 + (k0));       \
+  g7 = *reinterpret_cast<const uint4 *>(pwl1 + (k0));
+#define UDS_GEMM_STORE(buf)                                 \
+  *reinterpret_cast<uint4 *>(&lds[buf][0][lo0]) = g0;       \
+  *reinterpret_cast<uint4 *>(&lds[buf][0][lo1]) = g1;       \
+  *reinterpret_cast<uint4 *>(&lds[buf][1][lo0]) = g2;       \
+  *reinterpret_cast<uint4 *>(&lds[buf][1][lo1]) = g3;       \
+  *reinterpret_cast<uint4 *>(&lds[buf][2][lo0]) = g4;       \
+  *reinterpret_cast<uint4 *>(&lds[buf][2][lo1]) = g5;       \
+  *reinterpret_cast<uint4 *>(&lds[buf][3][lo0]) = g6;       \
+  *reinterpret_cast<uint4 *>(&lds[buf][3][lo1]) = g7;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fk = (lane >> 4) * 8;            // fragment: row / column lane&15, 8 consecutive k at 8 * (lane >> 4)
+  UDS_GEMM_LOAD(0)
+  UDS_GEMM_STORE(0)
+  __syncthreads();
+  const int64_t n_k = Kp / GEMM_BK;
+  for (int64_t kt = 0; kt < n_k; ++kt) {
+    const int buf = (int)(kt & 1);
+    if (kt + 1 < n_k) { UDS_GEMM_LOAD((kt + 1) * GEMM_BK) }      // in flight while this step is multiplied
+    bf16x8 xh[4], xl[4], wh[4], wl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int xo = (wr * 64 + i * 16 + fr) * GEMM_LDS_ROW + fk, wo = (wc * 64 + i * 16 + fr) * GEMM_LDS_ROW + fk;
+      xh[i] = *reinterpret_cast<const bf16x8 *>(&lds[buf][0][xo]);
+      xl[i] = *reinterpret_cast<const bf16x8 *>(&lds[buf][1][xo]);
+      wh[i] = *reinterpret_cast<const bf16x8 *>(&lds[buf][2][wo]);
+      wl[i] = *reinterpret_cast<const bf16x8 *>(&lds[buf][3][wo]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma3(xh[i], xl[i], wh[j], wl[j], acc[i][j]);
+    if (kt + 1 < n_k) { UDS_GEMM_STORE(buf ^ 1) }
+    __syncthreads();
+  }
+  // D[row = 4 (lane >> 4) + q][col = lane & 15] of tile (i, j): result column c = c0 + 64 wr + 16 i + 4 (lane >> 4) + q
+  // (= snapshot c / h, feature c % h), result row r = r0 + 64 wc + 16 j + (lane & 15): four consecutive features per lane
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t c = c0 + wr * 64 + i * 16 + (lane >> 4) * 4;
+    if (c >= Nc) continue;
+    const int64_t s = c / h, f = c - s * h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t r = r0 + wc * 64 + j * 16 + (lane & 15);
+      if (r < R) *reinterpret_cast<f32x4 *>(out + (s * R + r) * h + f) = acc[i][j];
+    }
+  }
+}
+
+#undef UDS_GEMM_LOAD
+#undef UDS_GEMM_STORE
+
+}  // namespace uds

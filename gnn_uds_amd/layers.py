@@ -296,6 +296,8 @@ class NodeEdge(nn.Module):
         self.bias = _param(torch.zeros(shape, device=device))
         self._handle = None
         self._val_cache = None
+        self._rest_packed = None
+        self.precision = 'bf16x3'      # of the dense remainder GEMM; SpatialLayer sets it to its own
 
     def support_values(self):
         """weight*inci + bias on the support (nnz,), plus the off-support remainder of bias or None."""
@@ -312,7 +314,21 @@ class NodeEdge(nn.Module):
             if not bool((rest != 0).any()):
                 rest = None
         self._val_cache = (key, val.contiguous(), rest)
+        self._rest_packed = None
         return self._val_cache[1], rest
+
+    def remainder(self, xs, precision='bf16x3'):
+        """`rest @ xs`, rest = the trained bias off the incidence support (emulator.py:36-39,44): the dense GEMM on the
+        matrix cores (uds_remainder_forward; `rest` is split into bf16 hi/lo once per parameter update), exact fp32 through
+        rocBLAS when precision='fp32'.  None when the bias is zero off the support."""
+        rest = self.support_values()[1]
+        if rest is None:
+            return None
+        if precision != 'bf16x3' or xs.shape[-1] % 4 or xs.shape[-1] > 64:
+            return torch.matmul(rest, xs)
+        if self._rest_packed is None:
+            self._rest_packed = _lib.remainder_pack(rest)
+        return _lib.remainder_forward(self._rest_packed, tuple(rest.shape), xs)
 
     def handle(self):
         if self._handle is None:
@@ -342,7 +358,7 @@ class NodeEdge(nn.Module):
         val, rest = self.support_values()
         out = _lib.csr_spmm(self.handle(), val, xs)
         if rest is not None:
-            out = out + torch.matmul(rest, xs)
+            out = out + self.remainder(xs, self.precision)
         return out.reshape(lead + out.shape[-2:])
 
 
@@ -384,6 +400,7 @@ class SpatialLayer(nn.Module):
         abs_e = CSR(graph.inc_e.rowptr, graph.inc_e.col, graph.n_edge, graph.n_node, np.abs(graph.inc_e.val))
         self.node_edge_n = NodeEdge(abs_n, sparse=sparse_params, generator=g)           # emulator.py:227
         self.node_edge_e = NodeEdge(abs_e, sparse=sparse_params, generator=g)           # emulator.py:228
+        self.node_edge_n.precision = self.node_edge_e.precision = precision
         if conv == 'GAT':
             self.gat_x = GATConv(self.d, activation=activation, in_channels=fx + self.h, generator=g)   # :229
             self.gat_e = GATConv(self.d, activation=activation, in_channels=fe + self.h, generator=g)   # :230
@@ -393,13 +410,25 @@ class SpatialLayer(nn.Module):
             self.gcn_e = GCNConv(self.d, activation=activation, in_channels=fe + self.h, generator=g)
         self._net = net
         self._packed = None       # (parameter versions, packed bf16 hi/lo fragments) of the four GEMM kernels
+        self.last_path = None     # which kernels the last forward ran: 'fused', 'fused+remainder', 'unfused' (tests, bench)
 
-    def _packed_weights(self, p, fx, fe):
+    def _packed_weights(self, p, fx, fe, remainder=False):
         ks = (self.dense_xe.kernel, self.dense_ex.kernel, self.gat_x.kernel, self.gat_e.kernel)
-        key = tuple((k._version, k.data_ptr()) for k in ks) + (fx, fe)
+        key = tuple((k._version, k.data_ptr()) for k in ks) + (fx, fe, remainder)
         if self._packed is None or self._packed[0] != key:
-            self._packed = (key, _lib.spatial_pack_weights(p, fx, fe, self.h, self.d))
-        return self._packed[1]
+            if remainder:
+                # a trained dense NodeEdge bias through the fused kernel's 96-wide split-input variant: the dense remainder
+                # `rest @ x_e` (S, R, 32) rides in as the 32 extra input columns, multiplied by the SAME rows of the GAT kernel
+                # as the CSR aggregate ([x | rem | agg] @ [Wx; Wagg; Wagg] = [x | agg + rem] @ [Wx; Wagg]); the in-kernel
+                # secondary MLP must not see those columns: zero rows under its kernel
+                z = torch.zeros((self.h, self.h), device=p['xe_k'].device)
+                aug = dict(xe_k=torch.cat([p['xe_k'], z]), ex_k=torch.cat([p['ex_k'], z]),
+                           gx_k=torch.cat([p['gx_k'], p['gx_k'][-self.h:]]), ge_k=torch.cat([p['ge_k'], p['ge_k'][-self.h:]]))
+                p = dict(p, **aug)
+            else:
+                aug = {}
+            self._packed = (key, _lib.spatial_pack_weights(p, fx, fe, self.h, self.d), aug)
+        return self._packed[1], self._packed[2]
 
     def network(self):
         if self._net is None:
@@ -457,22 +486,40 @@ class SpatialLayer(nn.Module):
             return ox.reshape(lead_x + ox.shape[-2:]), oe.reshape(lead_e + oe.shape[-2:])
         vn, rest_n = self.node_edge_n.support_values()
         ve, rest_e = self.node_edge_e.support_values()
-        if rest_n is None and rest_e is None:
-            p = dict(xe_k=self.dense_xe.kernel, xe_b=self.dense_xe.bias, ex_k=self.dense_ex.kernel, ex_b=self.dense_ex.bias,
-                     ne_n_val=vn, ne_e_val=ve,
-                     gx_k=self.gat_x.kernel, gx_as=self.gat_x.attn_kernel_self, gx_an=self.gat_x.attn_kernel_neighs,
-                     gx_b=self.gat_x.bias,
-                     ge_k=self.gat_e.kernel, ge_as=self.gat_e.attn_kernel_self, ge_an=self.gat_e.attn_kernel_neighs,
-                     ge_b=self.gat_e.bias)
+        p = dict(xe_k=self.dense_xe.kernel, xe_b=self.dense_xe.bias, ex_k=self.dense_ex.kernel, ex_b=self.dense_ex.bias,
+                 ne_n_val=vn, ne_e_val=ve,
+                 gx_k=self.gat_x.kernel, gx_as=self.gat_x.attn_kernel_self, gx_an=self.gat_x.attn_kernel_neighs,
+                 gx_b=self.gat_x.bias,
+                 ge_k=self.gat_e.kernel, ge_as=self.gat_e.attn_kernel_self, ge_an=self.gat_e.attn_kernel_neighs,
+                 ge_b=self.gat_e.bias)
+        self.last_path = 'unfused'
+        if rest_n is not None or rest_e is not None:
+            # trained dense NodeEdge bias (every checkpoint the reference trains, emulator.py:36-45): secondary MLP on the
+            # row-GEMM kernel, the dense remainder on the MFMA GEMM, everything else in the fused kernel
+            net = self.network()
+            x_e, e_x = self.dense_xe(es), self.dense_ex(xs)
+            if self.precision == 'bf16x3' and self.h == 32 and self.d == 64 and xs.shape[-1] == 64 and es.shape[-1] == 64 \
+                    and xbs is None and ebs is None:
+                rem_n = self.node_edge_n.remainder(x_e) if rest_n is not None else torch.zeros_like(e_x)
+                rem_e = self.node_edge_e.remainder(e_x) if rest_e is not None else torch.zeros_like(x_e)
+                packed, aug = self._packed_weights(p, 96, 96, remainder=True)
+                net.prepare(96, 96)
+                ox, oe = _lib.spatial_layer_forward(net, dict(p, packed=packed, **aug), xs, es, self.h, self.d, self.activation,
+                                                    _lib.PRECISION_FLAGS[self.precision], xb=rem_n, eb=rem_e)
+                self.last_path = 'fused+remainder'
+            else:
+                ox = self.gat_x([xs, net.adj], xb=self.node_edge_n(x_e))
+                oe = self.gat_e([es, net.edge_adj], xb=self.node_edge_e(e_x))
+        else:
             fx = xs.shape[-1] + (0 if xbs is None else xbs.shape[-1])
             fe = es.shape[-1] + (0 if ebs is None else ebs.shape[-1])
             if self.precision == 'bf16x3' and self.h == 32 and self.d == 64 and fx in (64, 96) and fe in (64, 96):
-                p['packed'] = self._packed_weights(p, fx, fe)       # split once per parameter update, not per call
+                p['packed'] = self._packed_weights(p, fx, fe)[0]    # split once per parameter update, not per call
                 self.network().prepare(fx, fe)                      # tile plans of the 96-wide variants are built on first use
             elif self.precision == 'bf16x3' and self.h == 64 and self.d == 128 and fx == 128 and fe in (64, 128) and xbs is None and ebs is None:
                 self.network().prepare(128, fe)                     # d = 128 (the reference default): the column-split fused kernel
                 if self.network().plan_info()['fused'] & (8 if fe == 128 else 16):
-                    p['packed'] = self._packed_weights(p, fx, fe)
+                    p['packed'] = self._packed_weights(p, fx, fe)[0]
             if 'packed' not in p and self.precision == 'bf16x3' and fx % 32 == 0 and fe % 32 == 0 and self.h % 16 == 0 and self.d % 16 == 0 \
                     and xs.shape[0] * xs.shape[1] >= 4096:
                 # no fused kernel for this shape (d = 128: the reference's default embed_size): unfused composition with
@@ -484,11 +531,7 @@ class SpatialLayer(nn.Module):
                 return ox.reshape(lead_x + ox.shape[-2:]), oe.reshape(lead_e + oe.shape[-2:])
             ox, oe = _lib.spatial_layer_forward(self.network(), p, xs, es, self.h, self.d, self.activation,
                                                 _lib.PRECISION_FLAGS[self.precision], xb=xbs, eb=ebs)
-        else:   # trained dense NodeEdge bias: unfused composition with the dense remainder GEMM
-            net = self.network()
-            x_e, e_x = self.dense_xe(es), self.dense_ex(xs)
-            ox = self.gat_x([xs, net.adj], xb=self.node_edge_n(x_e))
-            oe = self.gat_e([es, net.edge_adj], xb=self.node_edge_e(e_x))
+            self.last_path = 'fused' if 'packed' in p else 'unfused'
         return ox.reshape(lead_x + ox.shape[-2:]), oe.reshape(lead_e + oe.shape[-2:])
 
 

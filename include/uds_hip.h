@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 7
+#define UDS_ABI_VERSION 8
 
 enum {
   UDS_OK = 0,
@@ -110,6 +110,19 @@ int uds_rowgemm_forward(const float *x, int64_t B, int64_t T, int64_t R, int64_t
 int uds_rowgemm_forward_cat(const float *x, int64_t F1, const float *x2, int64_t F2, int64_t B, int64_t T, int64_t R,
                             const void *packed, const float *bias, int64_t taps, int64_t dil, int64_t f_out, int act,
                             float *out, int64_t ldo, int64_t col0, uds_stream_t stream);
+
+/* Dense remainder of a TRAINED NodeEdge layer.  The reference's layer is `(w * inci + b) @ x` with w, b dense trainable
+ * (R, M) matrices (emulator.py:34-45); on the incidence support that is the CSR aggregation of the fused kernel, off the
+ * support it is `rest @ x`, rest = b with the support entries zeroed -- a true (R x M) x (M x S*h) GEMM.  Matrix cores,
+ * split-bf16 (three products, fp32 accumulation):
+ *   out[s, r, :] = sum_m rest[r, m] * x[s, m, :]        x (S, M, h), out (S, R, h), h % 4 == 0, h <= 64.
+ * `packed` = uds_remainder_pack(rest), uds_remainder_packed_bytes(R, M) bytes, once per parameter update; `workspace` =
+ * uds_remainder_workspace_bytes(M, S, h) bytes of scratch per call (the transposed bf16 image of x). */
+int64_t uds_remainder_packed_bytes(int64_t R, int64_t M);
+int uds_remainder_pack(const float *rest, int64_t R, int64_t M, void *packed, uds_stream_t stream);
+int64_t uds_remainder_workspace_bytes(int64_t M, int64_t S, int64_t h);
+int uds_remainder_forward(const void *packed, int64_t R, int64_t M, const float *x, int64_t S, int64_t h, void *workspace,
+                          float *out, uds_stream_t stream);
 
 /* keras Dense(64) (64 inputs) + prefix sum over time + residual + activation in one pass (matrix cores, split-bf16):
  *   out[b,t,r,:] = act( sum_{t' <= t} (x[b,t',r,:] @ kernel + bias) + res[b,0,r,:] ),   x, out: (B,T,R,64), res: (B,1,R,64) or NULL.

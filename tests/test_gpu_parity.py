@@ -167,13 +167,35 @@ def test_spatial_layer_vs_dense_masked_oracle(dev, networks, name, d, S, precisi
     if d == 64:
         info = layer.network().plan_info()
         assert info['fused'] & 1 and info['lds_bytes'] <= 160 * 1024
-    # trained (dense) NodeEdge bias -> unfused composition + remainder GEMM, same answer as the dense oracle
+    # trained (dense) NodeEdge bias, the form every reference-trained checkpoint has (emulator.py:36-45): the dense remainder
+    # on the MFMA GEMM rides into the fused kernel as 32 extra input columns; same answer as the dense oracle
     p['ne_n_b'] = torch.randn(p['ne_n_b'].shape, generator=g, dtype=torch.float64) * 0.01
     p['ne_e_b'] = torch.randn(p['ne_e_b'].shape, generator=g, dtype=torch.float64) * 0.01
     rx, re = OD.spatial_layer_dense(x, e, p, torch.from_numpy(gph.adj.to_dense()), torch.from_numpy(gph.edge_adj.to_dense()), ne)
     load_spatial_layer(layer, p, dev)
     ox, oe = layer(x.float().to(dev), e.float().to(dev))
-    close(ox, rx, TOL); close(oe, re, TOL)
+    close(ox, rx, tol); close(oe, re, tol)
+    assert layer.last_path == ('fused+remainder' if d == 64 and precision == 'bf16x3' else 'unfused')
+    p['ne_e_b'] = torch.zeros_like(p['ne_e_b'])        # trained on the node side only
+    rx, re = OD.spatial_layer_dense(x, e, p, torch.from_numpy(gph.adj.to_dense()), torch.from_numpy(gph.edge_adj.to_dense()), ne)
+    load_spatial_layer(layer, p, dev)
+    ox, oe = layer(x.float().to(dev), e.float().to(dev))
+    close(ox, rx, tol); close(oe, re, tol)
+
+
+@pytest.mark.parametrize('R,M,S,h', [(1, 1, 1, 4), (130, 77, 3, 32), (257, 300, 5, 32), (64, 1000, 2, 64), (300, 129, 7, 12)])
+def test_remainder_gemm_ragged_shapes(dev, R, M, S, h):
+    """uds_remainder_forward (the dense off-support part of a trained NodeEdge, emulator.py:44) against the fp64 product:
+    shapes that are not multiples of the 128 x 128 tile, of the k-step of 32, or of one snapshot per tile column block."""
+    g = torch.Generator().manual_seed(R * 7 + M)
+    rest, x = rnd(g, R, M), rnd(g, S, M, h)
+    ref = torch.matmul(rest, x)
+    packed = _lib.remainder_pack(rest.float().to(dev))
+    out = _lib.remainder_forward(packed, (R, M), x.float().to(dev))
+    assert tuple(out.shape) == (S, R, h)
+    close(out, ref, TOL_BF16X3)
+    out4 = _lib.remainder_forward(packed, (R, M), x.float().to(dev).reshape(1, S, M, h))     # leading dims are kept
+    assert torch.equal(out4[0], out)
 
 
 def test_spatial_block_c1_wide_first_layer(dev):
