@@ -104,6 +104,45 @@ def rollout_autoregressive(U, dev, steps=100):
     return out
 
 
+def trained_bias_leg(U, g, args, dev, x, e, reps=5):
+    """The same block with the reference's trained form of NodeEdge: dense (R, M) weight and bias, the bias non-zero off the
+    incidence support (reference emulator.py:36-45 -- what every checkpoint the reference trains looks like).  Per layer:
+    secondary MLPs on the row-GEMM kernel, `rest @ x_e` on the split-bf16 MFMA GEMM (k_remainder_gemm), the rest in the fused
+    kernel's 96-wide variant with the remainder as 32 extra input columns."""
+    d, L, S = args.embed, args.layers, args.snapshots
+    blk = U.SpatialBlock(g, d, L, 'relu', sparse_params=False, generator=torch.Generator().manual_seed(1), precision=args.precision).to(dev)
+    with torch.no_grad():
+        for ly in blk.layers:
+            ly.node_edge_n.bias.normal_(0.0, 0.01)
+            ly.node_edge_e.bias.normal_(0.0, 0.01)
+        blk(x, e)                                    # packs weights and remainders, builds the 96-wide tile plan
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            blk(x, e)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ly = blk.layers[0]
+        x_e = ly.dense_xe(e)
+        ly.node_edge_n.remainder(x_e)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ly.node_edge_n.remainder(x_e)
+        torch.cuda.synchronize()
+        gemm_ms = (time.perf_counter() - t0) / reps * 1e3
+    ms = float(np.median(ts)) * 1e3
+    flops = 2.0 * g.n_node * g.n_edge * S * (d // 2)
+    return {'value': L * S / (ms * 1e-3), 'unit': 'graph-steps/s', 'ms_per_step': ms, 'path': [ly.last_path for ly in blk.layers],
+            'remainder_gemm': {'kernel': 'k_remainder_gemm (128x128 tiles, split-bf16, 3 MFMA products)', 'ms': gemm_ms,
+                               'shape': '(%d x %d) @ (%d x %d)' % (g.n_node, g.n_edge, g.n_edge, S * (d // 2)),
+                               'tflops_fp32_equivalent': flops / gemm_ms / 1e9, 'tflops_bf16_issued': 3 * flops / gemm_ms / 1e9,
+                               'bound': 'mfma', 'peak_tflops_bf16': 2500.0, 'frac': 3 * flops / gemm_ms / 1e9 / 2500.0,
+                               'launches_per_layer': 2},
+            'note': 'NodeEdge with dense trained bias: 2*N*E*S*d/2 flops per side and layer on top of the support-only layer'}
+
+
 def _cpu_model():
     try:
         with open('/proc/cpuinfo') as fh:
@@ -322,6 +361,7 @@ def main():
     ap.add_argument('--workload', default='headline', choices=['headline', 'c4', 'c5'],
                     help='c4: 200k-node / 240k-link network partitioned over the ranks with per-layer halo exchange')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-trained-bias', action='store_true', help='skip the dense-trained-bias NodeEdge leg')
     ap.add_argument('--autoregressive', action='store_true',
                     help='also time the C2 autoregressive rollout (100 fed-back steps, eager and HIP graph); off by default so that '
                          'the rocprofv3 averages of the default command are those of the timed headline launches')
@@ -403,6 +443,9 @@ def main():
                                    'S=%d snapshots per GPU (B=1,T=%d)' % (g.n_node, g.n_edge, d, L, S, S),
                        'graph_steps_per_step': L * S, 'nnz_node': g.adj.nnz, 'nnz_line': g.edge_adj.nnz,
                        'parallelism': 'snapshot-sharded x%d' % world, 'precision': args.precision,
+                       'node_edge': 'support-only parameters (one weight and bias per incidence entry): equals the reference model at '
+                                    'its initialisation (bias zeros) or with a bias trained on the support; a bias trained off the '
+                                    'support is the `trained_bias` leg',
                        'plan': block.layers[0].network().plan_info()},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': recorded_traffic(args),
@@ -417,6 +460,9 @@ def main():
             out['rollout'] = rollout_forward(U, g, args, dev)
             if args.autoregressive:
                 out['rollout']['autoregressive'] = rollout_autoregressive(U, dev)
+        if world == 1 and args.embed == 64 and args.precision == 'bf16x3' and not args.no_trained_bias \
+                and g.n_node * g.n_edge <= (1 << 28):
+            out['trained_bias'] = trained_bias_leg(U, g, args, dev, x, e)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(U, g, params, d, gpu_out=step(), gpu_in=(x, e))
             # max |GPU - fp64 oracle| / max(1, max|oracle|) over all rows of the first snapshot after the whole L-layer block

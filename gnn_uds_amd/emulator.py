@@ -222,7 +222,10 @@ class Emulator(nn.Module):
         self.embed_b = Dense(h, a, in_features=self.b_in, generator=gen)                        # :203
         self.embed_e = Dense(d, 'linear', in_features=self.e_in, generator=gen)                 # :206
         self.embed_ae = Dense(h, a, in_features=1, generator=gen) if self.act else None         # :212
-        sp = self.n_node * self.n_edge > (1 << 24)
+        # NodeEdge parameters: the reference's dense (R, M) pair, or one (weight, bias) per support entry (`args.sparse_params`,
+        # default: above 16M matrix entries) -- the latter cannot hold a bias trained off the support (load_keras_weights raises)
+        sp = getattr(args, 'sparse_params', None)
+        sp = self.n_node * self.n_edge > (1 << 24) if sp is None else bool(sp)
         if self.graph_base:
             self.block1 = GraphBaseBlock(self.n_node, self.n_edge, self._base_filter, d, L, a, generator=gen, conv=self.conv_kind,
                                          precision=precision)                                                          # :220-223
@@ -791,7 +794,8 @@ class Emulator(nn.Module):
         `weights['<layer>/<weight>:0']` or `weights['<layer>/<layer>/<weight>:0']` (the HDF5 group path) or
         `weights['<layer>'] = [arrays in the layer's own order]`, values array-like.  h5py is not part of this image: read
         the file where TensorFlow / h5py exist (`{n: f[n][()] ...}` -> `np.savez`) and pass the arrays here.  Shapes are
-        checked; NodeEdge parameters created with sparse=True take the dense (R, M) arrays on their support."""
+        checked; NodeEdge parameters created with sparse=True take the dense (R, M) arrays on their support and refuse a bias
+        that is non-zero off it (ValueError: nothing is dropped silently)."""
         weights = dict(weights)
         missing = []
         with torch.no_grad():
@@ -810,7 +814,18 @@ class Emulator(nn.Module):
                     p = getattr(mod, pname)
                     t = torch.as_tensor(np.asarray(arr), dtype=torch.float32)
                     if getattr(mod, 'sparse', False) and t.dim() == 2:        # NodeEdge with one parameter per support entry
-                        t = t.reshape(-1)[mod._flat.cpu()]
+                        flat = mod._flat.cpu()
+                        if pname == 'bias':
+                            # the reference trains `b` as a full (R, M) matrix (emulator.py:36-45): entries off the incidence
+                            # support act on the output (`+ b @ x`) and a sparse=True module has nowhere to keep them
+                            off = t.clone()
+                            off.reshape(-1)[flat] = 0.0
+                            if bool((off != 0).any()):
+                                raise ValueError('%s/%s: the checkpoint bias has %d non-zero entries off the incidence support (max |b| = %.3g); '
+                                                 'a model built with args.sparse_params=True would drop them and change the outputs -- build it '
+                                                 'with args.sparse_params=False (the fused kernel takes the dense remainder)'
+                                                 % (lname, kname, int((off != 0).sum()), float(off.abs().max())))
+                        t = t.reshape(-1)[flat]
                     if pname == 'kernel' and t.dim() == 2 and p.dim() == 3:   # GCNConv (F, C) vs GATConv (F, 1, C)
                         t = t.reshape(p.shape)
                     if tuple(t.shape) != tuple(p.shape):

@@ -58,3 +58,28 @@ def test_round_trip_and_shape_check():
     del bad['dense_1/kernel:0']
     with pytest.raises(KeyError):
         _emul().load_keras_weights(bad)
+
+
+def test_dense_bias_is_not_dropped_silently():
+    """The reference trains NodeEdge.b as a full (R, M) matrix (emulator.py:36-45): a model with one parameter per support
+    entry takes such a checkpoint only when the bias is zero off the support, and refuses it otherwise."""
+    a = _emul()
+    w = a.export_keras_weights()
+    sp = _emul(sparse_params=True)
+    sp.load_keras_weights(w)                       # fresh model: bias is all zero -> fine
+    ne = sp.block1.layers[0].node_edge_n
+    assert ne.sparse and torch.equal(ne.weight, a.block1.layers[0].node_edge_n.weight.reshape(-1)[ne._flat])
+    w = dict(w)
+    b = np.array(w['node_edge/bias:0'])
+    flat = np.asarray(ne._flat)
+    off = np.setdiff1d(np.arange(b.size), flat)[0]
+    b.reshape(-1)[flat] = 0.25                     # on the support: kept
+    w['node_edge/bias:0'] = b
+    sp.load_keras_weights(w)
+    assert float(ne.bias.min()) == 0.25
+    b = b.copy()
+    b.reshape(-1)[off] = 1e-3                      # one trained entry off the support
+    w['node_edge/bias:0'] = b
+    with pytest.raises(ValueError, match='off the incidence support'):
+        sp.load_keras_weights(w)
+    _emul().load_keras_weights(w)                  # the dense model keeps it
