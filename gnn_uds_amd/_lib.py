@@ -131,13 +131,24 @@ def _dev(t, name, allow_none=False):
         raise UdsError('%s must be float32, got %s' % (name, t.dtype))
     if not t.is_contiguous():
         raise UdsError('%s must be contiguous' % name)
+    _same_device(t.device.index, name)
     return t.data_ptr()
+
+
+def _same_device(index, what):
+    """Kernels are enqueued on the CURRENT device's stream and handles allocate on the current device: an operand or a
+    handle that lives on another GPU would be reached as peer traffic at best, fault at worst -- refuse it."""
+    cur = torch.cuda.current_device()
+    if index is not None and index != cur:
+        raise UdsError('%s lives on cuda:%d but the current device is cuda:%d: call torch.cuda.set_device(%d) (one process per GPU) '
+                       'or wrap the call in `with torch.cuda.device(%d):`' % (what, index, cur, index, index))
 
 
 def _dev_i32(t, name):
     """Device pointer of a contiguous int32 HIP tensor (index lists of the backward kernels)."""
     if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.int32 or not t.is_contiguous():
         raise UdsError('%s must be a contiguous int32 HIP tensor' % name)
+    _same_device(t.device.index, name)
     return t.data_ptr()
 
 
@@ -154,6 +165,7 @@ class CsrHandle:
         rowptr = np.ascontiguousarray(csr.rowptr, dtype=np.int32)
         col = np.ascontiguousarray(csr.col, dtype=np.int32)
         h = _c_ptr()
+        self.device = torch.cuda.current_device()        # uds_csr_create allocates on the current device
         _check(lib.uds_csr_create(rowptr.ctypes.data, col.ctypes.data, self.n_rows, self.n_cols, self.nnz,
                                   ctypes.byref(h)), 'uds_csr_create')
         self._h = h
@@ -186,6 +198,7 @@ class CsrHandle:
 
     @property
     def ptr(self):
+        _same_device(self.device, 'this CSR handle')
         return self._h
 
     def row_order(self):
@@ -215,6 +228,7 @@ class NetworkHandle:
         self.inc_n = CsrHandle(graph.inc_n)
         self.inc_e = CsrHandle(graph.inc_e)
         h = _c_ptr()
+        self.device = torch.cuda.current_device()        # tile plans are uploaded to the current device
         _check(lib.uds_network_create(self.adj.ptr, self.edge_adj.ptr, self.inc_n.ptr, self.inc_e.ptr, ctypes.byref(h)),
                'uds_network_create')
         self._h = h
@@ -222,13 +236,14 @@ class NetworkHandle:
 
     @property
     def ptr(self):
+        _same_device(self.device, 'this network handle')
         return self._h
 
     def prepare(self, fx, fe):
         """Build the tile plans a layer with input widths (fx, fe) needs (no-op for 64/64 and once built)."""
         key = (int(fx), int(fe))
         if key not in self._prepared:
-            _check(load().uds_network_prepare(self._h, key[0], key[1]), 'uds_network_prepare')
+            _check(load().uds_network_prepare(self.ptr, key[0], key[1]), 'uds_network_prepare')
             self._prepared.add(key)
 
     def plan_info(self):

@@ -235,6 +235,20 @@ def hip_layers(prob, global_params, embed_size, activation='relu', precision='bf
     return layers
 
 
+def all_ranks_finite(value, group=None):
+    """True only when `value` (a tensor) is finite on EVERY rank: a MIN all-reduce of the local 0/1 flag, so that all ranks
+    take the same branch -- a rank that raised on its own non-finite loss would leave its peers waiting in the gradient
+    all-reduce.  The local test alone when torch.distributed is not initialised or the world has one rank."""
+    ok = torch.isfinite(value).all()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        flag = ok.to(torch.float32).reshape(1)
+        if dist.get_backend(group) == 'gloo':
+            flag = flag.cpu()
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return bool(flag.item() > 0.5)
+    return bool(ok)
+
+
 def allreduce_gradients(params, group=None, bucket_bytes=64 << 20):
     """Data-parallel training (snapshot / scenario sharding adds ONE gradient all-reduce per step): average
     the `.grad` of `params` over the ranks.  Gradients are packed into flat fp32 buckets (one bucket for a whole emulator:

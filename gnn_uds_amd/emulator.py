@@ -674,12 +674,12 @@ class Emulator(nn.Module):
                     if fl_loss is None:
                         raise NotImplementedError('if_flood with balance: the reference leaves fl_loss undefined here (emulator.py:466,473)')
                     loss = loss + (alpha[1].detach() * fl_loss if self.gradnorm else fl_loss)
-                if not bool(torch.isfinite(loss)):
+                from .dist import all_ranks_finite, allreduce_gradients
+                if not all_ranks_finite(loss):       # agreed over the data-parallel ranks: all raise or none does
                     raise FloatingPointError('Loss contains NaN or Inf values.')
                 for p in params:
                     p.grad = None
                 loss.backward()
-                from .dist import allreduce_gradients
                 allreduce_gradients(params)          # data-parallel ranks: one bucketed all-reduce (no-op on one rank)
                 if self._optimizer is None:
                     self._optimizer = KerasAdam(params, self.learning_rate, clipnorm=1.0)

@@ -153,6 +153,11 @@ def _grad_worker(rank, world, port, result):
         calls_small = D.allreduce_gradients(params, bucket_bytes=40)                              # forces several buckets
         err = max(err, max(float((p.grad - sum(grads[r][k] for r in range(world)) / world).abs().max())
                            for k, p in enumerate(params)))
+        # a non-finite loss on ONE rank is seen by all of them (so that all raise together, none hangs in the all-reduce)
+        flags = (D.all_ranks_finite(torch.tensor(1.0)), D.all_ranks_finite(torch.tensor(float('nan') if rank == 1 else 1.0)))
+        t = torch.tensor([float(flags[0]), float(flags[1])])
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        assert flags == (True, False) and t.tolist() == [float(world), 0.0]
         if rank == 0:
             result.put((err, calls_one, calls_small))
     finally:
