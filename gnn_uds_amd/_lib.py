@@ -135,10 +135,16 @@ def _dev(t, name, allow_none=False):
     return t.data_ptr()
 
 
+def _current_device():
+    if not torch.cuda.is_available():
+        raise UdsError('no HIP device is visible: gnn_uds_amd runs on the MI355X only and has no CPU fallback')
+    return torch.cuda.current_device()
+
+
 def _same_device(index, what):
     """Kernels are enqueued on the CURRENT device's stream and handles allocate on the current device: an operand or a
     handle that lives on another GPU would be reached as peer traffic at best, fault at worst -- refuse it."""
-    cur = torch.cuda.current_device()
+    cur = _current_device()
     if index is not None and index != cur:
         raise UdsError('%s lives on cuda:%d but the current device is cuda:%d: call torch.cuda.set_device(%d) (one process per GPU) '
                        'or wrap the call in `with torch.cuda.device(%d):`' % (what, index, cur, index, index))
@@ -165,7 +171,7 @@ class CsrHandle:
         rowptr = np.ascontiguousarray(csr.rowptr, dtype=np.int32)
         col = np.ascontiguousarray(csr.col, dtype=np.int32)
         h = _c_ptr()
-        self.device = torch.cuda.current_device()        # uds_csr_create allocates on the current device
+        self.device = _current_device()                  # uds_csr_create allocates on the current device
         _check(lib.uds_csr_create(rowptr.ctypes.data, col.ctypes.data, self.n_rows, self.n_cols, self.nnz,
                                   ctypes.byref(h)), 'uds_csr_create')
         self._h = h
@@ -228,7 +234,7 @@ class NetworkHandle:
         self.inc_n = CsrHandle(graph.inc_n)
         self.inc_e = CsrHandle(graph.inc_e)
         h = _c_ptr()
-        self.device = torch.cuda.current_device()        # tile plans are uploaded to the current device
+        self.device = _current_device()                  # tile plans are uploaded to the current device
         _check(lib.uds_network_create(self.adj.ptr, self.edge_adj.ptr, self.inc_n.ptr, self.inc_e.ptr, ctypes.byref(h)),
                'uds_network_create')
         self._h = h
