@@ -262,6 +262,28 @@ def bench_c4(args, U, dist, world, rank, dev):
         t = torch.tensor([wall], device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
+    # what the exchange costs and how much of it the snapshot-group pipeline leaves exposed (max over ranks, per layer that
+    # exchanges): compute only (no exchange, results wrong but same kernels) | in-order compute-then-exchange | pipelined
+    def timed(fn, reps=3):
+        fn()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64)
+        if dist is not None:
+            t = t.to(dev if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def compute_only():
+        xx, ee = x, e
+        for ly in layers:
+            xx, ee = ly(xx, ee)
+    t_comp, t_inorder, t_pipe = timed(compute_only), timed(lambda: block.forward(x, e, stages=1)), timed(lambda: block.forward(x, e))
     if rank == 0:
         bytes_gs = algorithmic_bytes_per_graph_step(g, d, d)
         achieved = args.steps * L * S * bytes_gs / world / wall / 1e9        # per GPU: each rank streams 1/world of the network
@@ -275,6 +297,9 @@ def bench_c4(args, U, dist, world, rank, dev):
                        'own_nodes': int(len(prob.own_nodes)), 'halo_nodes': int(len(prob.nodes) - len(prob.own_nodes)),
                        'halo_links': int(len(prob.links) - len(prob.own_links)), 'peers': len(block.exchange.peers),
                        'halo_bytes_per_layer': block.exchange.bytes_per_layer(S, d), 'precision': args.precision},
+            'halo': {'compute_only_ms': t_comp, 'in_order_ms': t_inorder, 'pipelined_ms': t_pipe,
+                     'halo_ms_per_layer': (t_inorder - t_comp) / max(1, L - 1), 'exposed_ms_per_layer': (t_pipe - t_comp) / max(1, L - 1),
+                     'note': 'exchange hidden by pipelining over 2 snapshot groups on a side stream (dist.ShardedSpatialBlock.forward)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
                          'traffic': None, 'kernel': 'k_fused_tile (per rank, its part of the network)'}}))
     if dist is not None:

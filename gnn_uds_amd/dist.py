@@ -163,7 +163,9 @@ class HaloExchange:
         return sum((len(self.send_n[q]) + len(self.send_e[q])) * S * F * 4 for q in self.peers)
 
     def __call__(self, x, e):
-        """x (S, n_local_nodes, F), e (S, n_local_links, F): overwrite the halo rows with the owners' exact rows."""
+        """x (S, n_local_nodes, F), e (S, n_local_links, F): overwrite the halo rows with the owners' exact rows.  Everything
+        is enqueued on the CURRENT stream (RCCL: the send / receive kernels are ordered after the stream's earlier work and
+        `wait()` blocks the stream, not the host), so a caller that runs this under a side stream overlaps it with compute."""
         if not self.peers:
             return x, e
         ops, recvs, keep = [], [], []
@@ -196,6 +198,7 @@ class ShardedSpatialBlock:
     def __init__(self, prob, n_layers, layer_fn, device, group=None):
         self.prob, self.n_layers, self.layer_fn = prob, n_layers, layer_fn
         self.exchange = HaloExchange(prob, device, group)
+        self._side = None                     # side stream of the pipelined exchange, created on first use
 
     def scatter_inputs(self, x_global, e_global):
         """Local buffers from replicated global inputs (own + halo rows are simply read)."""
@@ -204,13 +207,55 @@ class ShardedSpatialBlock:
         li = torch.as_tensor(self.prob.links, dtype=torch.int64, device=dev)
         return x_global.index_select(1, ni).contiguous(), e_global.index_select(1, li).contiguous()
 
-    def forward(self, x_local, e_local):
-        """x_local (S, n_local_nodes, F), e_local likewise, halo rows valid.  Returns the own rows of the block output."""
-        for i in range(self.n_layers):
-            x_local, e_local = self.layer_fn(self.prob, i, x_local, e_local)
-            if i + 1 < self.n_layers:
-                x_local, e_local = self.exchange(x_local, e_local)
-        return x_local[:, :len(self.prob.own_nodes)], e_local[:, :len(self.prob.own_links)]
+    def forward(self, x_local, e_local, stages=2):
+        """x_local (S, n_local_nodes, F), e_local likewise, halo rows valid.  Returns the own rows of the block output.
+
+        The snapshots are independent, so the exchange is hidden by PIPELINING OVER SNAPSHOT GROUPS: the S snapshots are cut
+        into `stages` groups; as soon as a group's layer is computed its boundary rows are packed, sent and the received
+        halo rows scattered on a side stream, while the main stream computes the same layer of the next group (and then the
+        next layer of the first group, whose halo has arrived by then).  Only a group whose exchange is slower than one
+        group-layer of compute leaves the main stream waiting.  The fused kernel is launched per group (it takes any S); no
+        kernel needs a boundary / interior split of its tiles.  stages=1 (or one snapshot, or no peers): compute, then
+        exchange, in order on one stream."""
+        S = x_local.shape[0]
+        L, ex = self.n_layers, self.exchange
+        G = max(1, min(int(stages), S)) if ex.peers else 1
+        if G == 1:
+            for i in range(L):
+                x_local, e_local = self.layer_fn(self.prob, i, x_local, e_local)
+                if i + 1 < L:
+                    x_local, e_local = ex(x_local, e_local)
+            return x_local[:, :len(self.prob.own_nodes)], e_local[:, :len(self.prob.own_links)]
+        cuts = [g * S // G for g in range(G + 1)]
+        xs = [x_local[cuts[g]:cuts[g + 1]] for g in range(G)]
+        es = [e_local[cuts[g]:cuts[g + 1]] for g in range(G)]
+        on_gpu = x_local.is_cuda
+        if on_gpu:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=x_local.device)
+            main, side = torch.cuda.current_stream(x_local.device), self._side
+        ready = [None] * G                    # event: the halo rows of group g hold the previous layer's exchanged values
+        for i in range(L):
+            for g in range(G):
+                if ready[g] is not None:
+                    main.wait_event(ready[g])
+                xs[g], es[g] = self.layer_fn(self.prob, i, xs[g], es[g])
+                if i + 1 == L:
+                    continue
+                if not on_gpu:                # CPU tensors (gloo tests): same order of messages, no streams
+                    ex(xs[g], es[g])
+                    continue
+                computed = torch.cuda.Event()
+                computed.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(computed)
+                    ex(xs[g], es[g])          # pack, send / receive, scatter: all ordered on the side stream
+                    ready[g] = torch.cuda.Event()
+                    ready[g].record(side)
+                xs[g].record_stream(side)
+                es[g].record_stream(side)
+        no, lo = len(self.prob.own_nodes), len(self.prob.own_links)
+        return torch.cat([t[:, :no] for t in xs], dim=0), torch.cat([t[:, :lo] for t in es], dim=0)
 
 
 def hip_layers(prob, global_params, embed_size, activation='relu', precision='bf16x3', device='cuda'):

@@ -109,7 +109,11 @@ def _worker(rank, world, port, result):
         prob = D.build_partition_plan(g, world)[rank]
         block = D.ShardedSpatialBlock(prob, L, _oracle_layer_fn(params), torch.device('cpu'))
         lx, le = block.scatter_inputs(x, e)
-        ox, oe = block.forward(lx, le)
+        ox, oe = block.forward(lx, le)                    # pipelined over two snapshot groups (the default)
+        o1x, o1e = block.forward(lx, le, stages=1)        # compute, then exchange, layer by layer
+        assert torch.equal(ox, o1x) and torch.equal(oe, o1e)
+        o3x, _ = block.forward(lx, le, stages=S + 5)      # more groups than snapshots: one snapshot per group
+        assert torch.equal(ox, o3x)
         rx, re = _full_oracle(g, params, x, e)
         err = max(float((ox - rx[:, prob.own_nodes]).abs().max()), float((oe - re[:, prob.own_links]).abs().max()))
         t = torch.tensor([err], dtype=torch.float64)

@@ -109,3 +109,75 @@ def test_c4_size_network_properties(dev):
     assert cut <= 0.06 * g.n_edge, cut
     sizes = np.bincount(part, minlength=8)
     assert sizes.max() - sizes.min() <= 1
+
+
+class _MailboxExchange(D.HaloExchange):
+    """The exchange of `dist.HaloExchange` between rank THREADS of one process: the packed rows travel through queues with
+    the event that marks them written, the receiver's current stream waits on it.  Same packing, same message order and the
+    same stream discipline as the RCCL path (everything enqueued on the caller's current stream)."""
+
+    def __init__(self, prob, device, mail):
+        super().__init__(prob, device)
+        self.mail = mail
+
+    def __call__(self, x, e):
+        st = torch.cuda.current_stream()
+        for q in self.peers:
+            sn, se = self.send_n[q], self.send_e[q]
+            if len(sn) + len(se):
+                out = torch.cat([x.index_select(1, sn), e.index_select(1, se)], dim=1).contiguous()
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self.mail[(self.prob.rank, q)].put((out, ev))
+        for q in self.peers:
+            nn_ = len(self.recv_n[q])
+            if nn_ + len(self.recv_e[q]):
+                buf, ev = self.mail[(q, self.prob.rank)].get(timeout=120)
+                st.wait_event(ev)
+                x.index_copy_(1, self.recv_n[q], buf[:, :nn_])
+                e.index_copy_(1, self.recv_e[q], buf[:, nn_:])
+                buf.record_stream(st)
+        return x, e
+
+
+@pytest.mark.parametrize('n_parts,stages', [(2, 2), (4, 2), (4, 3), (8, 1)])
+def test_pipelined_exchange_on_side_streams(dev, c2_problem, n_parts, stages):
+    """`ShardedSpatialBlock.forward` with the exchange pipelined over snapshot groups (side stream + events) on the HIP
+    layers: one thread per rank on cuda:0, rows handed over in-process; own rows equal the fp64 oracle of the whole network
+    and the in-order (stages=1) schedule bit for bit."""
+    import queue
+    import threading
+    g, params, x, e, ox, oe, rx, re, d, L = c2_problem
+    probs = D.build_partition_plan(g, n_parts)
+    layers = [D.hip_layers(p, params, d, 'relu', 'bf16x3', dev) for p in probs]
+    results = {}
+
+    def run(stages_):
+        mail = {(p, q): queue.Queue() for p in range(n_parts) for q in range(n_parts)}
+        out, errs = [None] * n_parts, []
+
+        def rank_main(k):
+            try:
+                torch.cuda.set_device(dev)
+                blk = D.ShardedSpatialBlock(probs[k], L, lambda p, i, xx, ee: layers[p.rank][i](xx, ee), dev)
+                blk.exchange = _MailboxExchange(probs[k], dev, mail)
+                lx, le = x[:, probs[k].nodes].to(dev).contiguous(), e[:, probs[k].links].to(dev).contiguous()
+                with torch.no_grad():
+                    sx, se = blk.forward(lx, le, stages=stages_)
+                torch.cuda.synchronize()
+                out[k] = (sx.clone(), se.clone())
+            except Exception as exc:       # surfaced in the main thread
+                errs.append(exc)
+        ts = [threading.Thread(target=rank_main, args=(k,)) for k in range(n_parts)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=300)
+        assert not errs, errs
+        return out
+    piped = run(stages)
+    inorder = run(1)
+    for p, (sx, se), (ix, ie) in zip(probs, piped, inorder):
+        close(sx, rx[:, p.own_nodes], TOL_BF16X3)
+        close(se, re[:, p.own_links], TOL_BF16X3)
+        assert torch.equal(sx, ix) and torch.equal(se, ie)
