@@ -23,9 +23,9 @@
 
 namespace uds {
 
-constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32, GEMM_LDS_ROW = 40;      // LDS row stride in bf16 (80 bytes)
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 64, GEMM_LDS_ROW = 64;      // LDS rows of 64 bf16 (128 bytes), XOR-swizzled
 
-// fp32 (rows x K) -> bf16 hi / lo planes (rows x Kp), Kp = K rounded up to 32, zero padded
+// fp32 (rows x K) -> bf16 hi / lo planes (rows x Kp), Kp = K rounded up to 64, zero padded
 __global__ void k_split_rows_bf16(const float *__restrict__ a, int64_t rows, int64_t K, int64_t Kp, __bf16 *__restrict__ hi,
                                   __bf16 *__restrict__ lo) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per 8 consecutive k
@@ -67,68 +67,80 @@ __global__ __launch_bounds__(256) void k_split_transpose_bf16(const float *__res
 }
 
 // out[s][r][f] = sum_k X[(s, f)][k] * W[r][k]:  X = transposed activations (Nc x Kp, Nc = S * h), W = rest (R x Kp), both
-// as hi / lo bf16 planes.  grid = (ceil(Nc / 128), ceil(R / 128)).
+// as hi / lo bf16 planes, Kp % 64 == 0.  grid = n_ctile * ceil(R / 128) workgroups, n_ctile = ceil(Nc / 128).
+// Per k-step of 64: [barrier] staged registers -> LDS [barrier] next step's 16 global loads issued, then 2 x (16 fragment
+// reads + 48 MFMAs) -- the loads have a whole step of matrix work (and the other workgroup of the CU) to land.
 __global__ __launch_bounds__(256, 2) void k_remainder_gemm(const __bf16 *__restrict__ Xh, const __bf16 *__restrict__ Xl,
                                                           const __bf16 *__restrict__ Wh, const __bf16 *__restrict__ Wl, int64_t Nc, int64_t R,
-                                                          int64_t Kp, int h, float *__restrict__ out) {
-  __shared__ __attribute__((aligned(16))) __bf16 lds[2][4][GEMM_BM * GEMM_LDS_ROW];      // [buffer][Xh, Xl, Wh, Wl][128 rows x 40]
+                                                          int64_t Kp, int h, int n_ctile, float *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[4][GEMM_BM * GEMM_LDS_ROW];      // [Xh, Xl, Wh, Wl][128 rows x 64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;                   // wave tile: X rows (columns of the result) 64 wr.., W rows 64 wc..
-  const int64_t c0 = (int64_t)blockIdx.x * GEMM_BM, r0 = (int64_t)blockIdx.y * GEMM_BN;
-  // global -> register staging: the 128 x 32 bf16 tile of a plane is 512 16-byte chunks, two per thread
-  const int ch_row0 = tid >> 2, ch_k = (tid & 3) * 8;       // chunk rows tid/4 and tid/4 + 64, 8 bf16 at k offset ch_k
-  const int64_t xrow0 = min(c0 + ch_row0, Nc - 1), xrow1 = min(c0 + ch_row0 + 64, Nc - 1);      // rows past the matrix are clamped
-  const int64_t wrow0 = min(r0 + ch_row0, R - 1), wrow1 = min(r0 + ch_row0 + 64, R - 1);        // (their results are not stored)
-  const __bf16 *pxh0 = Xh + xrow0 * Kp + ch_k, *pxh1 = Xh + xrow1 * Kp + ch_k, *pxl0 = Xl + xrow0 * Kp + ch_k, *pxl1 = Xl + xrow1 * Kp + ch_k;
-  const __bf16 *pwh0 = Wh + wrow0 * Kp + ch_k, *pwh1 = Wh + wrow1 * Kp + ch_k, *pwl0 = Wl + wrow0 * Kp + ch_k, *pwl1 = Wl + wrow1 * Kp + ch_k;
-  uint4 g0, g1, g2, g3, g4, g5, g6, g7;
-  const int lo0 = ch_row0 * GEMM_LDS_ROW + ch_k, lo1 = lo0 + 64 * GEMM_LDS_ROW;
-#define UDS_GEMM_LOAD(k0)                                   \
-  g0 = *reinterpret_cast<const uint4 *>(pxh0 + (k0));       \
-  g1 = *reinterpret_cast<const uint4 *>(pxh1 + (k0));       \
-  g2 = *reinterpret_cast<const uint4 *>(pxl0 + (k0));       \
-  g3 = *reinterpret_cast<const uint4 *>(pxl1 + (k0));       \
-  g4 = *reinterpret_cast<const uint4 *>(pwh0 + (k0));       \
-  g5 = *reinterpret_cast<const uint4 *>(pwh1 + (k0));       \
-  g6 = *reinterpret_cast<const uint4 *>(pwl0 + (k0));       \
-  g7 = *reinterpret_cast<const uint4 *>(pwl1 + (k0));
-#define UDS_GEMM_STORE(buf)                                 \
-  *reinterpret_cast<uint4 *>(&lds[buf][0][lo0]) = g0;       \
-  *reinterpret_cast<uint4 *>(&lds[buf][0][lo1]) = g1;       \
-  *reinterpret_cast<uint4 *>(&lds[buf][1][lo0]) = g2;       \
-  *reinterpret_cast<uint4 *>(&lds[buf][1][lo1]) = g3;       \
-  *reinterpret_cast<uint4 *>(&lds[buf][2][lo0]) = g4;       \
-  *reinterpret_cast<uint4 *>(&lds[buf][2][lo1]) = g5;       \
-  *reinterpret_cast<uint4 *>(&lds[buf][3][lo0]) = g6;       \
-  *reinterpret_cast<uint4 *>(&lds[buf][3][lo1]) = g7;
+  // Workgroups b, b + 8, b + 16 ... share an XCD (and its 4 MB L2): give each XCD a contiguous run of tiles, column tile
+  // fastest, so that the ~64 tiles an XCD has in flight are a few row tiles of W times all column tiles of X -- every
+  // k-step's W and X pieces are then fetched into that L2 once and served to the 4-15 workgroups that use them
+  const int nblk = gridDim.x, b = blockIdx.x, q8 = nblk / 8, r8 = nblk % 8, xcd = b % 8;
+  const int w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+  const int64_t c0 = (int64_t)(w % n_ctile) * GEMM_BM, r0 = (int64_t)(w / n_ctile) * GEMM_BN;
+  // global -> register staging: the 128 x 64 bf16 tile of a plane is 1024 16-byte chunks, four per thread and plane:
+  // rows tid / 8 + 32 i, 8 bf16 at k offset 8 (tid % 8) -- eight threads read 128 contiguous bytes of a row
+  const int ch_row = tid >> 3, ch_k = (tid & 7) * 8;
+  // LDS image: the 16-byte chunk c of row r sits at chunk c ^ (r & 7) -- the four 16-lane groups of a ds_read_b128 fragment
+  // read (rows lane & 15, chunk lane >> 4) then touch every bank once (plain 128-byte rows: 4-way; padded to 144: 2-way)
+  const int ch_sw = (((tid & 7) ^ (ch_row & 7)) * 8);
+  int64_t xoff[4], woff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {       // rows past the matrix are clamped (their results are not stored)
+    xoff[i] = min(c0 + ch_row + 32 * i, Nc - 1) * Kp + ch_k;
+    woff[i] = min(r0 + ch_row + 32 * i, R - 1) * Kp + ch_k;
+  }
+  uint4 a0, a1, a2, a3, b0, b1, b2, b3, c0_, c1_, c2_, c3_, d0, d1, d2, d3;      // named scalars: an array here ends up in scratch
+#define UDS_GEMM_LOAD1(i, A, B, C, D, k0)                           \
+  A = *reinterpret_cast<const uint4 *>(Xh + xoff[i] + (k0));        \
+  B = *reinterpret_cast<const uint4 *>(Xl + xoff[i] + (k0));        \
+  C = *reinterpret_cast<const uint4 *>(Wh + woff[i] + (k0));        \
+  D = *reinterpret_cast<const uint4 *>(Wl + woff[i] + (k0));
+#define UDS_GEMM_LOAD(k0)                                           \
+  UDS_GEMM_LOAD1(0, a0, b0, c0_, d0, k0) UDS_GEMM_LOAD1(1, a1, b1, c1_, d1, k0) UDS_GEMM_LOAD1(2, a2, b2, c2_, d2, k0) UDS_GEMM_LOAD1(3, a3, b3, c3_, d3, k0)
+#define UDS_GEMM_STORE1(i, A, B, C, D)                              \
+  {                                                                 \
+    const int o = (ch_row + 32 * i) * GEMM_LDS_ROW + ch_sw;         \
+    *reinterpret_cast<uint4 *>(&lds[0][o]) = A;                     \
+    *reinterpret_cast<uint4 *>(&lds[1][o]) = B;                     \
+    *reinterpret_cast<uint4 *>(&lds[2][o]) = C;                     \
+    *reinterpret_cast<uint4 *>(&lds[3][o]) = D;                     \
+  }
+#define UDS_GEMM_STORE UDS_GEMM_STORE1(0, a0, b0, c0_, d0) UDS_GEMM_STORE1(1, a1, b1, c1_, d1) UDS_GEMM_STORE1(2, a2, b2, c2_, d2) UDS_GEMM_STORE1(3, a3, b3, c3_, d3)
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int fr = lane & 15, fk = (lane >> 4) * 8;            // fragment: row / column lane&15, 8 consecutive k at 8 * (lane >> 4)
+  const int fr = lane & 15;                                 // fragment: row / column lane & 15, 8 consecutive k at 8 * (lane >> 4)
   UDS_GEMM_LOAD(0)
-  UDS_GEMM_STORE(0)
-  __syncthreads();
   const int64_t n_k = Kp / GEMM_BK;
   for (int64_t kt = 0; kt < n_k; ++kt) {
-    const int buf = (int)(kt & 1);
-    if (kt + 1 < n_k) { UDS_GEMM_LOAD((kt + 1) * GEMM_BK) }      // in flight while this step is multiplied
-    bf16x8 xh[4], xl[4], wh[4], wl[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int xo = (wr * 64 + i * 16 + fr) * GEMM_LDS_ROW + fk, wo = (wc * 64 + i * 16 + fr) * GEMM_LDS_ROW + fk;
-      xh[i] = *reinterpret_cast<const bf16x8 *>(&lds[buf][0][xo]);
-      xl[i] = *reinterpret_cast<const bf16x8 *>(&lds[buf][1][xo]);
-      wh[i] = *reinterpret_cast<const bf16x8 *>(&lds[buf][2][wo]);
-      wl[i] = *reinterpret_cast<const bf16x8 *>(&lds[buf][3][wo]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = mfma3(xh[i], xl[i], wh[j], wl[j], acc[i][j]);
-    if (kt + 1 < n_k) { UDS_GEMM_STORE(buf ^ 1) }
+    __syncthreads();                                         // every wave has read the previous step's fragments
+    UDS_GEMM_STORE
     __syncthreads();
+    if (kt + 1 < n_k) { UDS_GEMM_LOAD((kt + 1) * GEMM_BK) }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      bf16x8 xh[4], xl[4], wh[4], wl[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int sw = (((half * 4 + (lane >> 4)) ^ (fr & 7)) * 8);       // rows 16 i + fr: (row & 7) = (fr & 7)
+        const int xo = (wr * 64 + i * 16 + fr) * GEMM_LDS_ROW + sw, wo = (wc * 64 + i * 16 + fr) * GEMM_LDS_ROW + sw;
+        xh[i] = *reinterpret_cast<const bf16x8 *>(&lds[0][xo]);
+        xl[i] = *reinterpret_cast<const bf16x8 *>(&lds[1][xo]);
+        wh[i] = *reinterpret_cast<const bf16x8 *>(&lds[2][wo]);
+        wl[i] = *reinterpret_cast<const bf16x8 *>(&lds[3][wo]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma3(xh[i], xl[i], wh[j], wl[j], acc[i][j]);
+    }
   }
   // D[row = 4 (lane >> 4) + q][col = lane & 15] of tile (i, j): result column c = c0 + 64 wr + 16 i + 4 (lane >> 4) + q
   // (= snapshot c / h, feature c % h), result row r = r0 + 64 wc + 16 j + (lane & 15): four consecutive features per lane
@@ -146,6 +158,8 @@ __global__ __launch_bounds__(256, 2) void k_remainder_gemm(const __bf16 *__restr
 }
 
 #undef UDS_GEMM_LOAD
+#undef UDS_GEMM_LOAD1
 #undef UDS_GEMM_STORE
+#undef UDS_GEMM_STORE1
 
 }  // namespace uds

@@ -333,18 +333,18 @@ int uds_rowgemm_pack(const float *W, int64_t k_total, int64_t f_out, void *packe
   return UDS_OK;
 }
 
-static int64_t pad32(int64_t k) { return (k + 31) / 32 * 32; }
+static int64_t pad_k(int64_t k) { return (k + 63) / 64 * 64; }      // the remainder GEMM's k-step
 
 int64_t uds_remainder_packed_bytes(int64_t R, int64_t M) {
   if (R <= 0 || M <= 0) return 0;
-  return 2 * R * pad32(M) * 2;
+  return 2 * R * pad_k(M) * 2;
 }
 
 int uds_remainder_pack(const float *rest, int64_t R, int64_t M, void *packed, uds_stream_t stream) {
   UDS_REQUIRE(rest && packed && aligned16(packed), "uds_remainder_pack: NULL / misaligned argument");
-  UDS_REQUIRE(R > 0 && M > 0 && R * pad32(M) / 8 < (int64_t)INT32_MAX * 256, "uds_remainder_pack: bad shape (%lld, %lld)", (long long)R,
+  UDS_REQUIRE(R > 0 && M > 0 && R * pad_k(M) / 8 < (int64_t)INT32_MAX * 256, "uds_remainder_pack: bad shape (%lld, %lld)", (long long)R,
               (long long)M);
-  const int64_t Kp = pad32(M), n = R * Kp / 8;
+  const int64_t Kp = pad_k(M), n = R * Kp / 8;
   __bf16 *hi = reinterpret_cast<__bf16 *>(packed), *lo = hi + R * Kp;
   hipLaunchKernelGGL(uds::k_split_rows_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), rest, R, M,
                      Kp, hi, lo);
@@ -355,7 +355,7 @@ int uds_remainder_pack(const float *rest, int64_t R, int64_t M, void *packed, ud
 
 int64_t uds_remainder_workspace_bytes(int64_t M, int64_t S, int64_t h) {
   if (M <= 0 || S <= 0 || h <= 0) return 0;
-  return 2 * S * h * pad32(M) * 2;
+  return 2 * S * h * pad_k(M) * 2;
 }
 
 int uds_remainder_forward(const void *packed, int64_t R, int64_t M, const float *x, int64_t S, int64_t h, void *workspace, float *out,
@@ -365,15 +365,16 @@ int uds_remainder_forward(const void *packed, int64_t R, int64_t M, const float 
   UDS_REQUIRE(packed && x && workspace && out, "uds_remainder_forward: NULL argument");
   UDS_REQUIRE(h > 0 && h <= 64 && h % 4 == 0, "uds_remainder_forward: h = %lld (needs h %% 4 == 0, h <= 64)", (long long)h);
   UDS_REQUIRE(aligned16(packed) && aligned16(workspace) && aligned16(out), "uds_remainder_forward: buffers must be 16-byte aligned");
-  const int64_t Kp = pad32(M), Nc = S * h;
-  UDS_REQUIRE(S <= 65535 && (Nc + 127) / 128 < INT32_MAX && (R + 127) / 128 <= 65535, "uds_remainder_forward: shape exceeds the launch grid");
+  const int64_t Kp = pad_k(M), Nc = S * h;
+  UDS_REQUIRE(S <= 65535 && ((Nc + 127) / 128) * ((R + 127) / 128) < INT32_MAX, "uds_remainder_forward: shape exceeds the launch grid");
   const __bf16 *wh = reinterpret_cast<const __bf16 *>(packed), *wl = wh + R * Kp;
   __bf16 *xh = reinterpret_cast<__bf16 *>(workspace), *xl = xh + Nc * Kp;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(uds::k_split_transpose_bf16, dim3((unsigned)(Kp / 64 + (Kp % 64 != 0)), (unsigned)S), dim3(256), 0, st, x, M, (int)h, Kp,
                      xh, xl);
-  hipLaunchKernelGGL(uds::k_remainder_gemm, dim3((unsigned)((Nc + 127) / 128), (unsigned)((R + 127) / 128)), dim3(256), 0, st, xh, xl, wh, wl,
-                     Nc, R, Kp, (int)h, out);
+  const int64_t n_ctile = (Nc + 127) / 128, n_rtile = (R + 127) / 128;
+  hipLaunchKernelGGL(uds::k_remainder_gemm, dim3((unsigned)(n_ctile * n_rtile)), dim3(256), 0, st, xh, xl, wh, wl, Nc, R, Kp, (int)h,
+                     (int)n_ctile, out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(UDS_EHIP, "uds_remainder_forward: launch -> %s", hipGetErrorString(e));
   return UDS_OK;
