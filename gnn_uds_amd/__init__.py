@@ -8,7 +8,7 @@ reference's layer signatures.  See DESIGN.md.
 """
 from . import graph                                                   # noqa: F401
 from .graph import CSR, DrainageGraph, synthetic_drainage_network     # noqa: F401
-from .layers import (Dense, GATConv, GCNConv, MixedGAT, NodeEdge,     # noqa: F401
+from .layers import (Dense, DiffusionConv, GATConv, GCNConv, MixedGAT, NodeEdge,     # noqa: F401
                      SpatialBlock, SpatialLayer)
 
 from .emulator import Conv1D, Emulator                                # noqa: F401,E402

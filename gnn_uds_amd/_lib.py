@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # UDS_LIB_PATH: a differently built copy of the same library (kernel experiments: tools/variant_bench.py)
 LIB_PATH = os.environ.get('UDS_LIB_PATH') or os.path.join(_HERE, 'libuds_hip.so')
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
 PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
 
@@ -40,6 +40,9 @@ SYMBOLS = {
                                    _c_ptr]),
     'uds_rowgemm_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
     'uds_rowgemm_pack': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
+    'uds_diffusion_forward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
+    'uds_halo_pack': (_c_int, [_c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_ptr]),
+    'uds_halo_unpack': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr]),
     'uds_remainder_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
     'uds_remainder_pack': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
     'uds_remainder_workspace_bytes': (_c_i64, [_c_i64, _c_i64, _c_i64]),
@@ -362,6 +365,46 @@ def rowgemm_pack(kernel2d):
     out = torch.empty(nbytes // 4, device=kernel2d.device, dtype=torch.float32)
     _check(lib.uds_rowgemm_pack(_dev(kernel2d, 'kernel'), K, fo, out.data_ptr(), _stream()), 'uds_rowgemm_pack')
     return out
+
+
+def diffusion_forward(csr, vals, c0, r, tot, act='tanh'):
+    """out[s, i, q] = act(c0[q] tot[s] + sum_p vals[p, q] r[s, col[p]]): DiffusionConv on the CSR support (uds_diffusion_forward)."""
+    lib = load()
+    S, C = r.shape[0], vals.shape[1]
+    if tuple(vals.shape) != (csr.nnz, C) or tuple(c0.shape) != (C,) or tuple(r.shape) != (S, csr.n_cols) or tuple(tot.shape) != (S,):
+        raise UdsError('diffusion_forward: vals %r c0 %r r %r tot %r for a %d x %d pattern with %d entries'
+                       % (tuple(vals.shape), tuple(c0.shape), tuple(r.shape), tuple(tot.shape), csr.n_rows, csr.n_cols, csr.nnz))
+    out = torch.empty((S, csr.n_rows, C), device=r.device, dtype=torch.float32)
+    if out.numel():
+        _check(lib.uds_diffusion_forward(csr.ptr, _dev(vals, 'vals'), _dev(c0, 'c0'), _dev(r, 'r'), _dev(tot, 'tot'), S, C, ACT[act],
+                                         _dev(out, 'out'), _stream()), 'uds_diffusion_forward')
+    return out
+
+
+def halo_pack(x, e, idx_x, idx_e):
+    """One message buffer (S, nx + ne, F) = [x[:, idx_x] | e[:, idx_e]] (int32 device index tensors): one launch per peer."""
+    lib = load()
+    S, n_x, F = x.shape
+    n_e = e.shape[1]
+    nx, ne = int(idx_x.numel()), int(idx_e.numel())
+    buf = torch.empty((S, nx + ne, F), device=x.device, dtype=torch.float32)
+    if buf.numel():
+        _check(lib.uds_halo_pack(_dev(x, 'x'), n_x, _dev(e, 'e'), n_e, S, F, _dev_i32(idx_x, 'idx_x') if nx else None, nx,
+                                 _dev_i32(idx_e, 'idx_e') if ne else None, ne, _dev(buf, 'buf'), _stream()), 'uds_halo_pack')
+    return buf
+
+
+def halo_unpack(buf, x, e, idx_x, idx_e):
+    """x[:, idx_x], e[:, idx_e] = the two parts of a received message buffer (in place)."""
+    lib = load()
+    S, n_x, F = x.shape
+    nx, ne = int(idx_x.numel()), int(idx_e.numel())
+    if tuple(buf.shape) != (S, nx + ne, F):
+        raise UdsError('halo_unpack: buffer %r for %d + %d rows of %r' % (tuple(buf.shape), nx, ne, tuple(x.shape)))
+    if buf.numel():
+        _check(lib.uds_halo_unpack(_dev(buf, 'buf'), S, F, _dev_i32(idx_x, 'idx_x') if nx else None, nx,
+                                   _dev_i32(idx_e, 'idx_e') if ne else None, ne, _dev(x, 'x'), n_x, _dev(e, 'e'), e.shape[1], _stream()),
+               'uds_halo_unpack')
 
 
 def remainder_pack(rest):

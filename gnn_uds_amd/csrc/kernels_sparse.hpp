@@ -451,4 +451,74 @@ inline hipError_t launch_roll_update(const RollArgs &a, hipStream_t st) {
   return hipGetLastError();
 }
 
+// Message buffers of the graph-sharded block (dist.py; no reference counterpart -- SURVEY.md 8e).  One buffer per peer:
+//   PACK:   buf[s, i, :] = i < nx ? x[s, idx_x[i], :] : e[s, idx_e[i - nx], :]      (own rows a peer holds as halo)
+//   UNPACK: the inverse scatter into the halo rows of x / e.
+// One thread per 16 bytes; rows are F floats (F % 4 == 0), x is (S, n_x, F), e is (S, n_e, F).
+struct HaloArgs {
+  float *x, *e, *buf;
+  const int32_t *idx_x, *idx_e;
+  int64_t n_x, n_e, total;      // total = S * (nx + ne) * F / 4 float4 elements
+  int nx, ne, f4;
+};
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_halo_rows(HaloArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.total) return;
+  const int c = (int)(i % a.f4);
+  const int64_t r = i / a.f4;
+  const int n = a.nx + a.ne, j = (int)(r % n);
+  const int64_t s = r / n;
+  float4 *row = j < a.nx ? reinterpret_cast<float4 *>(a.x + (s * a.n_x + a.idx_x[j]) * (a.f4 * 4))
+                         : reinterpret_cast<float4 *>(a.e + (s * a.n_e + a.idx_e[j - a.nx]) * (a.f4 * 4));
+  float4 *slot = reinterpret_cast<float4 *>(a.buf) + i;
+  if (PACK) *slot = row[c];
+  else row[c] = *slot;
+}
+
+inline hipError_t launch_halo_rows(const HaloArgs &a, bool pack, hipStream_t st) {
+  const unsigned grid = (unsigned)((a.total + 255) / 256);
+  if (pack) hipLaunchKernelGGL(k_halo_rows<true>, dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_halo_rows<false>, dim3(grid), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// spektral DiffusionConv in the reference's dense "mixed" mode (emulator.py:135-138,229): each of the C output channels
+// is ONE DiffuseFeatures filter, H_q = reduce_sum(polyval(theta_q, a_hat) @ x, -1), where tf.math.polyval runs Horner's
+// rule on the ENTRIES of a_hat.  A zero entry therefore gets the constant coefficient c0_q = theta_q[K], and with
+// r[s, j] = sum_f x[s, j, f], tot[s] = sum_j r[s, j]:
+//     H_q[s, i] = c0_q * tot[s] + sum_{p in row i} (polyval(theta_q, a_p) - c0_q) * r[s, col[p]]
+// -- the dense N x N product collapses to the support.  vals[p, q] = polyval(theta_q, a_p) - c0_q is prepared once per
+// parameter update.  One thread per (row, 4 channels), one grid row per snapshot.
+struct DiffusionArgs {
+  const int32_t *rowptr, *col;
+  const float *vals, *c0, *r, *tot;
+  float *out;
+  int n_rows, n_cols, c4, act;
+};
+
+__global__ __launch_bounds__(256) void k_diffusion(DiffusionArgs a) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int i = (int)(idx / a.c4), q = (int)(idx % a.c4), s = blockIdx.y;
+  if (i >= a.n_rows) return;
+  const float4 c = reinterpret_cast<const float4 *>(a.c0)[q];
+  const float t = a.tot[s];
+  float4 acc = make_float4(c.x * t, c.y * t, c.z * t, c.w * t);
+  const float *r = a.r + (int64_t)s * a.n_cols;
+  for (int p = a.rowptr[i]; p < a.rowptr[i + 1]; ++p) {
+    const float rv = r[a.col[p]];
+    const float4 v = reinterpret_cast<const float4 *>(a.vals)[(int64_t)p * a.c4 + q];
+    acc.x += v.x * rv, acc.y += v.y * rv, acc.z += v.z * rv, acc.w += v.w * rv;
+  }
+  acc.x = apply_act(acc.x, a.act), acc.y = apply_act(acc.y, a.act), acc.z = apply_act(acc.z, a.act), acc.w = apply_act(acc.w, a.act);
+  reinterpret_cast<float4 *>(a.out)[((int64_t)s * a.n_rows + i) * a.c4 + q] = acc;
+}
+
+inline hipError_t launch_diffusion(const DiffusionArgs &a, int S, hipStream_t st) {
+  const int64_t per_s = (int64_t)a.n_rows * a.c4;
+  hipLaunchKernelGGL(k_diffusion, dim3((unsigned)((per_s + 255) / 256), (unsigned)S), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 }  // namespace uds

@@ -461,6 +461,44 @@ int uds_flow_balance(const uds_csr_t *inc_n, const float *sign, const float *flo
   return UDS_OK;
 }
 
+int uds_diffusion_forward(const uds_csr_t *csr, const float *vals, const float *c0, const float *r, const float *tot, int64_t S, int64_t C,
+                          int act, float *out, uds_stream_t stream) {
+  UDS_REQUIRE(csr && vals && c0 && r && tot && out, "uds_diffusion_forward: NULL argument");
+  UDS_REQUIRE(S >= 0 && S <= 65535 && C > 0 && C % 4 == 0, "uds_diffusion_forward: S=%lld C=%lld (needs S <= 65535, C %% 4 == 0)", (long long)S,
+              (long long)C);
+  UDS_REQUIRE(act >= 0 && act <= 4, "uds_diffusion_forward: unknown activation %d", act);
+  UDS_REQUIRE(aligned16(vals) && aligned16(c0) && aligned16(out), "uds_diffusion_forward: vals / c0 / out must be 16-byte aligned");
+  if (S == 0 || csr->n_rows == 0) return UDS_OK;
+  uds::DiffusionArgs a{csr->d_rowptr, csr->d_col, vals, c0, r, tot, out, (int)csr->n_rows, (int)csr->n_cols, (int)(C / 4), act};
+  hipError_t e = uds::launch_diffusion(a, (int)S, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_diffusion_forward: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
+static int halo_rows(const char *what, bool pack, float *x, int64_t n_x, float *e, int64_t n_e, int64_t S, int64_t F, const int32_t *idx_x,
+                     int64_t nx, const int32_t *idx_e, int64_t ne, float *buf, uds_stream_t stream) {
+  UDS_REQUIRE(S >= 0 && nx >= 0 && ne >= 0 && n_x >= 0 && n_e >= 0 && F > 0 && F % 4 == 0, "%s: bad sizes (S=%lld nx=%lld ne=%lld F=%lld)", what,
+              (long long)S, (long long)nx, (long long)ne, (long long)F);
+  if (S == 0 || nx + ne == 0) return UDS_OK;
+  UDS_REQUIRE(buf && (nx == 0 || (x && idx_x)) && (ne == 0 || (e && idx_e)), "%s: NULL argument", what);
+  UDS_REQUIRE(aligned16(buf) && aligned16(x) && aligned16(e), "%s: buffers must be 16-byte aligned", what);
+  UDS_REQUIRE(nx + ne < INT32_MAX && S * (nx + ne) * (F / 4) < (int64_t)INT32_MAX * 256, "%s: message too large", what);
+  uds::HaloArgs a{x, e, buf, idx_x, idx_e, n_x, n_e, S * (nx + ne) * (F / 4), (int)nx, (int)ne, (int)(F / 4)};
+  hipError_t err = uds::launch_halo_rows(a, pack, static_cast<hipStream_t>(stream));
+  if (err != hipSuccess) return fail(UDS_EHIP, "%s: launch -> %s", what, hipGetErrorString(err));
+  return UDS_OK;
+}
+
+int uds_halo_pack(const float *x, int64_t n_x, const float *e, int64_t n_e, int64_t S, int64_t F, const int32_t *idx_x, int64_t nx,
+                  const int32_t *idx_e, int64_t ne, float *buf, uds_stream_t stream) {
+  return halo_rows("uds_halo_pack", true, const_cast<float *>(x), n_x, const_cast<float *>(e), n_e, S, F, idx_x, nx, idx_e, ne, buf, stream);
+}
+
+int uds_halo_unpack(const float *buf, int64_t S, int64_t F, const int32_t *idx_x, int64_t nx, const int32_t *idx_e, int64_t ne, float *x,
+                    int64_t n_x, float *e, int64_t n_e, uds_stream_t stream) {
+  return halo_rows("uds_halo_unpack", false, x, n_x, e, n_e, S, F, idx_x, nx, idx_e, ne, const_cast<float *>(buf), stream);
+}
+
 int uds_roll_update(const uds_csr_t *inc_n, const float *sign, const float *span_e, const float *mini_e, const float *scale_in,
                     const float *scale_out, const float *y, int64_t cy, const float *ey, int64_t ce, const float *b, int64_t B, int64_t so,
                     int64_t T, int flood, float *x, float *ex, float *preds, uds_stream_t stream) {

@@ -158,6 +158,11 @@ class HaloExchange:
         self.send_e = {q: t(prob.send_links.get(q, np.zeros(0, np.int64))) for q in self.peers}
         self.recv_n = {q: t(prob.recv_nodes.get(q, np.zeros(0, np.int64))) for q in self.peers}
         self.recv_e = {q: t(prob.recv_links.get(q, np.zeros(0, np.int64))) for q in self.peers}
+        # on the GPU a message is packed / unpacked by ONE launch (uds_halo_pack / uds_halo_unpack) with int32 row lists
+        self.on_gpu = torch.device(device).type == 'cuda'
+        if self.on_gpu:
+            i32 = lambda d: {q: v.to(torch.int32) for q, v in d.items()}
+            self._i32 = (i32(self.send_n), i32(self.send_e), i32(self.recv_n), i32(self.recv_e))
 
     def bytes_per_layer(self, S, F):
         return sum((len(self.send_n[q]) + len(self.send_e[q])) * S * F * 4 for q in self.peers)
@@ -177,15 +182,31 @@ class HaloExchange:
                 ops.append(dist.P2POp(dist.irecv, buf, q, self.group))
             sn, se = self.send_n[q], self.send_e[q]
             if len(sn) + len(se):
-                out = torch.cat([x.index_select(1, sn), e.index_select(1, se)], dim=1).contiguous()
+                out = self.pack(x, e, q)
                 keep.append(out)
                 ops.append(dist.P2POp(dist.isend, out, q, self.group))
         for w in dist.batch_isend_irecv(ops):
             w.wait()
         for q, buf, nn_ in recvs:
-            x.index_copy_(1, self.recv_n[q], buf[:, :nn_])
-            e.index_copy_(1, self.recv_e[q], buf[:, nn_:])
+            self.unpack(buf, x, e, q)
         return x, e
+
+    def pack(self, x, e, q):
+        """The message for peer q: [own node rows it holds as halo | own link rows], (S, n, F)."""
+        if self.on_gpu and x.is_cuda and x.shape[-1] % 4 == 0 and x.is_contiguous() and e.is_contiguous():
+            from . import _lib
+            return _lib.halo_pack(x, e, self._i32[0][q], self._i32[1][q])
+        return torch.cat([x.index_select(1, self.send_n[q]), e.index_select(1, self.send_e[q])], dim=1).contiguous()
+
+    def unpack(self, buf, x, e, q):
+        """Scatter peer q's message into the halo rows it owns (in place)."""
+        if self.on_gpu and x.is_cuda and x.shape[-1] % 4 == 0 and x.is_contiguous() and e.is_contiguous():
+            from . import _lib
+            _lib.halo_unpack(buf, x, e, self._i32[2][q], self._i32[3][q])
+            return
+        nn_ = len(self.recv_n[q])
+        x.index_copy_(1, self.recv_n[q], buf[:, :nn_])
+        e.index_copy_(1, self.recv_e[q], buf[:, nn_:])
 
 
 class ShardedSpatialBlock:

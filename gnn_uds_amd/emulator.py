@@ -11,11 +11,12 @@ names and defaults, emulator.py:48-127), same method names, positional order and
     post_proc_tf, constrain_tf, normalize, set_norm, get_edge_action, get_action     :364-398,680-810
     save / load              weights + norm_*.npy                                    :814-852
 
-What runs where: every layer of the network (embedding / fusion / head Dense, NodeEdge, GAT or GCN, causal dilated
+What runs where: every layer of the network (embedding / fusion / head Dense, NodeEdge, GAT / GCN / Diffusion, causal dilated
 Conv1D, the resnet prefix sum) and the link->node flow balance of post_proc_tf are HIP kernels behind the C ABI.
 The remaining post-processing is elementwise gating / clipping on tensors already in HBM and is written with torch
-tensor ops (device plumbing).  Not built: training (`fit_eval`), `graph_base` > 0, `use_adj`,
-GRU / LSTM, DiffusionConv / GeneralConv -- each raises.
+tensor ops (device plumbing).  Training (`fit_eval`, GradNorm), `graph_base` 1 / 2, GCN and DiffusionConv are built.
+Not built, each raises: `use_adj`, GRU / LSTM temporal nets, training-time dropout, GeneralConv (a sparse-mode-only
+Spektral layer the reference's dense call cannot run either) and the conv=None dense-MLP variant.
 """
 import os
 
@@ -144,8 +145,12 @@ class Emulator(nn.Module):
             self.conv_kind = 'GAT'
         elif 'GCN' in self.conv:
             self.conv_kind = 'GCN'
+        elif 'Diff' in self.conv:                      # emulator.py:135-138
+            self.conv_kind = 'Diffusion'
         else:
-            raise NotImplementedError('conv=%r is not built (GAT and GCN are)' % (conv,))
+            # GeneralConv (emulator.py:146-149) is a sparse-mode-only Spektral layer: the reference's dense mixed-mode call
+            # does not run with it either
+            raise NotImplementedError('conv=%r is not built (GAT, GCN and Diffusion are)' % (conv,))
         if self.use_adj:
             raise NotImplementedError('use_adj (per-step adjacency rewritten by the control action) is not built')
         if self.graph_base not in (0, 1, 2):
@@ -166,9 +171,9 @@ class Emulator(nn.Module):
                 adj = np.asarray(g('adj'))
                 if adj.shape != (self.n_node + self.n_edge,) * 2:
                     raise ValueError('graph_base needs the combined (N+E, N+E) adjacency, got %r' % (adj.shape,))
-                if self.conv_kind == 'GCN':
-                    from .layers import GCNConv
-                    self._base_filter = GCNConv.preprocess(adj)
+                if self.conv_kind != 'GAT':
+                    from .layers import DiffusionConv, GCNConv
+                    self._base_filter = (GCNConv if self.conv_kind == 'GCN' else DiffusionConv).preprocess(adj)
                 else:
                     self._base_filter = csr_from_dense((adj > 0).astype(int), add_self_loops=True)
             else:
@@ -188,9 +193,10 @@ class Emulator(nn.Module):
             edge_adj = np.asarray(g('edge_adj', np.eye(self.n_edge)))
             node_edge = np.asarray(g('node_edge'), dtype=np.float64)
             self.graph = DrainageGraph.from_dense(adj, edge_adj, node_edge, self.edges)
-            if self.conv_kind == 'GCN':
-                from .layers import GCNConv
-                self.filter, self.edge_filter = GCNConv.preprocess(adj), GCNConv.preprocess(edge_adj)     # emulator.py:133-134
+            if self.conv_kind != 'GAT':
+                from .layers import DiffusionConv, GCNConv
+                pre = (GCNConv if self.conv_kind == 'GCN' else DiffusionConv).preprocess
+                self.filter, self.edge_filter = pre(adj), pre(edge_adj)                                   # emulator.py:133-134,137-138
             else:
                 self.filter, self.edge_filter = (adj > 0).astype(int), (edge_adj > 0).astype(int)        # emulator.py:143-145
 
@@ -752,10 +758,15 @@ class Emulator(nn.Module):
         if self.act:
             out.append((name('dense'), self.embed_ae, dense_w))
 
+        # DiffusionConv keeps its coefficients in `channels` DiffuseFeatures sub-layers (one (K + 1,) kernel each): the importer
+        # takes them stacked in creation order as ONE (channels, K + 1) array under '<layer>/kernel:0'
+        conv_name = {'GAT': 'mixed_gat', 'GCN': 'gcn_conv', 'Diffusion': 'diffusion_conv'}[self.conv_kind]
+        conv_w = {'GAT': gat_w, 'GCN': dense_w, 'Diffusion': [('kernel', 'kernel')]}[self.conv_kind]
+
         def spatial(block):
             if self.graph_base:
                 for ly in block.layers:
-                    out.append((name('mixed_gat' if self.conv_kind == 'GAT' else 'gcn_conv'), ly, gat_w if self.conv_kind == 'GAT' else dense_w))
+                    out.append((name(conv_name), ly, conv_w))
                 return
             for ly in block.layers:
                 out.append((name('dense'), ly.dense_xe, dense_w))
@@ -766,8 +777,8 @@ class Emulator(nn.Module):
                     out.append((name('mixed_gat'), ly.gat_x, gat_w))
                     out.append((name('mixed_gat'), ly.gat_e, gat_w))
                 else:
-                    out.append((name('gcn_conv'), ly.gcn_x, dense_w))
-                    out.append((name('gcn_conv'), ly.gcn_e, dense_w))
+                    out.append((name(conv_name), ly.gcn_x, conv_w))
+                    out.append((name(conv_name), ly.gcn_e, conv_w))
 
         def temporal(mods):
             for m in mods:

@@ -265,6 +265,62 @@ class GCNConv(nn.Module):
         return out.reshape(lead + out.shape[-2:])
 
 
+class DiffusionConv(nn.Module):
+    """spektral.layers.DiffusionConv(channels, K=6, activation='tanh') as the reference runs it (`emulator.py:135-138,229`:
+    dense mixed mode, `net(embed_size, activation=...)([x, filter])`): `channels` DiffuseFeatures filters with K + 1
+    coefficients each -- `kernel` (channels, K + 1), row q = theta_q, highest power first, glorot_uniform -- and
+        out[..., q] = act( reduce_sum( polyval(theta_q, a_hat) @ x, -1 ) ),     no bias,
+    where tf.math.polyval is Horner's rule on the ENTRIES of a_hat (element-wise powers).  A zero entry of a_hat therefore
+    takes the constant coefficient theta_q[K]; with r = x.sum(-1) the dense (N, N) product collapses to the support of a_hat
+    plus a rank-one term (uds_diffusion_forward).  a_hat = DiffusionConv.preprocess(adj).  Inference only."""
+
+    def __init__(self, channels, K=6, activation='tanh', in_channels=None, generator=None):
+        super().__init__()
+        self.channels, self.K, self.activation = int(channels), int(K) + 1, activation or 'linear'      # spektral: self.K = K + 1
+        if self.channels % 4:
+            raise ValueError('DiffusionConv: channels must be a multiple of 4, got %d' % self.channels)
+        lim = math.sqrt(6.0 / (2 * self.K))         # glorot_uniform on shape (K + 1,): fan_in = fan_out = K + 1
+        self.kernel = _param((torch.rand((self.channels, self.K), generator=generator) * 2 - 1) * lim)
+        self._cache, self._vals = {}, None
+
+    @staticmethod
+    def preprocess(adj):
+        """normalized_adjacency: D^-1/2 A D^-1/2 (no self loops added), row-sum degrees, inf -> 0 (`emulator.py:137-138`)."""
+        a = np.asarray(adj, dtype=np.float64)
+        deg = a.sum(axis=1)
+        with np.errstate(divide='ignore'):
+            dinv = np.power(deg, -0.5)
+        dinv[np.isinf(dinv)] = 0.0
+        return dinv[:, None] * a * dinv[None, :]
+
+    def _filter(self, a, device):
+        hit = self._cache.get(id(a))
+        if hit is None or hit[0] is not a:
+            dense = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+            csr = csr_from_dense(dense, keep_values=True)
+            hit = self._cache[id(a)] = (a, _lib.CsrHandle(csr), torch.as_tensor(csr.val, dtype=torch.float32, device=device))
+            self._vals = None
+        key = (self.kernel._version, self.kernel.data_ptr(), id(a))
+        if self._vals is None or self._vals[0] != key:
+            av = hit[2].double()[:, None]
+            th = self.kernel.detach().double()
+            v = th[:, 0].expand(av.shape[0], -1)
+            for k in range(1, self.K):                       # Horner, as tf.math.polyval
+                v = v * av + th[:, k]
+            self._vals = (key, (v - th[:, -1]).float().contiguous(), th[:, -1].float().contiguous())
+        return hit[1], self._vals[1], self._vals[2]
+
+    def forward(self, inputs):
+        x, a = inputs
+        if _ag.grad_on(x, self.kernel):
+            raise NotImplementedError('DiffusionConv is built for inference (no backward kernels)')
+        h, vals, c0 = self._filter(a, x.device)
+        xs, lead = _flatten_snapshots(x)
+        r = xs.sum(dim=-1)
+        out = _lib.diffusion_forward(h, vals, c0, r.contiguous(), r.sum(dim=-1).contiguous(), self.activation)
+        return out.reshape(lead + out.shape[-2:])
+
+
 class NodeEdge(nn.Module):
     """`NodeEdge(inci)` (`emulator.py:27-45`): out = (weight * inci + bias) @ x, inci (R, M).
 
@@ -375,10 +431,10 @@ class SpatialLayer(nn.Module):
     def __init__(self, graph, embed_size, activation='relu', fx=None, fe=None, sparse_params=None, net=None,
                  generator=None, precision='bf16x3', conv='GAT', filters=None):
         super().__init__()
-        if conv not in ('GAT', 'GCN'):
-            raise NotImplementedError('conv=%r: GAT and GCN are built' % (conv,))
-        if conv == 'GCN' and filters is None:
-            raise ValueError("conv='GCN' needs filters=(GCNConv.preprocess(adj), GCNConv.preprocess(edge_adj))")
+        if conv not in ('GAT', 'GCN', 'Diffusion'):
+            raise NotImplementedError('conv=%r: GAT, GCN and Diffusion are built' % (conv,))
+        if conv != 'GAT' and filters is None:
+            raise ValueError("conv=%r needs filters=(preprocess(adj), preprocess(edge_adj)) of its layer class" % (conv,))
         self.conv, self.filters = conv, filters
         if precision not in _lib.PRECISION_FLAGS:
             raise ValueError("precision must be 'bf16x3' (fused kernel, split-bf16 MFMA, fp32 accumulate) or 'fp32' "
@@ -405,9 +461,12 @@ class SpatialLayer(nn.Module):
             self.gat_x = GATConv(self.d, activation=activation, in_channels=fx + self.h, generator=g)   # :229
             self.gat_e = GATConv(self.d, activation=activation, in_channels=fe + self.h, generator=g)   # :230
             self.gat_x.precision = self.gat_e.precision = precision
-        else:
+        elif conv == 'GCN':
             self.gcn_x = GCNConv(self.d, activation=activation, in_channels=fx + self.h, generator=g)
             self.gcn_e = GCNConv(self.d, activation=activation, in_channels=fe + self.h, generator=g)
+        else:
+            self.gcn_x = DiffusionConv(self.d, activation=activation, generator=g)        # emulator.py:229-230 with net = DiffusionConv
+            self.gcn_e = DiffusionConv(self.d, activation=activation, generator=g)
         self._net = net
         self._packed = None       # (parameter versions, packed bf16 hi/lo fragments) of the four GEMM kernels
         self.last_path = None     # which kernels the last forward ran: 'fused', 'fused+remainder', 'unfused' (tests, bench)
@@ -472,7 +531,7 @@ class SpatialLayer(nn.Module):
         es, lead_e = _flatten_snapshots(e)
         xbs = None if xb is None else _flatten_snapshots(xb)[0]
         ebs = None if eb is None else _flatten_snapshots(eb)[0]
-        if self.conv == 'GCN':     # a_hat @ ([x | agg] W) + b: unfused composition of the Dense / NodeEdge / spmm kernels
+        if self.conv != 'GAT':     # GCN a_hat @ ([x | agg] W) + b, or Diffusion: unfused composition of the Dense / NodeEdge / sparse kernels
             x_e, e_x = self.dense_xe(es), self.dense_ex(xs)
             ox = self.gcn_x([torch.cat([xs, self.node_edge_n(x_e)], dim=-1), self.filters[0]])
             oe = self.gcn_e([torch.cat([es, self.node_edge_e(e_x)], dim=-1), self.filters[1]])
@@ -544,11 +603,11 @@ class GraphBaseBlock(nn.Module):
     def __init__(self, n_node, n_edge, filt, embed_size, n_sp_layer, activation='relu', f_in=None, generator=None, conv='GAT',
                  precision='bf16x3'):
         super().__init__()
-        if conv not in ('GAT', 'GCN'):
-            raise NotImplementedError('conv=%r: GAT and GCN are built' % (conv,))
+        if conv not in ('GAT', 'GCN', 'Diffusion'):
+            raise NotImplementedError('conv=%r: GAT, GCN and Diffusion are built' % (conv,))
         self.n_node, self.n_edge, self.filt, self.conv = int(n_node), int(n_edge), filt, conv
         f_in = int(embed_size) if f_in is None else int(f_in)
-        mk = GATConv if conv == 'GAT' else GCNConv
+        mk = {'GAT': GATConv, 'GCN': GCNConv, 'Diffusion': DiffusionConv}[conv]
         self.layers = nn.ModuleList([mk(embed_size, activation=activation, in_channels=(f_in if i == 0 else embed_size), generator=generator)
                                      for i in range(n_sp_layer)])
         for ly in self.layers:

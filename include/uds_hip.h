@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 8
+#define UDS_ABI_VERSION 9
 
 enum {
   UDS_OK = 0,
@@ -110,6 +110,25 @@ int uds_rowgemm_forward(const float *x, int64_t B, int64_t T, int64_t R, int64_t
 int uds_rowgemm_forward_cat(const float *x, int64_t F1, const float *x2, int64_t F2, int64_t B, int64_t T, int64_t R,
                             const void *packed, const float *bias, int64_t taps, int64_t dil, int64_t f_out, int act,
                             float *out, int64_t ldo, int64_t col0, uds_stream_t stream);
+
+/* spektral DiffusionConv as the reference runs it (dense mixed mode, emulator.py:135-138,229): channel q is
+ * reduce_sum(polyval(theta_q, a_hat) @ x, -1) with tf.math.polyval applied to the ENTRIES of a_hat, so zero entries take the
+ * constant coefficient c0[q] and the N x N product collapses to the CSR support:
+ *   out[s, i, q] = act( c0[q] * tot[s] + sum_{p in row i} vals[p, q] * r[s, col[p]] ),
+ * r[s, j] = sum_f x[s, j, f] (S, n_cols), tot[s] = sum_j r[s, j] (S), vals[p, q] = polyval(theta_q, a_p) - c0[q] (nnz, C),
+ * out (S, n_rows, C), C % 4 == 0. */
+int uds_diffusion_forward(const uds_csr_t *csr, const float *vals, const float *c0, const float *r, const float *tot,
+                          int64_t S, int64_t C, int act, float *out, uds_stream_t stream);
+
+/* Message buffers of the graph-sharded spatial block (one 200k-node network node-cut over the GPUs; the reference holds
+ * whole graphs on one device, SURVEY.md F5 / 8e -- the exchange itself is torch.distributed isend / irecv over RCCL).
+ *   pack:   buf[s, i, :] = i < nx ? x[s, idx_x[i], :] : e[s, idx_e[i - nx], :]     one buffer per peer, node rows then link rows
+ *   unpack: the inverse scatter into rows idx_x of x and idx_e of e (the halo rows the peer owns).
+ * x (S, n_x, F), e (S, n_e, F), buf (S, nx + ne, F), F % 4 == 0; idx_* are int32 device arrays of LOCAL row numbers. */
+int uds_halo_pack(const float *x, int64_t n_x, const float *e, int64_t n_e, int64_t S, int64_t F, const int32_t *idx_x,
+                  int64_t nx, const int32_t *idx_e, int64_t ne, float *buf, uds_stream_t stream);
+int uds_halo_unpack(const float *buf, int64_t S, int64_t F, const int32_t *idx_x, int64_t nx, const int32_t *idx_e,
+                    int64_t ne, float *x, int64_t n_x, float *e, int64_t n_e, uds_stream_t stream);
 
 /* Dense remainder of a TRAINED NodeEdge layer.  The reference's layer is `(w * inci + b) @ x` with w, b dense trainable
  * (R, M) matrices (emulator.py:34-45); on the incidence support that is the CSR aggregation of the fused kernel, off the

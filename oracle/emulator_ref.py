@@ -64,16 +64,17 @@ def config(args):
     c.hmax = np.asarray(g('hmax', np.full(c.n_node, 1.5)), dtype=np.float64)
     c.hmin = np.asarray(g('hmin', np.zeros(c.n_node)), dtype=np.float64)
     conv = g('conv', 'GAT')
-    c.conv = 'GCN' if 'GCN' in conv else 'GAT'
+    c.conv = 'GCN' if 'GCN' in conv else 'Diffusion' if 'Diff' in conv else 'GAT'     # emulator.py:131-142
     c.resnet = bool(g('resnet', False))
     c.roll = int(g('roll', 0))
     c.graph_base = int(g('graph_base', 0))                # 0: node graph + line graph; 1 / 2: one graph over nodes AND links (:220-223)
     if c.conv == 'GAT':                                   # emulator.py:143-145
         c.filter = (c.adj > 0).astype(np.float64)
         c.edge_filter = (c.edge_adj > 0).astype(np.float64)
-    else:                                                 # emulator.py:133-134
-        c.filter = OD.gcn_preprocess(torch.from_numpy(c.adj.astype(np.float64))).numpy()
-        c.edge_filter = OD.gcn_preprocess(torch.from_numpy(c.edge_adj.astype(np.float64))).numpy()
+    else:                                                 # emulator.py:133-134 / :137-138
+        pre = OD.gcn_preprocess if c.conv == 'GCN' else OD.diffusion_preprocess
+        c.filter = pre(torch.from_numpy(c.adj.astype(np.float64))).numpy()
+        c.edge_filter = pre(torch.from_numpy(c.edge_adj.astype(np.float64))).numpy()
     return c
 
 
@@ -101,10 +102,15 @@ def init_params(args, seed=1, bias_scale=0.05):
     def spatial(fx, fe):
         if c.graph_base:                                      # one conv over concat([x, e], axis=-2) (emulator.py:220-223,273-276)
             assert fx == fe, 'graph_base concatenates node and link rows: equal widths needed'
+            if c.conv == 'Diffusion':
+                return {'gat': {'theta': (torch.rand(d, 7, generator=g, dtype=torch.float64) * 2 - 1) * math.sqrt(6.0 / 14)}}
             return {'gat': {'kernel': _glorot(g, (fx, 1, d)), 'attn_kernel_self': _glorot(g, (d, 1, 1)),
                             'attn_kernel_neighs': _glorot(g, (d, 1, 1)), 'bias': bias(d)}}
-        conv = lambda f: {'kernel': _glorot(g, (f, 1, d)), 'attn_kernel_self': _glorot(g, (d, 1, 1)),
-                          'attn_kernel_neighs': _glorot(g, (d, 1, 1)), 'bias': bias(d)}
+        if c.conv == 'Diffusion':      # `d` DiffuseFeatures filters of K + 1 = 7 coefficients each (spektral default K = 6), no bias
+            conv = lambda f: {'theta': (torch.rand(d, 7, generator=g, dtype=torch.float64) * 2 - 1) * math.sqrt(6.0 / 14)}
+        else:
+            conv = lambda f: {'kernel': _glorot(g, (f, 1, d)), 'attn_kernel_self': _glorot(g, (d, 1, 1)),
+                              'attn_kernel_neighs': _glorot(g, (d, 1, 1)), 'bias': bias(d)}
         return {'dense_xe': dense(fe, h), 'dense_ex': dense(fx, h),
                 'node_edge_n': {'weight': torch.randn(c.n_node, c.n_edge, generator=g, dtype=torch.float64) * 0.05,
                                 'bias': torch.zeros(c.n_node, c.n_edge, dtype=torch.float64)},
@@ -163,8 +169,12 @@ def conv1d_causal(x, kernel, bias, dilation, act):
 def _spatial_layer(x, e, p, c, dtype):
     q = {'xe_k': p['dense_xe']['kernel'], 'xe_b': p['dense_xe']['bias'], 'ex_k': p['dense_ex']['kernel'],
          'ex_b': p['dense_ex']['bias'], 'ne_n_w': p['node_edge_n']['weight'], 'ne_n_b': p['node_edge_n']['bias'],
-         'ne_e_w': p['node_edge_e']['weight'], 'ne_e_b': p['node_edge_e']['bias'],
-         'gx_k': p['gat_x']['kernel'], 'gx_as': p['gat_x']['attn_kernel_self'], 'gx_an': p['gat_x']['attn_kernel_neighs'],
+         'ne_e_w': p['node_edge_e']['weight'], 'ne_e_b': p['node_edge_e']['bias']}
+    if c.conv == 'Diffusion':
+        q.update(gx_theta=p['gat_x']['theta'], ge_theta=p['gat_e']['theta'])
+        return OD.spatial_layer_dense(x, e, q, torch.from_numpy(c.filter).to(dtype), torch.from_numpy(c.edge_filter).to(dtype),
+                                      torch.from_numpy(c.node_edge).to(dtype), c.activation, c.conv)
+    q = {**q, 'gx_k': p['gat_x']['kernel'], 'gx_as': p['gat_x']['attn_kernel_self'], 'gx_an': p['gat_x']['attn_kernel_neighs'],
          'gx_b': p['gat_x']['bias'], 'ge_k': p['gat_e']['kernel'], 'ge_as': p['gat_e']['attn_kernel_self'],
          'ge_an': p['gat_e']['attn_kernel_neighs'], 'ge_b': p['gat_e']['bias']}
     return OD.spatial_layer_dense(x, e, q, torch.from_numpy(c.filter).to(dtype), torch.from_numpy(c.edge_filter).to(dtype),
@@ -194,6 +204,10 @@ def forward(args, params, X, B, E, AE=None):
         for p in layers:
             if c.graph_base:
                 q = p['gat']
+                if c.conv == 'Diffusion':
+                    z = OD.diffusion_conv_dense(torch.cat([xs, es], dim=-2), torch.from_numpy(c.filter).to(dt), q['theta'], c.activation)
+                    xs, es = z[:, :c.n_node], z[:, c.n_node:]
+                    continue
                 z = OD.gat_conv_dense(torch.cat([xs, es], dim=-2), torch.from_numpy(c.filter).to(dt), q['kernel'], q['attn_kernel_self'],
                                       q['attn_kernel_neighs'], q['bias'], c.activation)
                 xs, es = z[:, :c.n_node], z[:, c.n_node:]

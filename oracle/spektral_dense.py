@@ -92,6 +92,34 @@ def gcn_conv_dense(x, a_hat, kernel, bias, act='relu'):
     return activation(act)(out)
 
 
+def diffusion_preprocess(adj):
+    """spektral DiffusionConv.preprocess = normalized_adjacency(A): D^-1/2 A D^-1/2, NO self loops added, row-sum degrees,
+    inf -> 0 (`emulator.py:137-138`; restated from Spektral 1.3.1 utils/convolution.py -- unverifiable offline)."""
+    a = adj.to(torch.float64)
+    deg = a.sum(dim=1)
+    dinv = deg.pow(-0.5)
+    dinv[torch.isinf(dinv)] = 0.0
+    return dinv[:, None] * a * dinv[None, :]
+
+
+def diffusion_conv_dense(x, a_hat, kernel, act='tanh'):
+    """spektral DiffusionConv.call (`emulator.py:135-138,229`), restated from Spektral 1.3.1 diffusion_conv.py: `channels`
+    DiffuseFeatures filters, each with K + 1 coefficients theta (kernel[q], highest power first), each producing ONE column:
+        D_q = tf.math.polyval(theta_q, a_hat)        -- Horner's rule on the ENTRIES of a_hat (element-wise powers, not
+                                                        matrix powers): D_q[i, j] = sum_k theta_q[k] * a_hat[i, j]^(K - k);
+                                                        an entry that is zero in a_hat gets the constant term theta_q[K]
+        H_q = reduce_sum(D_q @ x, axis=-1)           -- summed over the input features
+    out = act(concat_q H_q), no bias.  x (S, N, F), a_hat (N, N), kernel (channels, K + 1) -> (S, N, channels)."""
+    a = a_hat.to(x.dtype)
+    cols = []
+    for q in range(kernel.shape[0]):
+        d = torch.zeros_like(a) + kernel[q, 0]
+        for k in range(1, kernel.shape[1]):
+            d = d * a + kernel[q, k]
+        cols.append((d @ x).sum(dim=-1, keepdim=True))
+    return activation(act)(torch.cat(cols, dim=-1))
+
+
 def node_edge_dense(x, inci, w, b):
     """NodeEdge.call (`emulator.py:42-45`): (w * inci + b) @ x, `inci:(R,M)`, `x:(...,M,F)`."""
     mat = w * inci.to(x.dtype) + b
@@ -120,6 +148,9 @@ def spatial_layer_dense(x, e, p, adj_filter, edge_filter, node_edge, act='relu',
     elif conv == 'GCN':
         x_new = gcn_conv_dense(xc, adj_filter, p['gx_k'][:, 0, :], p['gx_b'], act)
         e_new = gcn_conv_dense(ec, edge_filter, p['ge_k'][:, 0, :], p['ge_b'], act)
+    elif conv == 'Diffusion':
+        x_new = diffusion_conv_dense(xc, adj_filter, p['gx_theta'], act)
+        e_new = diffusion_conv_dense(ec, edge_filter, p['ge_theta'], act)
     else:
         raise ValueError(conv)
     return x_new, e_new

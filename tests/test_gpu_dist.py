@@ -125,7 +125,8 @@ class _MailboxExchange(D.HaloExchange):
         for q in self.peers:
             sn, se = self.send_n[q], self.send_e[q]
             if len(sn) + len(se):
-                out = torch.cat([x.index_select(1, sn), e.index_select(1, se)], dim=1).contiguous()
+                out = self.pack(x, e, q)                      # uds_halo_pack
+                assert torch.equal(out, torch.cat([x.index_select(1, sn), e.index_select(1, se)], dim=1))
                 ev = torch.cuda.Event()
                 ev.record(st)
                 self.mail[(self.prob.rank, q)].put((out, ev))
@@ -134,8 +135,8 @@ class _MailboxExchange(D.HaloExchange):
             if nn_ + len(self.recv_e[q]):
                 buf, ev = self.mail[(q, self.prob.rank)].get(timeout=120)
                 st.wait_event(ev)
-                x.index_copy_(1, self.recv_n[q], buf[:, :nn_])
-                e.index_copy_(1, self.recv_e[q], buf[:, nn_:])
+                self.unpack(buf, x, e, q)                     # uds_halo_unpack
+                assert torch.equal(x[:, self.recv_n[q]], buf[:, :nn_]) and torch.equal(e[:, self.recv_e[q]], buf[:, nn_:])
                 buf.record_stream(st)
         return x, e
 

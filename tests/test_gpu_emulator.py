@@ -152,6 +152,19 @@ def test_network_forward_gcn_and_plain_variants(dev, networks):
     close(y, ry, TOL_FWD['fp32']); close(ey, rey, TOL_FWD['fp32'])
 
 
+@pytest.mark.parametrize('graph_base', [0, 1])
+def test_network_forward_diffusion(dev, networks, graph_base):
+    """conv = Diffusion (emulator.py:135-138) through the whole network, two-graph and graph_base forms (parity unpinned)."""
+    args, params, emul, _ = _setup(networks, 'astlingen', dev, conv='Diffusion', act=bool(graph_base), if_flood=0, seq_in=4, seq_out=4,
+                                   embed_size=32, hidden_dim=32, n_sp_layer=2, n_tp_layer=1, graph_base=graph_base)
+    X, Bd, Ex, a = _inputs(args, 2)           # graph_base stacks node and link rows: equal widths need the action embedding
+    AE = OE.get_edge_action(OE.config(args), a) if graph_base else None
+    ry, rey = OE.forward(args, params, X, Bd, Ex, AE)
+    f = lambda t: t.float().to(dev)
+    y, ey = emul(f(X), f(Bd), f(Ex), emul.get_edge_action(f(a)) if graph_base else None)
+    close(y, ry, TOL_FWD['fp32']); close(ey, rey, TOL_FWD['fp32'])
+
+
 @pytest.mark.parametrize('variant', ['edge_fusion_act', 'pumps_offset_tide', 'plain'])
 def test_predict_tf(dev, networks, variant):
     """predict_tf (emulator.py:604-641) incl. post_proc_tf / constrain_tf branches; raw states in, physical units out."""

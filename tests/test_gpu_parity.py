@@ -132,6 +132,29 @@ def test_gcn_conv(dev, networks):
     close(layer([x.float().to(dev), ah]), ref)
 
 
+@pytest.mark.parametrize('name,act', [('astlingen', 'tanh'), ('shunqing', 'relu')])
+def test_diffusion_conv(dev, networks, name, act):
+    """DiffusionConv (emulator.py:135-138): uds_diffusion_forward on the support of the normalised adjacency against the
+    dense element-wise-polyval oracle (parity unpinned: Spektral 1.3.1 restated from memory, see the oracle's docstring)."""
+    e = np.array(networks[name]['edges'])
+    adj = U.graph.get_adj(e)
+    ah = U.DiffusionConv.preprocess(adj)
+    assert np.allclose(ah, OD.diffusion_preprocess(torch.from_numpy(adj)).numpy(), atol=1e-15)
+    g = torch.Generator().manual_seed(4)
+    n = adj.shape[0]
+    x = rnd(g, 3, n, 24) - 0.3
+    layer = U.DiffusionConv(16, activation=act, generator=g).to(dev)
+    assert tuple(layer.kernel.shape) == (16, 7)                  # K = 6 -> 7 coefficients per output channel
+    ref = OD.diffusion_conv_dense(x, torch.from_numpy(ah), layer.kernel.detach().double().cpu(), act)
+    close(layer([x.float().to(dev), ah]), ref)
+    out4 = layer([x.float().to(dev).reshape(1, 3, n, 24), ah])     # leading dims kept
+    assert out4.shape == (1, 3, n, 16)
+    with torch.no_grad():
+        layer.kernel.mul_(0.5)                                     # the prepared polynomial values follow the parameter
+    ref = OD.diffusion_conv_dense(x, torch.from_numpy(ah), layer.kernel.detach().double().cpu(), act)
+    close(layer([x.float().to(dev), ah]), ref)
+
+
 @pytest.mark.parametrize('trained_bias', [False, True])
 def test_node_edge_dense_parameters(dev, networks, trained_bias):
     net = networks['shunqing']

@@ -135,3 +135,34 @@ def test_gcn_preprocess_and_conv():
     ref = OD.gcn_conv_dense(x, ah, k, b)
     rowptr, col, val = OS.csr_from_dense(ah.numpy())
     assert torch.allclose(ref, OS.gcn_conv_csr(x, rowptr, col, val, k, b), atol=1e-14)
+
+
+def test_diffusion_conv_known_answer_and_support_collapse():
+    """DiffusionConv as the reference's dense call computes it (oracle/spektral_dense.py): element-wise polyval, feature sum.
+    (1) hand-computed 2-node case; (2) the collapse the HIP kernel relies on -- zero entries of a_hat take the constant
+    coefficient, so the dense product equals c0 * total + a sum over the support -- on a random graph with an isolated node."""
+    a = torch.tensor([[0., 1], [1, 0]], dtype=torch.float64)
+    ah = OD.diffusion_preprocess(a)
+    assert torch.equal(ah, a)                                   # degrees 1: D^-1/2 A D^-1/2 = A, no self loops
+    theta = torch.tensor([[2.0, 3.0, 5.0]], dtype=torch.float64)             # p(t) = 2 t^2 + 3 t + 5: p(0) = 5, p(1) = 10
+    x = torch.tensor([[[1.0, 2.0], [3.0, 4.0]]], dtype=torch.float64)       # feature sums 3 and 7
+    out = OD.diffusion_conv_dense(x, ah, theta, 'linear')
+    assert torch.allclose(out, torch.tensor([[[5 * 3 + 10 * 7.0], [10 * 3 + 5 * 7.0]]], dtype=torch.float64))
+    g = torch.Generator().manual_seed(3)
+    n = 9
+    adj = (torch.rand(n, n, generator=g) < 0.3).double()
+    adj = ((adj + adj.T) > 0).double()
+    adj.fill_diagonal_(0)
+    adj[4], adj[:, 4] = 0, 0                                     # isolated node: degree 0 -> inf -> 0
+    ah = OD.diffusion_preprocess(adj)
+    assert torch.isfinite(ah).all() and float(ah[4].abs().sum()) == 0
+    theta = torch.rand(8, 7, generator=g, dtype=torch.float64) - 0.5
+    x = torch.rand(3, n, 5, generator=g, dtype=torch.float64)
+    ref = OD.diffusion_conv_dense(x, ah, theta, 'tanh')
+    r = x.sum(-1)
+    poly = torch.zeros(n, n, 8, dtype=torch.float64) + theta[:, 0]
+    for k in range(1, 7):
+        poly = poly * ah[..., None] + theta[:, k]
+    vals = (poly - theta[:, -1]) * (ah != 0)[..., None]
+    got = torch.tanh(theta[:, -1] * r.sum(-1)[:, None, None] + torch.einsum('ijq,sj->siq', vals, r))
+    assert torch.allclose(ref, got, atol=1e-13)

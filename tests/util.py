@@ -125,6 +125,9 @@ def load_emulator(emul, p, device):
     def spatial(block, layers):
         for layer, q in zip(block.layers, layers):
             if 'gat' in q:                      # graph_base: one conv over the stacked node + link rows
+                if 'theta' in q['gat']:
+                    layer.kernel.data = f32(q['gat']['theta'])
+                    continue
                 layer.kernel.data = f32(q['gat']['kernel'])
                 layer.attn_kernel_self.data, layer.attn_kernel_neighs.data = f32(q['gat']['attn_kernel_self']), f32(q['gat']['attn_kernel_neighs'])
                 layer.bias.data = f32(q['gat']['bias'])
@@ -134,6 +137,9 @@ def load_emulator(emul, p, device):
                 ne.weight.data, ne.bias.data = f32(q[key]['weight']), f32(q[key]['bias'])
             convs = (layer.gat_x, layer.gat_e) if layer.conv == 'GAT' else (layer.gcn_x, layer.gcn_e)
             for m, key in zip(convs, ('gat_x', 'gat_e')):
+                if layer.conv == 'Diffusion':
+                    m.kernel.data = f32(q[key]['theta'])
+                    continue
                 if layer.conv == 'GAT':
                     m.kernel.data = f32(q[key]['kernel'])
                     m.attn_kernel_self.data, m.attn_kernel_neighs.data = f32(q[key]['attn_kernel_self']), f32(q[key]['attn_kernel_neighs'])
