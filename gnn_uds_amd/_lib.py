@@ -40,6 +40,7 @@ SYMBOLS = {
                                    _c_ptr]),
     'uds_rowgemm_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
     'uds_rowgemm_pack': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
+    'uds_gat_aggregate_masked': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_diffusion_forward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_halo_pack': (_c_int, [_c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_ptr]),
     'uds_halo_unpack': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr]),
@@ -590,10 +591,22 @@ def gat_forward(handle, xa, kernel, a_self, a_nbr, bias=None, act='relu', xb=Non
     return out
 
 
-def gat_aggregate(handle, hx, s_self, s_nbr, bias=None, act='relu'):
-    """Attention softmax + neighbour sum of a GATConv from precomputed hx (S,n,d), s_self / s_nbr (S,n)."""
+def gat_aggregate(handle, hx, s_self, s_nbr, bias=None, act='relu', edge_mask=None):
+    """Attention softmax + neighbour sum of a GATConv from precomputed hx (S,n,d), s_self / s_nbr (S,n).
+    edge_mask (S, nnz): per-snapshot 0/1 over the pattern's entries (`use_adj`; the diagonal always takes part)."""
     lib = load()
     S, n, d = hx.shape
+    if edge_mask is not None:
+        if tuple(edge_mask.shape) != (S, handle.nnz):
+            raise UdsError('gat_aggregate: edge_mask %r for %d snapshots of a %d-entry pattern' % (tuple(edge_mask.shape), S, handle.nnz))
+        if n != handle.n_rows or tuple(s_self.shape) != (S, n) or tuple(s_nbr.shape) != (S, n):
+            raise UdsError('gat_aggregate: hx %r does not match a %d-row pattern' % (tuple(hx.shape), handle.n_rows))
+        out = torch.empty_like(hx)
+        if out.numel():
+            _check(lib.uds_gat_aggregate_masked(handle.ptr, _dev(hx, 'hx'), _dev(s_self, 's_self'), _dev(s_nbr, 's_nbr'), _dev(bias, 'bias', True),
+                                                _dev(edge_mask, 'edge_mask'), S, d, ACT[act], _dev(out, 'out'), _stream()),
+                   'uds_gat_aggregate_masked')
+        return out
     if n != handle.n_rows or tuple(s_self.shape) != (S, n) or tuple(s_nbr.shape) != (S, n):
         raise UdsError('gat_aggregate: hx %r, s_self %r, s_nbr %r do not match a %d-row pattern' %
                        (tuple(hx.shape), tuple(s_self.shape), tuple(s_nbr.shape), handle.n_rows))

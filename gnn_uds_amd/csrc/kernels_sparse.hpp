@@ -297,6 +297,57 @@ __global__ __launch_bounds__(256) void k_gat_aggregate_g(GatArgs a) {
   }
 }
 
+// k_gat_aggregate with a PER-SNAPSHOT edge mask (`use_adj`, emulator.py:268-271,343-362: the control action rewrites
+// adjacency entries of the actuated links per time step; GAT casts the result to int, so a setting < 1 removes the entry).
+// mask (S, nnz) floats: entry p of snapshot s takes part iff mask != 0 or it is the diagonal (spektral sets the diagonal
+// to one after the rewrite: tf.linalg.set_diag).  A masked logit is -10e9 in the reference: exp underflows to exactly 0.
+__global__ __launch_bounds__(256) void k_gat_aggregate_masked(GatArgs a, const float *__restrict__ mask, int64_t nnz) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per_snap = (int64_t)a.n * a.d4;
+  if (t >= per_snap) return;
+  const int s = blockIdx.y;
+  const int c = (int)(t % a.d4);
+  const int i = a.order[t / a.d4];
+  const int beg = a.rowptr[i], end = a.rowptr[i + 1];
+  const float *sn = a.s_nbr + (int64_t)s * a.n;
+  const float *mk = mask + (int64_t)s * nnz;
+  const float ss = a.s_self[(int64_t)s * a.n + i];
+  float m = -INFINITY;
+  for (int p = beg; p < end; ++p) {
+    const int j = a.col[p];
+    if (mk[p] != 0.0f || j == i) m = fmaxf(m, leaky02(ss + sn[j]));
+  }
+  const float4 *hx4 = reinterpret_cast<const float4 *>(a.hx) + (int64_t)s * a.n * a.d4 + c;
+  float den = 0.0f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = beg; p < end; ++p) {
+    const int j = a.col[p];
+    if (!(mk[p] != 0.0f || j == i)) continue;
+    const float w = expf(leaky02(ss + sn[j]) - m);
+    const float4 hv = hx4[(int64_t)j * a.d4];
+    den += w;
+    acc.x = fmaf(w, hv.x, acc.x);
+    acc.y = fmaf(w, hv.y, acc.y);
+    acc.z = fmaf(w, hv.z, acc.z);
+    acc.w = fmaf(w, hv.w, acc.w);
+  }
+  const float inv = den > 0.0f ? 1.0f / den : 0.0f;
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.bias) b = reinterpret_cast<const float4 *>(a.bias)[c];
+  float4 o;
+  o.x = apply_act(fmaf(acc.x, inv, b.x), a.act);
+  o.y = apply_act(fmaf(acc.y, inv, b.y), a.act);
+  o.z = apply_act(fmaf(acc.z, inv, b.z), a.act);
+  o.w = apply_act(fmaf(acc.w, inv, b.w), a.act);
+  reinterpret_cast<float4 *>(a.out)[((int64_t)s * a.n + i) * a.d4 + c] = o;
+}
+
+inline hipError_t launch_gat_aggregate_masked(const GatArgs &a, const float *mask, int64_t nnz, hipStream_t st) {
+  const int64_t per_snap = (int64_t)a.n * a.d4;
+  hipLaunchKernelGGL(k_gat_aggregate_masked, dim3((unsigned)((per_snap + 255) / 256), (unsigned)a.S), dim3(256), 0, st, a, mask, nnz);
+  return hipGetLastError();
+}
+
 inline hipError_t launch_gat_aggregate(const GatArgs &a, hipStream_t st) {
   int G, NC;
   group_shape(a.d4, G, NC);

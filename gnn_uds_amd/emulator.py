@@ -15,8 +15,9 @@ What runs where: every layer of the network (embedding / fusion / head Dense, No
 Conv1D, the resnet prefix sum) and the link->node flow balance of post_proc_tf are HIP kernels behind the C ABI.
 The remaining post-processing is elementwise gating / clipping on tensors already in HBM and is written with torch
 tensor ops (device plumbing).  Training (`fit_eval`, GradNorm), `graph_base` 1 / 2, GCN and DiffusionConv are built.
-Not built, each raises: `use_adj`, GRU / LSTM temporal nets, training-time dropout, GeneralConv (a sparse-mode-only
-Spektral layer the reference's dense call cannot run either) and the conv=None dense-MLP variant.
+`use_adj` (per-time-step adjacency rewritten by the control action) is built for GAT as a mask over the CSR entries.
+Not built, each raises: GRU / LSTM temporal nets, training-time dropout, `use_adj` with GCN / Diffusion or under autograd,
+GeneralConv (a sparse-mode-only Spektral layer the reference's dense call cannot run either) and the conv=None dense-MLP variant.
 """
 import os
 
@@ -151,8 +152,9 @@ class Emulator(nn.Module):
             # GeneralConv (emulator.py:146-149) is a sparse-mode-only Spektral layer: the reference's dense mixed-mode call
             # does not run with it either
             raise NotImplementedError('conv=%r is not built (GAT, GCN and Diffusion are)' % (conv,))
-        if self.use_adj:
-            raise NotImplementedError('use_adj (per-step adjacency rewritten by the control action) is not built')
+        if self.use_adj and self.conv_kind != 'GAT':
+            raise NotImplementedError('use_adj is built for conv=GAT (GCN / Diffusion re-normalise the rewritten adjacency per time step: '
+                                      'emulator.py:355-358)')
         if self.graph_base not in (0, 1, 2):
             raise ValueError('graph_base must be 0, 1 (node-based) or 2 (edge-based), got %r' % (self.graph_base,))
         if recurrent not in ('Conv1D', None, 'None', False):
@@ -263,9 +265,16 @@ class Emulator(nn.Module):
         self.e_out_layer = Dense(self.e_out, 'tanh', in_features=d, generator=gen, precision=pr)              # :336
 
     # ------------------------------------------------------------------ network forward (build_network)
-    def forward(self, X, B, E, AE=None):
+    def forward(self, X, B, E, AE=None, ADJ=None):
+        """ADJ: the per-time-step node adjacency of `use_adj` (emulator.py:178-180,268-271; block 2 only): the edge mask
+        (B, T_out, nnz) of `get_adj_action`, or the reference's dense (B, T_out, n, n) integer array (small networks)."""
         nb = X.shape[0]
         c = lambda t: t.contiguous()
+        adj_mask = None
+        if ADJ is not None:
+            if not (self.act and self.use_adj):
+                raise ValueError('ADJ given but the model was built without act + use_adj')
+            adj_mask = self._adj_mask_from(ADJ, X.device).reshape(nb * self.seq_out, -1)
         # the embedding is linear, its last step is kept as the residual, then the activation is applied (:198-201):
         # two launches of the same GEMM (same per-row arithmetic), one with and one without the activation
         x_lin_last = self.embed_x(c(X[:, -1:]), 'linear')
@@ -275,10 +284,13 @@ class Emulator(nn.Module):
         b = self.embed_b(c(B))
         ae = self.embed_ae(c(AE)) if self.act else None
 
-        def spatial(block, x, e, xb=None, eb=None):
+        def spatial(block, x, e, xb=None, eb=None, mask=None):
             T = x.shape[1]
             r = lambda t, n: None if t is None else t.reshape(nb * T, n, -1)
-            xs, es = block(r(x, self.n_node), r(e, self.n_edge), r(xb, self.n_node), r(eb, self.n_edge))
+            if mask is None:
+                xs, es = block(r(x, self.n_node), r(e, self.n_edge), r(xb, self.n_node), r(eb, self.n_edge))
+            else:
+                xs, es = block(r(x, self.n_node), r(e, self.n_edge), r(xb, self.n_node), r(eb, self.n_edge), adj_mask=mask)
             return xs.reshape(nb, T, self.n_node, -1), es.reshape(nb, T, self.n_edge, -1)
 
         x, e = spatial(self.block1, x, e)
@@ -288,7 +300,7 @@ class Emulator(nn.Module):
             e = ly(e)
         x, e = x[:, -self.seq_out:], e[:, -self.seq_out:]             # :249,256
         # concat([x, b]) / concat([e, ae]) (:260-262) are not materialised: the first layer of block 2 reads both pieces
-        x, e = spatial(self.block2, c(x), c(e), b, ae if self.act else None)
+        x, e = spatial(self.block2, c(x), c(e), b, ae if self.act else None, adj_mask)
         for ly in self.tem2_x:
             x = ly(x)
         for ly in self.tem2_e:
@@ -361,6 +373,50 @@ class Emulator(nn.Module):
         out[self._act_edge_index()] = np.arange(1, a.shape[-1] + 1)
         table = torch.cat([torch.ones_like(a[..., :1]), a], dim=-1)
         return table[..., self._dev_index('edge_action', out, a.device)].unsqueeze(-1)
+
+    def _adj_pattern(self):
+        """(CSR of the adjacency the node-side conv of block 2 runs on, raw values at its entries, entry position of every
+        actuated (from, to) pair or -1).  Two-graph form: the node adjacency; graph_base: the combined node + link graph."""
+        if getattr(self, '_adj_pat', None) is None:
+            csr = self._base_filter if self.graph_base else self.graph.adj
+            raw = np.ones(csr.nnz) if getattr(self, '_adj_raw', None) is None else self._adj_raw
+            rp, col = np.asarray(csr.rowptr, dtype=np.int64), np.asarray(csr.col, dtype=np.int64)
+            pos = np.full(len(self.act_edges), -1, dtype=np.int64)
+            for k, (u, v) in enumerate(np.asarray(self.act_edges, dtype=np.int64)):
+                hit = np.nonzero(col[rp[u]:rp[u + 1]] == v)[0]
+                if len(hit):
+                    pos[k] = rp[u] + hit[0]
+            self._adj_pat = (csr, raw, pos)
+        return self._adj_pat
+
+    def get_adj_action(self, a, g=True):
+        """`get_adj_action` (emulator.py:343-362) for conv=GAT, in CSR form: a (B, T, n_act) settings -> edge mask
+        (B, T, nnz) over the entries of the node adjacency.  The reference writes `adj[from_k, to_k] = a_k` (g=False) or
+        multiplies that entry by a_k (g=True) -- the (from, to) entry only, not its transpose -- and casts the matrix to int:
+        an entry survives iff trunc(value) != 0, so with a 0/1 adjacency any setting below 1 removes it."""
+        csr, raw, pos = self._adj_pattern()
+        dev = a.device
+        base = torch.as_tensor(np.trunc(raw) != 0, dtype=torch.float32, device=dev)
+        mask = base.expand(tuple(a.shape[:-1]) + (csr.nnz,)).clone()
+        ok = pos >= 0
+        if ok.any():
+            w = torch.as_tensor(raw[pos[ok]], dtype=a.dtype, device=dev) if g else torch.ones(int(ok.sum()), dtype=a.dtype, device=dev)
+            val = a[..., torch.as_tensor(np.nonzero(ok)[0], device=dev)] * w
+            mask[..., torch.as_tensor(pos[ok], device=dev)] = (torch.trunc(val) != 0).to(torch.float32)
+        return mask
+
+    def _adj_mask_from(self, adj, device):
+        """Edge mask from what `forward` is given: the mask itself (..., nnz) or the reference's dense (..., n, n) adjacency."""
+        csr, _, _ = self._adj_pattern()
+        adj = torch.as_tensor(adj) if not isinstance(adj, torch.Tensor) else adj
+        n = csr.n_rows
+        if adj.dim() >= 2 and tuple(adj.shape[-2:]) == (n, n) and adj.shape[-1] != csr.nnz:
+            rows = torch.as_tensor(np.repeat(np.arange(n), np.diff(csr.rowptr)), device=adj.device)
+            cols = torch.as_tensor(np.asarray(csr.col, dtype=np.int64), device=adj.device)
+            adj = (torch.trunc(adj[..., rows, cols].to(torch.float32)) != 0)
+        elif adj.shape[-1] != csr.nnz:
+            raise ValueError('ADJ %r is neither an edge mask (..., %d) nor a dense (..., %d, %d) adjacency' % (tuple(adj.shape), csr.nnz, n, n))
+        return adj.to(device=device, dtype=torch.float32)
 
     def get_action(self, a, g=True):
         out_o, out_i = np.zeros(self.n_node, dtype=np.int64), np.zeros(self.n_node, dtype=np.int64)
@@ -474,8 +530,9 @@ class Emulator(nn.Module):
         ex = edge_state[:, -self.seq_in:]
         assert b.shape[1] == self.seq_out
         ae = self.get_edge_action(a, True) if self.act else None
+        adj = self.get_adj_action(a, True) if self.act and self.use_adj else None        # :612-617
         nb_ = self.normalize(b, 'b')
-        y, ey = self.forward(self.normalize(x, 'x'), nb_, self.normalize(ex, 'e'), ae)
+        y, ey = self.forward(self.normalize(x, 'x'), nb_, self.normalize(ex, 'e'), ae, adj)
         y, ey = self._post_proc((y, ey), a, nb_, np_form)
         ey = self.normalize(ey, 'e', True)
         ey = torch.cat([torch.minimum(ey[..., 0].clamp(min=0), self.ehmax).unsqueeze(-1), ey[..., 1:]], dim=-1)
@@ -506,14 +563,17 @@ class Emulator(nn.Module):
         else:
             if ae is None and self.act:
                 ae = self.get_edge_action(a, True)
-            preds, edge_preds = self.post_proc_tf(self.forward(x, b, ex, ae), a, b)
+            if adj is None and self.act and self.use_adj:
+                adj = self.get_adj_action(a, True)
+            preds, edge_preds = self.post_proc_tf(self.forward(x, b, ex, ae, adj), a, b)
         return preds.clamp(0, 1), edge_preds                          # :437
 
     def _roll_step(self, x, ex, a_i, b_i):
         """One chunk of the autoregressive rollout (emulator.py:403-423): forward on the last seq_in steps, post-processing,
         then the window shifts by seq_out steps fed with the prediction (flood bit thresholded at 0.5)."""
         ae_i = self.get_edge_action(a_i, True) if self.act else None
-        y, ey = self.forward(x[:, -self.seq_in:], b_i, ex[:, -self.seq_in:], ae_i)
+        adj_i = self.get_adj_action(a_i, True) if self.act and self.use_adj else None       # :407
+        y, ey = self.forward(x[:, -self.seq_in:], b_i, ex[:, -self.seq_in:], ae_i, adj_i)
         y, ey = self.post_proc_tf((y, ey), a_i, b_i)
         if self.if_flood:                                   # flood bit fed back as a hard 0/1 (:417)
             x_new = torch.cat([y[..., :-1], (y[..., -1:] > 0.5).float(), b_i], dim=-1)

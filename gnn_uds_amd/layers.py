@@ -166,13 +166,25 @@ class GATConv(nn.Module):
         self.attn_kernel_neighs = _param(_glorot_uniform((c, 1, 1), device, self._gen))
         self.bias = _param(torch.zeros(c, device=device)) if self.use_bias else None
 
-    def forward(self, inputs, xb=None):
+    def forward(self, inputs, xb=None, edge_mask=None):
+        """edge_mask (..., nnz): per-snapshot 0/1 over the entries of the pattern `a` (`use_adj`, emulator.py:268-271: the
+        reference feeds a (S, N, N) adjacency here; the mask is that adjacency gathered at the static pattern's entries --
+        `Emulator.get_adj_action`).  The diagonal always takes part (set_diag).  Inference only."""
         x, a = inputs
         if self.kernel is None:
             self.build(x.shape[-1] + (0 if xb is None else xb.shape[-1]), x.device)
         h = self._graphs.handle(a, self.add_self_loops)
         xs, lead = _flatten_snapshots(x)
         xbs = None if xb is None else _flatten_snapshots(xb)[0]
+        if edge_mask is not None:
+            if _ag.grad_on(xs, xbs, self.kernel, self.attn_kernel_self, self.attn_kernel_neighs, self.bias):
+                raise NotImplementedError('GATConv with a per-snapshot edge mask (use_adj) is built for inference')
+            fin = xs.shape[-1] + (0 if xbs is None else xbs.shape[-1])
+            hx, s_self, s_nbr = _lib.dense_act(xs, self.kernel.reshape(fin, self.channels), None, 'linear', xbs,
+                                               attn=(self.attn_kernel_self.reshape(-1), self.attn_kernel_neighs.reshape(-1)))
+            mk = edge_mask.reshape(-1, edge_mask.shape[-1]).to(torch.float32).contiguous()
+            out = _lib.gat_aggregate(h, hx, s_self, s_nbr, self.bias, self.activation, edge_mask=mk)
+            return out.reshape(lead + out.shape[-2:])
         if _ag.grad_on(xs, xbs, self.kernel, self.attn_kernel_self, self.attn_kernel_neighs, self.bias):
             out = _ag.GatFn.apply(xs, xbs, self.kernel, self.attn_kernel_self, self.attn_kernel_neighs, self.bias,
                                   self.activation, h, self.precision)
@@ -513,9 +525,25 @@ class SpatialLayer(nn.Module):
                 p['ne_%s_w' % tag], p['ne_%s_b' % tag] = c(ne.weight), c(ne.bias)
         return p
 
-    def forward(self, x, e, xb=None, eb=None):
+    def forward(self, x, e, xb=None, eb=None, adj_mask=None):
         """xb / eb: 32 extra columns appended to a 64-wide x / e (`concat([x, b])`, emulator.py:260-262) -- read in place
-        by the fused kernel; every other path concatenates."""
+        by the fused kernel; every other path concatenates.  adj_mask (..., nnz of the node adjacency): the per-snapshot
+        adjacency of `use_adj` (emulator.py:268-271,282) -- node side through the masked aggregation kernel."""
+        if adj_mask is not None:
+            if self.conv != 'GAT':
+                raise NotImplementedError('use_adj is built for conv=GAT (GCN / Diffusion would re-normalise the filter per snapshot)')
+            if xb is not None:
+                x = torch.cat([x, xb], dim=-1)
+            if eb is not None:
+                e = torch.cat([e, eb], dim=-1)
+            xs, lead_x = _flatten_snapshots(x)
+            es, lead_e = _flatten_snapshots(e)
+            net = self.network()
+            x_e, e_x = self.dense_xe(es), self.dense_ex(xs)
+            ox = self.gat_x([xs, net.adj], xb=self.node_edge_n(x_e), edge_mask=adj_mask)
+            oe = self.gat_e([es, net.edge_adj], xb=self.node_edge_e(e_x))
+            self.last_path = 'unfused'
+            return ox.reshape(lead_x + ox.shape[-2:]), oe.reshape(lead_e + oe.shape[-2:])
         fused_split = (xb is not None or eb is not None) and self.conv == 'GAT' and self.precision == 'bf16x3' and \
             self.h == 32 and self.d == 64 and x.shape[-1] + (0 if xb is None else xb.shape[-1]) in (64, 96) and \
             e.shape[-1] + (0 if eb is None else eb.shape[-1]) in (64, 96) and (xb is None or (x.shape[-1], xb.shape[-1]) == (64, 32)) and \
@@ -614,16 +642,18 @@ class GraphBaseBlock(nn.Module):
             if conv == 'GAT':
                 ly.precision = precision
 
-    def forward(self, x, e, xb=None, eb=None):
+    def forward(self, x, e, xb=None, eb=None, adj_mask=None):
         if xb is not None:
             x = torch.cat([x, xb], dim=-1)
         if eb is not None:
             e = torch.cat([e, eb], dim=-1)
         if x.shape[-1] != e.shape[-1]:
             raise _lib.UdsError('graph_base stacks node and link rows: widths %d and %d differ' % (x.shape[-1], e.shape[-1]))
+        if adj_mask is not None and self.conv != 'GAT':
+            raise NotImplementedError('use_adj is built for conv=GAT')
         z = torch.cat([x, e], dim=-2)
         for ly in self.layers:
-            z = ly([z, self.filt])
+            z = ly([z, self.filt], edge_mask=adj_mask) if adj_mask is not None else ly([z, self.filt])
         return z[..., :self.n_node, :].contiguous(), z[..., self.n_node:, :].contiguous()
 
 
@@ -640,10 +670,11 @@ class SpatialBlock(nn.Module):
         self.layers = nn.ModuleList(layers)
         self.graph = graph
 
-    def forward(self, x, e, xb=None, eb=None):
-        """xb / eb: extra input columns of the FIRST layer (`concat([x, b])` before block 2, emulator.py:260-262)."""
+    def forward(self, x, e, xb=None, eb=None, adj_mask=None):
+        """xb / eb: extra input columns of the FIRST layer (`concat([x, b])` before block 2, emulator.py:260-262);
+        adj_mask: the per-snapshot node adjacency of `use_adj`, seen by every layer of the block (emulator.py:268-282)."""
         net = self.layers[0].network() if self.layers[0].conv == 'GAT' else None
         for i, layer in enumerate(self.layers):
             layer._net = net
-            x, e = layer(x, e, xb, eb) if i == 0 else layer(x, e)
+            x, e = layer(x, e, xb if i == 0 else None, eb if i == 0 else None, adj_mask=adj_mask)
         return x, e

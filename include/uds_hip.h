@@ -195,6 +195,14 @@ int uds_gat_aggregate(const uds_csr_t *graph, const float *hx, const float *s_se
 
 /* ---- reverse mode of the sparse operators (the GradientTape of fit_eval, emulator.py:457-484) ---------- */
 
+/* uds_gat_aggregate with a per-snapshot edge mask: the `use_adj` variant, where the control action rewrites the adjacency
+ * entries of the actuated links at every time step and GAT casts the result to int (a setting < 1 removes the entry) --
+ * emulator.py:268-271,343-362.  edge_mask (S, nnz) floats in the pattern's entry order: entry p of snapshot s takes part
+ * iff edge_mask[s, p] != 0 or it is the diagonal (spektral sets the diagonal to one after the rewrite). */
+int uds_gat_aggregate_masked(const uds_csr_t *graph, const float *hx, const float *s_self, const float *s_nbr,
+                             const float *bias, const float *edge_mask, int64_t S, int64_t d, int act, float *out,
+                             uds_stream_t stream);
+
 /* Attention part of uds_gat_forward, backwards.  With pre_i = sum_j alpha_ij hx_j (before bias / activation) and
  * grad = dL/dpre (S,n,d), hx / s_self / s_nbr as uds_gat_forward left them in its workspace:
  *   d_hx (S,n,d)   = dL/dhx (aggregation + both attention scores),

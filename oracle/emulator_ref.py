@@ -15,8 +15,8 @@ Restates, on torch CPU tensors (fp64 or fp32), `surrogate/emulator.py` of the re
 `args` is any object with the reference's attribute names (`state_shape`, `edge_state_shape`, `seq_in`,
 `embed_size`, `adj`, `edge_adj`, `node_edge`, ... -- `Emulator.__init__`, emulator.py:48-127); `params`
 is the dict made by `init_params` (Keras creation order and initialisers).
-Not restated (the reference's shipped models never use them): graph_base > 0, use_adj, GRU/LSTM,
-DiffusionConv / GeneralConv, the non-conv MLP variant.
+Not restated (the reference's shipped models never use them): use_adj for GCN / Diffusion (per-step re-normalised
+filters), GRU/LSTM, GeneralConv, the non-conv MLP variant.
 """
 import math
 from types import SimpleNamespace
@@ -166,7 +166,18 @@ def conv1d_causal(x, kernel, bias, dilation, act):
     return OD.activation(act)(out + bias)
 
 
-def _spatial_layer(x, e, p, c, dtype):
+def get_adj_action(c, a):
+    """`get_adj_action` (emulator.py:343-362), GAT branch: a (B, T, n_act) -> (B, T, N, N) integer adjacency with the entry
+    (from_k, to_k) of every actuated link multiplied by its setting (the graph form, `self.adj * gather(...)`, which equals
+    the numpy form `adj[act_edges] = s` on a 0/1 adjacency), then cast to int (truncation)."""
+    adj = torch.from_numpy(np.asarray(c.adj, dtype=np.float64))
+    out = adj.expand(tuple(a.shape[:-1]) + adj.shape).clone()
+    for k, (u, v) in enumerate(np.asarray(c.act_edges, dtype=np.int64)):
+        out[..., u, v] = adj[u, v] * a[..., k].to(torch.float64)
+    return torch.trunc(out)
+
+
+def _spatial_layer(x, e, p, c, dtype, adj=None):
     q = {'xe_k': p['dense_xe']['kernel'], 'xe_b': p['dense_xe']['bias'], 'ex_k': p['dense_ex']['kernel'],
          'ex_b': p['dense_ex']['bias'], 'ne_n_w': p['node_edge_n']['weight'], 'ne_n_b': p['node_edge_n']['bias'],
          'ne_e_w': p['node_edge_e']['weight'], 'ne_e_b': p['node_edge_e']['bias']}
@@ -177,11 +188,11 @@ def _spatial_layer(x, e, p, c, dtype):
     q = {**q, 'gx_k': p['gat_x']['kernel'], 'gx_as': p['gat_x']['attn_kernel_self'], 'gx_an': p['gat_x']['attn_kernel_neighs'],
          'gx_b': p['gat_x']['bias'], 'ge_k': p['gat_e']['kernel'], 'ge_as': p['gat_e']['attn_kernel_self'],
          'ge_an': p['gat_e']['attn_kernel_neighs'], 'ge_b': p['gat_e']['bias']}
-    return OD.spatial_layer_dense(x, e, q, torch.from_numpy(c.filter).to(dtype), torch.from_numpy(c.edge_filter).to(dtype),
-                                  torch.from_numpy(c.node_edge).to(dtype), c.activation, c.conv)
+    return OD.spatial_layer_dense(x, e, q, torch.from_numpy(c.filter).to(dtype) if adj is None else adj.to(dtype),
+                                  torch.from_numpy(c.edge_filter).to(dtype), torch.from_numpy(c.node_edge).to(dtype), c.activation, c.conv)
 
 
-def forward(args, params, X, B, E, AE=None):
+def forward(args, params, X, B, E, AE=None, ADJ=None):
     """`Emulator.build_network` as a function: X (B,T_in,N,n_in), B (B,T_out,N,b_in), E (B,T_in,E,e_in),
     AE (B,T_out,E,1) when act -> out (B,T_out,N,n_out[+1]), e_out (B,T_out,E,e_out).  emulator.py:195-338."""
     c = config(args)
@@ -198,9 +209,10 @@ def forward(args, params, X, B, E, AE=None):
     ae = D(AE, params['embed_ae'], c.activation) if c.act else None      # :212
     nb = X.shape[0]
 
-    def spatial(x, e, layers):                                    # :217-235 / :265-288
+    def spatial(x, e, layers, adj=None):                          # :217-235 / :265-288; adj: (B,T,n,n) of use_adj (:268-271)
         T = x.shape[1]
         xs, es = x.reshape((-1,) + tuple(x.shape[2:])), e.reshape((-1,) + tuple(e.shape[2:]))
+        A = None if adj is None else adj.reshape((-1,) + tuple(adj.shape[-2:]))
         for p in layers:
             if c.graph_base:
                 q = p['gat']
@@ -208,11 +220,11 @@ def forward(args, params, X, B, E, AE=None):
                     z = OD.diffusion_conv_dense(torch.cat([xs, es], dim=-2), torch.from_numpy(c.filter).to(dt), q['theta'], c.activation)
                     xs, es = z[:, :c.n_node], z[:, c.n_node:]
                     continue
-                z = OD.gat_conv_dense(torch.cat([xs, es], dim=-2), torch.from_numpy(c.filter).to(dt), q['kernel'], q['attn_kernel_self'],
+                z = OD.gat_conv_dense(torch.cat([xs, es], dim=-2), torch.from_numpy(c.filter).to(dt) if A is None else A.to(dt), q['kernel'], q['attn_kernel_self'],
                                       q['attn_kernel_neighs'], q['bias'], c.activation)
                 xs, es = z[:, :c.n_node], z[:, c.n_node:]
             else:
-                xs, es = _spatial_layer(xs, es, p, c, dt)
+                xs, es = _spatial_layer(xs, es, p, c, dt, A)
         return xs.reshape(nb, T, c.n_node, -1), es.reshape(nb, T, c.n_edge, -1)
 
     def temporal(x, layers, n):                                   # :244-257 / :299-310
@@ -228,7 +240,7 @@ def forward(args, params, X, B, E, AE=None):
     x = torch.cat([x, b], dim=-1)                                 # :260
     if c.act:
         e = torch.cat([e, ae], dim=-1)                            # :262
-    x, e = spatial(x, e, params['block2'])
+    x, e = spatial(x, e, params['block2'], ADJ)                       # :264-288 (A = A_in with use_adj)
     x = temporal(x, params['tem2_x'], c.n_node)
     e = temporal(e, params['tem2_e'], c.n_edge)
     x_out = D(x, params['res_x'])                                 # :313

@@ -165,6 +165,34 @@ def test_network_forward_diffusion(dev, networks, graph_base):
     close(y, ry, TOL_FWD['fp32']); close(ey, rey, TOL_FWD['fp32'])
 
 
+@pytest.mark.parametrize('graph_base', [0, 1])
+def test_network_forward_use_adj(dev, networks, graph_base):
+    """`use_adj` (emulator.py:178-180,268-271,343-362): the control action rewrites the adjacency entry of every actuated link
+    per time step (GAT: cast to int, a setting < 1 removes it); block 2's node-side GAT sees a per-snapshot mask.  The HIP
+    path takes the mask over the CSR entries, the oracle the dense (B, T, n, n) array; both forms of ADJ give the same."""
+    act_edges = np.array(networks['astlingen']['edges'])[::2]     # half of the links actuated: the mask moves the outputs visibly
+    args, params, emul, _ = _setup(networks, 'astlingen', dev, use_adj=True, if_flood=0, seq_in=4, seq_out=3, embed_size=32,
+                                   hidden_dim=32, n_sp_layer=2, n_tp_layer=1, graph_base=graph_base, act_edges=act_edges)
+    X, Bd, Ex, _ = _inputs(args, 2)
+    g = torch.Generator().manual_seed(5)
+    a = (torch.rand(2, 3, len(args.act_edges), generator=g) > 0.4).double() * (0.5 + torch.rand(2, 3, len(args.act_edges), generator=g))
+    c = OE.config(args)
+    AE, ADJ = OE.get_edge_action(c, a), OE.get_adj_action(c, a)
+    assert 0 < float((ADJ != torch.from_numpy(np.asarray(c.adj, dtype=np.float64))).double().mean())       # some entries switched off
+    ry, rey = OE.forward(args, params, X, Bd, Ex, AE, ADJ)
+    r0y, _ = OE.forward(args, params, X, Bd, Ex, AE)
+    assert float((ry - r0y).abs().max()) > 0                     # the outputs feel it (the layer-level test in test_gpu_parity.py bounds the effect from below)
+    f = lambda t: t.float().to(dev)
+    mask = emul.get_adj_action(f(a))
+    assert mask.shape[:2] == (2, 3) and float(mask.min()) == 0.0
+    y, ey = emul(f(X), f(Bd), f(Ex), emul.get_edge_action(f(a)), mask)
+    close(y, ry, TOL_FWD['bf16x3']); close(ey, rey, TOL_FWD['bf16x3'])
+    y2, ey2 = emul(f(X), f(Bd), f(Ex), emul.get_edge_action(f(a)), f(ADJ))           # the reference's dense layout
+    assert torch.equal(y, y2) and torch.equal(ey, ey2)
+    ym, _ = emul._model(f(X), f(a), f(Bd), f(Ex))                # _model builds both action tensors itself (:427-433)
+    assert ym.shape[:3] == y.shape[:3] and bool(torch.isfinite(ym).all())
+
+
 @pytest.mark.parametrize('variant', ['edge_fusion_act', 'pumps_offset_tide', 'plain'])
 def test_predict_tf(dev, networks, variant):
     """predict_tf (emulator.py:604-641) incl. post_proc_tf / constrain_tf branches; raw states in, physical units out."""

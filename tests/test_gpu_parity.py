@@ -206,6 +206,37 @@ def test_spatial_layer_vs_dense_masked_oracle(dev, networks, name, d, S, precisi
     close(ox, rx, tol); close(oe, re, tol)
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_spatial_layer_with_per_snapshot_adjacency(dev, networks, precision):
+    """`use_adj` at the layer (emulator.py:268-271,282): node-side GAT with a different adjacency per snapshot -- entries of the
+    static pattern switched off by a (S, nnz) mask (uds_gat_aggregate_masked) -- against the dense oracle fed the (S, N, N)
+    arrays; the diagonal is kept whatever the mask says (set_diag), and the masked result differs visibly from the plain one."""
+    tol = PREC_TOL[precision]
+    net = networks['shunqing']
+    gph = U.DrainageGraph.from_edges(np.array(net['edges']), net['n_node'])
+    d, S = 64, 3
+    p = spatial_params(gph.n_node, gph.n_edge, d, d, d, seed=7)
+    g = torch.Generator().manual_seed(8)
+    x, e = rnd(g, S, gph.n_node, d), rnd(g, S, gph.n_edge, d)
+    ne = torch.from_numpy(gph.inc_n.to_dense())
+    adj = torch.from_numpy(gph.adj.to_dense())
+    mask = (torch.rand(S, gph.adj.nnz, generator=g) > 0.4).double()
+    rows = np.repeat(np.arange(gph.n_node), np.diff(gph.adj.rowptr))
+    cols = np.asarray(gph.adj.col, dtype=np.int64)
+    A = torch.zeros(S, gph.n_node, gph.n_node, dtype=torch.float64)
+    A[:, rows, cols] = mask                                       # the diagonal entries that got a 0 are restored by set_diag
+    assert float(A[:, np.arange(gph.n_node), np.arange(gph.n_node)].min()) == 0
+    rx, re = OD.spatial_layer_dense(x, e, p, A, torch.from_numpy(gph.edge_adj.to_dense()), ne)
+    r0x, _ = OD.spatial_layer_dense(x, e, p, adj, torch.from_numpy(gph.edge_adj.to_dense()), ne)
+    assert float((rx - r0x).abs().max()) > 1000 * tol
+    layer = load_spatial_layer(U.SpatialLayer(gph, d, 'relu', sparse_params=False, precision=precision), p, dev)
+    ox, oe = layer(x.float().to(dev), e.float().to(dev), adj_mask=mask.float().to(dev))
+    close(ox, rx, tol); close(oe, re, tol)
+    ones = torch.ones(S, gph.adj.nnz, device=dev)                 # an all-ones mask is the plain layer
+    ox1, _ = layer(x.float().to(dev), e.float().to(dev), adj_mask=ones)
+    close(ox1, r0x, tol)
+
+
 @pytest.mark.parametrize('R,M,S,h', [(1, 1, 1, 4), (130, 77, 3, 32), (257, 300, 5, 32), (64, 1000, 2, 64), (300, 129, 7, 12)])
 def test_remainder_gemm_ragged_shapes(dev, R, M, S, h):
     """uds_remainder_forward (the dense off-support part of a trained NodeEdge, emulator.py:44) against the fp64 product:
