@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # UDS_LIB_PATH: a differently built copy of the same library (kernel experiments: tools/variant_bench.py)
 LIB_PATH = os.environ.get('UDS_LIB_PATH') or os.path.join(_HERE, 'libuds_hip.so')
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
 PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
 
@@ -38,6 +38,7 @@ SYMBOLS = {
     'uds_csr_spmm': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_int, _c_ptr, _c_ptr]),
     'uds_conv1d_causal': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr,
                                    _c_ptr]),
+    'uds_recurrent_forward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_rowgemm_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
     'uds_rowgemm_pack': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
     'uds_gat_aggregate_masked': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
@@ -345,6 +346,21 @@ def conv1d_causal(x, kernel, bias=None, dilation=1, act='linear'):
         return out
     _check(lib.uds_conv1d_causal(_dev(x, 'x'), B, T, R, F, _dev(kernel, 'kernel'), _dev(bias, 'bias', True), taps, dilation, H,
                                  ACT[act], _dev(out, 'out'), _stream()), 'uds_conv1d_causal')
+    return out
+
+
+def recurrent_forward(xp, recurrent_kernel, recurrent_bias, kind):
+    """Hidden states (B, T, R, H) of a GRU (kind 'GRU') or LSTM from the input projections xp (B, T, R, G*H)."""
+    lib = load()
+    B, T, R, GH = xp.shape
+    G = {'GRU': 3, 'LSTM': 4}[kind]
+    H = GH // G
+    if GH != G * H or tuple(recurrent_kernel.shape) != (H, GH):
+        raise UdsError('recurrent_forward: xp %r, recurrent kernel %r for a %s' % (tuple(xp.shape), tuple(recurrent_kernel.shape), kind))
+    out = torch.empty((B, T, R, H), device=xp.device, dtype=torch.float32)
+    if out.numel():
+        _check(lib.uds_recurrent_forward(_dev(xp, 'xp'), _dev(recurrent_kernel, 'recurrent_kernel'), _dev(recurrent_bias, 'recurrent_bias', True),
+                                         B, T, R, H, 0 if kind == 'GRU' else 1, _dev(out, 'out'), _stream()), 'uds_recurrent_forward')
     return out
 
 

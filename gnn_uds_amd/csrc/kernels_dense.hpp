@@ -246,4 +246,84 @@ inline hipError_t launch_dense_act(const DenseArgs &a, hipStream_t st) {
   return launch_dense_cg<64>(a, st);
 }
 
+// keras GRU / LSTM(units, return_sequences=True) along the time axis (emulator.py:158-161: the `recurrent` alternatives to
+// the causal Conv1D; no shipped model uses them).  The input projections xp = x @ kernel + input bias for ALL time steps
+// come from the Dense kernels; this kernel is the time recurrence, exact fp32.  A workgroup owns `rows` independent rows
+// (node or link series) and walks t = 0..T-1: thread (row, f) forms the G gate pre-activations of feature f,
+//     a_g = xp[b, t, n, g H + f] + sum_k h[row][k] U[k][g H + f] (+ recurrent bias),
+// from the recurrent kernel U (H x G H, staged once in LDS) and the previous state (LDS), then
+//   GRU (G = 3, gates z, r, h; TF2 default reset_after=True, recurrent_activation = sigmoid):
+//       z = sig(a_z), r = sig(a_r): here a_r, a_z add the two projections; cand = tanh(xp_h + r * (h U_h + rb_h)); h' = z h + (1 - z) cand
+//   LSTM (G = 4, gates i, f, c, o): c' = sig(a_f) c + sig(a_i) tanh(a_c); h' = sig(a_o) tanh(c')
+// x is indexed as (B, T, R, .) directly: no (B*R, T, .) transpose as in the reference (emulator.py:244).
+struct RecurrentArgs {
+  const float *xp, *U, *rb;
+  float *out;
+  int B, T, R, H, G, rows;      // rows per workgroup; blockDim = rows * H
+};
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+template <int G>
+__global__ void k_recurrent(RecurrentArgs a) {
+  extern __shared__ float smem_rc[];
+  const int H = a.H, GH = G * H;
+  float *U = smem_rc;                       // H x GH
+  float *hs = smem_rc + (size_t)H * GH;     // rows x H
+  const int tid = threadIdx.x, row = tid / H, f = tid - row * H;
+  for (int i = tid; i < H * GH; i += blockDim.x) U[i] = a.U[i];
+  const int64_t grow = (int64_t)blockIdx.x * a.rows + row;      // global row = b * R + n
+  const bool live = grow < (int64_t)a.B * a.R;
+  const int b = live ? (int)(grow / a.R) : 0, n = live ? (int)(grow - (int64_t)b * a.R) : 0;
+  hs[row * H + f] = 0.0f;
+  float rb[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) rb[g] = a.rb ? a.rb[g * H + f] : 0.0f;
+  float c = 0.0f, h = 0.0f;
+  __syncthreads();
+  for (int t = 0; t < a.T; ++t) {
+    float acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = rb[g];
+    const float *hr = hs + row * H;
+    for (int k = 0; k < H; ++k) {
+      const float hk = hr[k];
+#pragma unroll
+      for (int g = 0; g < G; ++g) acc[g] = fmaf(hk, U[k * GH + g * H + f], acc[g]);
+    }
+    float xg[G];
+    const int64_t base = (((int64_t)b * a.T + t) * a.R + n);
+#pragma unroll
+    for (int g = 0; g < G; ++g) xg[g] = live ? a.xp[base * GH + g * H + f] : 0.0f;
+    if (G == 3) {
+      const float z = sigmoidf_(xg[0] + acc[0]), r = sigmoidf_(xg[1] + acc[1]);
+      const float cand = tanhf(xg[2] + r * acc[2]);
+      h = z * h + (1.0f - z) * cand;
+    } else {
+      const float ig = sigmoidf_(xg[0] + acc[0]), fg = sigmoidf_(xg[1] + acc[1]);
+      const float cg = tanhf(xg[2] + acc[2]), og = sigmoidf_(xg[G - 1] + acc[G - 1]);
+      c = fg * c + ig * cg;
+      h = og * tanhf(c);
+    }
+    __syncthreads();                 // every thread has read the previous state
+    hs[row * H + f] = h;
+    if (live) a.out[base * H + f] = h;
+    __syncthreads();
+  }
+}
+
+inline hipError_t launch_recurrent(const RecurrentArgs &a, hipStream_t st) {
+  const int64_t total = (int64_t)a.B * a.R;
+  const unsigned grid = (unsigned)((total + a.rows - 1) / a.rows);
+  const size_t lds = ((size_t)a.H * a.G * a.H + (size_t)a.rows * a.H) * sizeof(float);
+  if (a.G == 3) {
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_recurrent<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_recurrent<3>, dim3(grid), dim3(a.rows * a.H), lds, st, a);
+  } else {
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_recurrent<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_recurrent<4>, dim3(grid), dim3(a.rows * a.H), lds, st, a);
+  }
+  return hipGetLastError();
+}
+
 }  // namespace uds

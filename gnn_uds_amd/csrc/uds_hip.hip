@@ -315,6 +315,25 @@ int uds_conv1d_causal(const float *x, int64_t B, int64_t T, int64_t R, int64_t F
   return UDS_OK;
 }
 
+int uds_recurrent_forward(const float *xp, const float *U, const float *rb, int64_t B, int64_t T, int64_t R, int64_t H, int kind,
+                          float *out, uds_stream_t stream) {
+  UDS_REQUIRE(xp && U && out, "uds_recurrent_forward: NULL argument");
+  UDS_REQUIRE(kind == 0 || kind == 1, "uds_recurrent_forward: kind %d (0 = GRU, 1 = LSTM)", kind);
+  UDS_REQUIRE(B >= 0 && T >= 0 && R >= 0 && H > 0 && H <= 256, "uds_recurrent_forward: bad sizes B=%lld T=%lld R=%lld H=%lld", (long long)B,
+              (long long)T, (long long)R, (long long)H);
+  if (B == 0 || T == 0 || R == 0) return UDS_OK;
+  const int G = kind == 0 ? 3 : 4;
+  const int rows = (int)std::max<int64_t>(1, 256 / H);
+  const size_t lds = ((size_t)H * G * H + (size_t)rows * H) * sizeof(float);
+  UDS_REQUIRE(lds <= 160 * 1024, "uds_recurrent_forward: the recurrent kernel (%lld x %lld floats) does not fit the 160 KiB LDS", (long long)H,
+              (long long)(G * H));
+  UDS_REQUIRE((B * R + rows - 1) / rows < INT32_MAX, "uds_recurrent_forward: too many rows");
+  uds::RecurrentArgs a{xp, U, rb, out, (int)B, (int)T, (int)R, (int)H, G, rows};
+  hipError_t e = uds::launch_recurrent(a, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_recurrent_forward: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
 int64_t uds_rowgemm_packed_bytes(int64_t k_total, int64_t f_out) {
   if (k_total <= 0 || k_total % 32 || f_out <= 0 || f_out > 64) return 0;
   return (k_total / 32) * uds::rowgemm_mb((int)f_out) * 2 * 64 * 16;

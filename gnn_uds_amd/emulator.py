@@ -16,7 +16,7 @@ Conv1D, the resnet prefix sum) and the link->node flow balance of post_proc_tf a
 The remaining post-processing is elementwise gating / clipping on tensors already in HBM and is written with torch
 tensor ops (device plumbing).  Training (`fit_eval`, GradNorm), `graph_base` 1 / 2, GCN and DiffusionConv are built.
 `use_adj` (per-time-step adjacency rewritten by the control action) is built for GAT as a mask over the CSR entries.
-Not built, each raises: GRU / LSTM temporal nets, training-time dropout, `use_adj` with GCN / Diffusion or under autograd,
+GRU / LSTM temporal nets run (inference).  Not built, each raises: training-time dropout, `use_adj` with GCN / Diffusion or under autograd,
 GeneralConv (a sparse-mode-only Spektral layer the reference's dense call cannot run either) and the conv=None dense-MLP variant.
 """
 import os
@@ -54,6 +54,47 @@ class Conv1D(nn.Module):
             return _lib.rowgemm_forward(x, _packed_kernel(self, self.kernel.reshape(k * f, h)), self.bias, h, self.activation,
                                         taps=k, dilation=self.dilation_rate)
         return _lib.conv1d_causal(x, self.kernel, self.bias, self.dilation_rate, self.activation)
+
+
+class _Recurrent(nn.Module):
+    """keras GRU / LSTM(units, return_sequences=True) along the time axis of x (B, T, R, F) (emulator.py:158-161): the input
+    projection of every time step is one Dense launch, the recurrence one streaming kernel (uds_recurrent_forward), exact
+    fp32.  Parameters keep the Keras names and shapes -- `kernel` (F, G*units), `recurrent_kernel` (units, G*units), `bias`
+    ((2, 3*units) for the TF2 GRU with reset_after=True: input and recurrent bias; (4*units,) for the LSTM) -- and the
+    Keras initialisers (glorot_uniform, orthogonal, zeros with the LSTM's forget-gate bias at one).  Inference only."""
+    KIND, G = None, 0
+
+    def __init__(self, units, return_sequences=True, in_features=None, generator=None):
+        super().__init__()
+        if not return_sequences:
+            raise NotImplementedError('the emulator uses return_sequences=True (emulator.py:159,161)')
+        self.units = int(units)
+        gh = self.G * self.units
+        self.kernel = _param(_glorot_uniform((int(in_features), gh), 'cpu', generator))
+        q, _ = torch.linalg.qr(torch.randn(gh, self.units, generator=generator))            # orthogonal initialiser
+        self.recurrent_kernel = _param(q.T.contiguous())
+        if self.KIND == 'GRU':
+            self.bias = _param(torch.zeros(2, gh))
+        else:
+            b = torch.zeros(gh)
+            b[self.units:2 * self.units] = 1.0                                              # unit_forget_bias
+            self.bias = _param(b)
+
+    def forward(self, x):
+        if _ag.grad_on(x, self.kernel, self.recurrent_kernel, self.bias):
+            raise NotImplementedError('%s temporal layers are built for inference (no backward kernel)' % self.KIND)
+        x = x.contiguous()
+        b_in, b_rec = (self.bias[0], self.bias[1].contiguous()) if self.KIND == 'GRU' else (self.bias, None)
+        xp = _lib.dense_act(x, self.kernel, b_in.contiguous(), 'linear')
+        return _lib.recurrent_forward(xp, self.recurrent_kernel, b_rec, self.KIND)
+
+
+class GRU(_Recurrent):
+    KIND, G = 'GRU', 3
+
+
+class LSTM(_Recurrent):
+    KIND, G = 'LSTM', 4
 
 
 class KerasAdam:
@@ -157,8 +198,8 @@ class Emulator(nn.Module):
                                       'emulator.py:355-358)')
         if self.graph_base not in (0, 1, 2):
             raise ValueError('graph_base must be 0, 1 (node-based) or 2 (edge-based), got %r' % (self.graph_base,))
-        if recurrent not in ('Conv1D', None, 'None', False):
-            raise NotImplementedError('recurrent=%r is not built (Conv1D is what every shipped model uses)' % (recurrent,))
+        if recurrent not in ('Conv1D', 'GRU', 'LSTM', None, 'None', False):
+            raise NotImplementedError('recurrent=%r: Conv1D, GRU, LSTM or none (emulator.py:154-163)' % (recurrent,))
         if self.dropout:
             raise NotImplementedError('dropout > 0 (training-time) is not built')
 
@@ -240,8 +281,19 @@ class Emulator(nn.Module):
         else:
             self.block1 = SpatialBlock(self.graph, d, L, a, sparse_params=sp, generator=gen, precision=precision,
                                        conv=self.conv_kind, filters=(self.filter, self.edge_filter))                  # :219-235
-        tem = lambda f: nn.ModuleList([Conv1D(H, self.kernel_size, 2 ** i, a, in_features=(f if i == 0 else H), generator=gen, precision=pr)
-                                       for i in range(self.n_tp_layer)])
+        rec = self.recurrent if self.recurrent in ('Conv1D', 'GRU', 'LSTM') else None              # get_tem_nets, :154-163
+
+        def tem(f):
+            if rec == 'Conv1D':
+                mods = [Conv1D(H, self.kernel_size, 2 ** i, a, in_features=(f if i == 0 else H), generator=gen, precision=pr)
+                        for i in range(self.n_tp_layer)]
+            elif rec:
+                mods = [(GRU if rec == 'GRU' else LSTM)(H, in_features=(f if i == 0 else H), generator=gen) for i in range(self.n_tp_layer)]
+            else:
+                mods = []                                                                       # no temporal net: widths stay d
+            return nn.ModuleList(mods)
+        if not (rec and self.n_tp_layer):
+            H = d
         self.tem1_x, self.tem1_e = tem(d), tem(d)                                               # :247,254
         fx2, fe2 = H + h, H + (h if self.act else 0)
         if self.graph_base:
@@ -842,7 +894,12 @@ class Emulator(nn.Module):
 
         def temporal(mods):
             for m in mods:
-                out.append((name('conv1d'), m, dense_w))
+                if isinstance(m, _Recurrent):       # keras nests the weights in the layer's cell: gru/gru_cell/kernel:0, ...
+                    cell = m.KIND.lower() + '_cell'
+                    out.append((name(m.KIND.lower()), m, [(cell + '/kernel', 'kernel'), (cell + '/recurrent_kernel', 'recurrent_kernel'),
+                                                         (cell + '/bias', 'bias')]))
+                else:
+                    out.append((name('conv1d'), m, dense_w))
 
         spatial(self.block1)
         temporal(self.tem1_x)

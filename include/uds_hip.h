@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 9
+#define UDS_ABI_VERSION 10
 
 enum {
   UDS_OK = 0,
@@ -92,6 +92,14 @@ int uds_csr_spmm(const uds_csr_t *csr, const float *val, const float *x, int64_t
 int uds_conv1d_causal(const float *x, int64_t B, int64_t T, int64_t R, int64_t F, const float *kernel,
                       const float *bias, int64_t taps, int64_t dil, int64_t H, int act, float *out,
                       uds_stream_t stream);
+
+/* The time recurrence of keras GRU / LSTM(H, return_sequences=True) (emulator.py:158-161, the `recurrent` alternatives to
+ * the causal Conv1D), exact fp32.  xp (B, T, R, G*H) = x @ kernel + input bias for every time step (uds_dense_act), U
+ * (H, G*H) the recurrent kernel, rb (G*H) the recurrent bias or NULL; kind 0 = GRU (G = 3, gate order z, r, h, TF2's
+ * reset_after=True form, sigmoid recurrent activation), 1 = LSTM (G = 4: i, f, c, o).  out (B, T, R, H) = the hidden state
+ * after every step, initial state zero.  H <= 256 and H * G*H floats must fit the LDS. */
+int uds_recurrent_forward(const float *xp, const float *U, const float *rb, int64_t B, int64_t T, int64_t R, int64_t H,
+                          int kind, float *out, uds_stream_t stream);
 
 /* Matrix-core version of uds_dense_act (taps = 1, T = 1: rows = B*R) and uds_conv1d_causal for F % 32 == 0 and
  * f_out <= 64: operands split into bf16 hi + lo, three MFMA products, fp32 accumulation (the fused spatial kernel's

@@ -2,7 +2,7 @@
 PARITY UNPINNED, see oracle/__init__.py).
 
 Restates, on torch CPU tensors (fp64 or fp32), `surrogate/emulator.py` of the reference:
-  forward            build_network, conv = GAT / GCN, recurrent = Conv1D      emulator.py:166-341
+  forward            build_network, conv = GAT / GCN / Diffusion, recurrent = Conv1D / GRU / LSTM / none      emulator.py:166-341
   normalize          min-max (de)normalisation                                 emulator.py:803-810
   get_edge_action / get_action   action -> per-link / per-node gates           emulator.py:364-398
   post_proc          post_proc_tf                                              emulator.py:680-725
@@ -16,7 +16,7 @@ Restates, on torch CPU tensors (fp64 or fp32), `surrogate/emulator.py` of the re
 `embed_size`, `adj`, `edge_adj`, `node_edge`, ... -- `Emulator.__init__`, emulator.py:48-127); `params`
 is the dict made by `init_params` (Keras creation order and initialisers).
 Not restated (the reference's shipped models never use them): use_adj for GCN / Diffusion (per-step re-normalised
-filters), GRU/LSTM, GeneralConv, the non-conv MLP variant.
+filters), GeneralConv, the non-conv MLP variant, training-time dropout.
 """
 import math
 from types import SimpleNamespace
@@ -40,6 +40,9 @@ def config(args):
     c.seq_in, c.seq_out = g('seq_in', 6), g('seq_out', 1)
     c.d, c.H = g('embed_size', 64), g('hidden_dim', 64)
     c.k, c.L, c.n_tp = g('kernel_size', 3), g('n_sp_layer', 3), g('n_tp_layer', 2)
+    c.recurrent = g('recurrent', 'Conv1D')                # get_tem_nets (:154-163): 'Conv1D' | 'GRU' | 'LSTM' | anything else = none
+    if c.recurrent not in ('Conv1D', 'GRU', 'LSTM') or not c.n_tp:
+        c.recurrent, c.n_tp, c.H = None, 0, c.d           # no temporal net: the width stays embed_size
     c.activation = g('activation', 'relu')
     c.if_flood = int(g('if_flood', 0))
     c.n_in = n_in0 + (1 if c.if_flood else 0)
@@ -121,7 +124,12 @@ def init_params(args, seed=1, bias_scale=0.05):
     def temporal(f):
         out, fi = [], f
         for _ in range(c.n_tp):
-            out.append({'kernel': _glorot(g, (c.k, fi, H)), 'bias': bias(H)})
+            if c.recurrent == 'Conv1D':
+                out.append({'kernel': _glorot(g, (c.k, fi, H)), 'bias': bias(H)})
+            else:      # keras GRU (reset_after=True: bias (2, 3H)) / LSTM (bias (4H,)): kernel (F, G H), recurrent_kernel (H, G H)
+                G = 3 if c.recurrent == 'GRU' else 4
+                out.append({'kernel': _glorot(g, (fi, G * H)), 'recurrent_kernel': _glorot(g, (H, G * H)),
+                            'bias': bias(2 * G * H).reshape(2, G * H) if G == 3 else bias(G * H)})
             fi = H
         return out
 
@@ -175,6 +183,41 @@ def get_adj_action(c, a):
     for k, (u, v) in enumerate(np.asarray(c.act_edges, dtype=np.int64)):
         out[..., u, v] = adj[u, v] * a[..., k].to(torch.float64)
     return torch.trunc(out)
+
+
+def gru_sequence(x, kernel, recurrent_kernel, bias):
+    """keras.layers.GRU(H, return_sequences=True) as TF 2.10 builds it (emulator.py:159; defaults activation='tanh',
+    recurrent_activation='sigmoid', reset_after=True, zero initial state): x (M, T, F), kernel (F, 3H) / recurrent_kernel (H, 3H)
+    in gate order z, r, h, bias (2, 3H) = [input bias, recurrent bias].
+        z = sig(x_z + h U_z), r = sig(x_r + h U_r), cand = tanh(x_h + r * (h U_h)), h' = z h + (1 - z) cand   (biases inside)."""
+    H = recurrent_kernel.shape[0]
+    xp = x @ kernel + bias[0]
+    h = torch.zeros(x.shape[0], H, dtype=x.dtype)
+    out = []
+    for t in range(x.shape[1]):
+        rp = h @ recurrent_kernel + bias[1]
+        z = torch.sigmoid(xp[:, t, :H] + rp[:, :H])
+        r = torch.sigmoid(xp[:, t, H:2 * H] + rp[:, H:2 * H])
+        cand = torch.tanh(xp[:, t, 2 * H:] + r * rp[:, 2 * H:])
+        h = z * h + (1 - z) * cand
+        out.append(h)
+    return torch.stack(out, dim=1)
+
+
+def lstm_sequence(x, kernel, recurrent_kernel, bias):
+    """keras.layers.LSTM(H, return_sequences=True) (emulator.py:161; tanh / sigmoid, zero initial state): gate order i, f, c, o,
+    z = x W + h U + b;  c' = sig(z_f) c + sig(z_i) tanh(z_c);  h' = sig(z_o) tanh(c')."""
+    H = recurrent_kernel.shape[0]
+    xp = x @ kernel + bias
+    h = torch.zeros(x.shape[0], H, dtype=x.dtype)
+    cst = torch.zeros_like(h)
+    out = []
+    for t in range(x.shape[1]):
+        z = xp[:, t] + h @ recurrent_kernel
+        cst = torch.sigmoid(z[:, H:2 * H]) * cst + torch.sigmoid(z[:, :H]) * torch.tanh(z[:, 2 * H:3 * H])
+        h = torch.sigmoid(z[:, 3 * H:]) * torch.tanh(cst)
+        out.append(h)
+    return torch.stack(out, dim=1)
 
 
 def _spatial_layer(x, e, p, c, dtype, adj=None):
@@ -231,7 +274,10 @@ def forward(args, params, X, B, E, AE=None, ADJ=None):
         T = x.shape[1]
         y = x.permute(0, 2, 1, 3).reshape(-1, T, x.shape[-1])
         for i, p in enumerate(layers):
-            y = conv1d_causal(y, p['kernel'], p['bias'], 2 ** i, c.activation)
+            if c.recurrent == 'Conv1D':
+                y = conv1d_causal(y, p['kernel'], p['bias'], 2 ** i, c.activation)
+            else:
+                y = (gru_sequence if c.recurrent == 'GRU' else lstm_sequence)(y, p['kernel'], p['recurrent_kernel'], p['bias'])
         return y.reshape(nb, n, T, -1).permute(0, 2, 1, 3)
 
     x, e = spatial(x, e, params['block1'])

@@ -165,6 +165,23 @@ def test_network_forward_diffusion(dev, networks, graph_base):
     close(y, ry, TOL_FWD['fp32']); close(ey, rey, TOL_FWD['fp32'])
 
 
+@pytest.mark.parametrize('recurrent', ['GRU', 'LSTM', 'None'])
+def test_network_forward_recurrent_variants(dev, networks, recurrent):
+    """`get_tem_nets` (emulator.py:154-163): GRU / LSTM temporal layers (uds_recurrent_forward after a Dense input projection)
+    and the variant without temporal layers, against the step-by-step oracle (TF 2.10 gate conventions restated; unpinned)."""
+    args, params, emul, _ = _setup(networks, 'astlingen', dev, recurrent=recurrent, seq_in=7, seq_out=4, embed_size=32, hidden_dim=16,
+                                   n_sp_layer=1, n_tp_layer=2, if_flood=2)
+    X, Bd, Ex, a = _inputs(args, 2)
+    AE = OE.get_edge_action(OE.config(args), a)
+    ry, rey = OE.forward(args, params, X, Bd, Ex, AE)
+    f = lambda t: t.float().to(dev)
+    y, ey = emul(f(X), f(Bd), f(Ex), emul.get_edge_action(f(a)))
+    assert len(emul.tem1_x) == (0 if recurrent == 'None' else 2)
+    close(y, ry, TOL_FWD['bf16x3']); close(ey, rey, TOL_FWD['bf16x3'])
+    names = [n for n, _, _ in emul.keras_layer_map()]
+    assert (recurrent.lower() + '_3' in names) == (recurrent != 'None') and 'conv1d' not in names
+
+
 @pytest.mark.parametrize('graph_base', [0, 1])
 def test_network_forward_use_adj(dev, networks, graph_base):
     """`use_adj` (emulator.py:178-180,268-271,343-362): the control action rewrites the adjacency entry of every actuated link
@@ -407,5 +424,8 @@ def test_save_load_and_not_built(dev, networks, tmp_path):
     other.load(str(tmp_path))
     y1, e1 = other.predict_tf(f(X), f(Bd), f(a), f(Ex))
     assert torch.equal(y0, y1) and torch.equal(e0, e1)
-    with pytest.raises(NotImplementedError):
-        U.Emulator('GAT', False, 'GRU', args)
+    for bad in (dict(conv='General'), dict(recurrent='Transformer'), dict(dropout=0.2), dict(conv='GCN', use_adj=True)):
+        from types import SimpleNamespace
+        a2 = SimpleNamespace(**{**vars(args), **bad})
+        with pytest.raises(NotImplementedError):
+            U.Emulator(a2.conv, False, a2.recurrent, a2)

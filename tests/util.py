@@ -152,8 +152,11 @@ def load_emulator(emul, p, device):
         dense(emul.embed_ae, p['embed_ae'])
     spatial(emul.block1, p['block1']); spatial(emul.block2, p['block2'])
     for mods, key in ((emul.tem1_x, 'tem1_x'), (emul.tem1_e, 'tem1_e'), (emul.tem2_x, 'tem2_x'), (emul.tem2_e, 'tem2_e')):
+        assert len(mods) == len(p[key])
         for m, q in zip(mods, p[key]):
             dense(m, q)
+            if 'recurrent_kernel' in q:
+                m.recurrent_kernel.data = f32(q['recurrent_kernel'])
     dense(emul.res_x, p['res_x']); dense(emul.res_e, p['res_e']); dense(emul.out, p['out'])
     for m, q in zip(emul.flood, p['flood']):
         dense(m, q)
