@@ -74,3 +74,30 @@ def test_constrain_and_normalize_roundtrip(networks):
     hmax = torch.as_tensor(args.hmax)
     assert torch.equal(yc[..., 0][f], hmax.expand_as(yc[..., 0])[f])        # flooded nodes sit at hmax
     assert float(q_w[~f].abs().max()) == 0 and float(q_w[..., 0].abs().max()) == 0   # gated by the flood bit; outfall (node 0) never floods
+
+
+def test_gru_lstm_sequences_match_torch_modules():
+    """The GRU / LSTM restatements (TF 2.10 conventions: GRU reset_after=True with a (2, 3H) bias and gate order z, r, h; LSTM
+    gate order i, f, c, o) against torch.nn.GRU / LSTM, an independent implementation of the same recurrences (torch's GRU
+    also applies the reset gate AFTER the recurrent product; its gate order is r, z, n)."""
+    g = torch.Generator().manual_seed(11)
+    M, T, F, H = 5, 9, 6, 4
+    x = torch.rand(M, T, F, generator=g, dtype=torch.float64) - 0.5
+    r = lambda *s: torch.rand(*s, generator=g, dtype=torch.float64) - 0.5
+    # GRU
+    k, u, b = r(F, 3 * H), r(H, 3 * H), r(2, 3 * H)
+    ref = torch.nn.GRU(F, H, batch_first=True).double()
+    perm = torch.cat([torch.arange(H, 2 * H), torch.arange(0, H), torch.arange(2 * H, 3 * H)])       # keras (z, r, h) -> torch (r, z, n)
+    with torch.no_grad():
+        ref.weight_ih_l0.copy_(k[:, perm].T); ref.weight_hh_l0.copy_(u[:, perm].T)
+        ref.bias_ih_l0.copy_(b[0, perm]); ref.bias_hh_l0.copy_(b[1, perm])
+        want = ref(x)[0]
+    assert torch.allclose(OE.gru_sequence(x, k, u, b), want, atol=1e-13)
+    # LSTM (torch keeps two bias vectors that are simply added)
+    k, u, b = r(F, 4 * H), r(H, 4 * H), r(4 * H)
+    ref = torch.nn.LSTM(F, H, batch_first=True).double()
+    with torch.no_grad():
+        ref.weight_ih_l0.copy_(k.T); ref.weight_hh_l0.copy_(u.T)
+        ref.bias_ih_l0.copy_(b); ref.bias_hh_l0.zero_()
+        want = ref(x)[0]
+    assert torch.allclose(OE.lstm_sequence(x, k, u, b), want, atol=1e-13)
