@@ -157,12 +157,20 @@ def test_network_forward_diffusion(dev, networks, graph_base):
     """conv = Diffusion (emulator.py:135-138) through the whole network, two-graph and graph_base forms (parity unpinned)."""
     args, params, emul, _ = _setup(networks, 'astlingen', dev, conv='Diffusion', act=bool(graph_base), if_flood=0, seq_in=4, seq_out=4,
                                    embed_size=32, hidden_dim=32, n_sp_layer=2, n_tp_layer=1, graph_base=graph_base)
+    # a diffusion filter sums over all features of all nodes (the constant coefficient reaches every zero entry of the filter):
+    # with glorot-sized coefficients the heads saturate and the comparison would be vacuous -- shrink them
+    for blk in ('block1', 'block2'):
+        for q in params[blk]:
+            for conv in (q['gat'],) if 'gat' in q else (q['gat_x'], q['gat_e']):
+                conv['theta'] *= 0.002
+    load_emulator(emul, params, dev)
     X, Bd, Ex, a = _inputs(args, 2)           # graph_base stacks node and link rows: equal widths need the action embedding
     AE = OE.get_edge_action(OE.config(args), a) if graph_base else None
     ry, rey = OE.forward(args, params, X, Bd, Ex, AE)
     f = lambda t: t.float().to(dev)
     y, ey = emul(f(X), f(Bd), f(Ex), emul.get_edge_action(f(a)) if graph_base else None)
-    close(y, ry, TOL_FWD['fp32']); close(ey, rey, TOL_FWD['fp32'])
+    assert float(ry.std()) > 1e-3 and float(((ry > 0.02) & (ry < 0.98)).double().mean()) > 0.5      # not saturated: the comparison bites
+    close(y, ry, TOL_FWD['bf16x3']); close(ey, rey, TOL_FWD['bf16x3'])
 
 
 @pytest.mark.parametrize('recurrent', ['GRU', 'LSTM', 'None'])
