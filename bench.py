@@ -134,12 +134,25 @@ def trained_bias_leg(U, g, args, dev, x, e, reps=5):
         gemm_ms = (time.perf_counter() - t0) / reps * 1e3
     ms = float(np.median(ts)) * 1e3
     flops = 2.0 * g.n_node * g.n_edge * S * (d // 2)
+    # yardstick, not part of the product: the vendor library's plain bf16 GEMM with the SAME number of MFMA flops as the
+    # three split products (K tripled) -- what this part sustains in practice at this shape
+    la = torch.randn(g.n_node, 3 * g.n_edge, device=dev, dtype=torch.bfloat16)
+    lb = torch.randn(3 * g.n_edge, S * (d // 2), device=dev, dtype=torch.bfloat16)
+    torch.matmul(la, lb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        torch.matmul(la, lb)
+    torch.cuda.synchronize()
+    lib_ms = (time.perf_counter() - t0) / reps * 1e3
+    del la, lb
     return {'value': L * S / (ms * 1e-3), 'unit': 'graph-steps/s', 'ms_per_step': ms, 'path': [ly.last_path for ly in blk.layers],
             'remainder_gemm': {'kernel': 'k_remainder_gemm (128x128 tiles, split-bf16, 3 MFMA products)', 'ms': gemm_ms,
                                'shape': '(%d x %d) @ (%d x %d)' % (g.n_node, g.n_edge, g.n_edge, S * (d // 2)),
                                'tflops_fp32_equivalent': flops / gemm_ms / 1e9, 'tflops_bf16_issued': 3 * flops / gemm_ms / 1e9,
                                'bound': 'mfma', 'peak_tflops_bf16': 2500.0, 'frac': 3 * flops / gemm_ms / 1e9 / 2500.0,
-                               'launches_per_layer': 2},
+                               'launches_per_layer': 2, 'library_bf16_gemm_same_mfma_flops_ms': lib_ms,
+                               'frac_of_library_rate': lib_ms / gemm_ms},
             'note': 'NodeEdge with dense trained bias: 2*N*E*S*d/2 flops per side and layer on top of the support-only layer'}
 
 
