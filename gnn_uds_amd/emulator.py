@@ -920,8 +920,8 @@ class Emulator(nn.Module):
     def load_keras_weights(self, weights):
         """Weights of a trained reference model, keyed the way Keras stores them in `model.h5`:
         `weights['<layer>/<weight>:0']` or `weights['<layer>/<layer>/<weight>:0']` (the HDF5 group path) or
-        `weights['<layer>'] = [arrays in the layer's own order]`, values array-like.  h5py is not part of this image: read
-        the file where TensorFlow / h5py exist (`{n: f[n][()] ...}` -> `np.savez`) and pass the arrays here.  Shapes are
+        `weights['<layer>'] = [arrays in the layer's own order]`, values array-like.  `Emulator.load('model.h5')` reads the file
+        with the minimal HDF5 reader of `gnn_uds_amd/h5.py` and calls this; arrays dumped elsewhere with h5py work the same.  Shapes are
         checked; NodeEdge parameters created with sparse=True take the dense (R, M) arrays on their support and refuse a bias
         that is non-zero off it (ValueError: nothing is dropped silently)."""
         weights = dict(weights)
@@ -996,13 +996,20 @@ class Emulator(nn.Module):
         """emulator.py:833-852; `retrain=True` also restores the optimizer moments / step count and the GradNorm state, so
         that training resumes where it stopped (`--load_model`, main.py:199-205)."""
         model_dir = model_dir if model_dir is not None else self.model_dir
-        if model_dir.endswith('.h5'):
-            raise NotImplementedError('Keras HDF5 weights: convert with Emulator.load_keras_weights (h5py is not available here)')
-        if model_dir.endswith('.pt'):
+        keras = None
+        if model_dir.endswith('.h5'):                     # the reference's own layout: a Keras weight file (:835-838)
+            keras, model_dir = model_dir, os.path.dirname(model_dir)
+        elif model_dir.endswith('.pt'):
             weights, model_dir = model_dir, os.path.dirname(model_dir)
         else:
             weights = os.path.join(model_dir, 'model.pt')
-        self.load_state_dict(torch.load(weights, weights_only=True))
+            if not os.path.exists(weights) and os.path.exists(os.path.join(model_dir, 'model.h5')):
+                keras = os.path.join(model_dir, 'model.h5')   # a model directory written by the reference
+        if keras is not None:
+            from .h5 import read_keras_weights            # minimal HDF5 reader (no h5py in this image): see h5.py for what it covers
+            self.load_keras_weights(read_keras_weights(keras))
+        else:
+            self.load_state_dict(torch.load(weights, weights_only=True))
         for item in 'xbyre':
             path = os.path.join(model_dir, 'norm_%s.npy' % item)
             if os.path.exists(path):
