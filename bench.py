@@ -58,19 +58,23 @@ def rollout_forward(U, g, args, dev, reps=5):
     a = SimpleNamespace(state_shape=(g.n_node, 4), edge_state_shape=(g.n_edge, 4), seq_in=T, seq_out=T, embed_size=args.embed,
                         hidden_dim=64, kernel_size=3, n_sp_layer=args.layers, n_tp_layer=3, activation='relu', if_flood=3,
                         edge_fusion=True, edges=g.edges, act=False, graph=g, model_dir=None)
-    emul = U.Emulator('GAT', True, 'Conv1D', a, precision=args.precision, generator=torch.Generator().manual_seed(1)).to(dev)
     X = torch.rand(1, T, g.n_node, 5, device=dev)
     B = torch.rand(1, T, g.n_node, 1, device=dev)
     E = torch.rand(1, T, g.n_edge, 4, device=dev)
-    for _ in range(2):
-        emul(X, B, E)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        emul(X, B, E)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    return {'ms_per_forward': dt * 1e3, 'time_steps_per_s': T / dt, 'graph_steps_per_s_end_to_end': 2 * args.layers * T / dt,
+
+    def timed(recurrent):
+        emul = U.Emulator('GAT', True, recurrent, a, precision=args.precision, generator=torch.Generator().manual_seed(1)).to(dev)
+        for _ in range(2):
+            emul(X, B, E)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            emul(X, B, E)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+    dt = timed('Conv1D')               # 75 of the reference's 86 shipped model configurations; 6 use LSTM, 5 the GRU default
+    other = {'ms_per_forward_' + r: timed(r) * 1e3 for r in ('GRU', 'LSTM')}
+    return {'ms_per_forward': dt * 1e3, **other, 'time_steps_per_s': T / dt, 'graph_steps_per_s_end_to_end': 2 * args.layers * T / dt,
             'config': 'Emulator(GAT, resnet, Conv1D) B=1 T_in=T_out=%d, %d+%d spatial layers, 3+3 temporal layers x2 sides, '
                       'flood head' % (T, args.layers, args.layers)}
 

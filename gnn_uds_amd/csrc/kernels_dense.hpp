@@ -247,7 +247,7 @@ inline hipError_t launch_dense_act(const DenseArgs &a, hipStream_t st) {
 }
 
 // keras GRU / LSTM(units, return_sequences=True) along the time axis (emulator.py:158-161: the `recurrent` alternatives to
-// the causal Conv1D; no shipped model uses them).  The input projections xp = x @ kernel + input bias for ALL time steps
+// the causal Conv1D; 6 of the reference's 86 shipped model configurations use LSTM, 5 fall back to the GRU default).  The input projections xp = x @ kernel + input bias for ALL time steps
 // come from the Dense kernels; this kernel is the time recurrence, exact fp32.  A workgroup owns `rows` independent rows
 // (node or link series) and walks t = 0..T-1: thread (row, f) forms the G gate pre-activations of feature f,
 //     a_g = xp[b, t, n, g H + f] + sum_k h[row][k] U[k][g H + f] (+ recurrent bias),

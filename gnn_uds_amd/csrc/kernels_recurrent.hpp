@@ -1,0 +1,164 @@
+// keras GRU / LSTM(64, return_sequences=True) on 64-wide rows as ONE time-streaming kernel per layer on the matrix cores
+// (gfx950).  emulator.py:158-161: `recurrent: GRU` is the reference's default (`main.py` / utils/config.yaml), 6 of its 86
+// shipped model configurations use LSTM.
+//
+// A wave owns 16 consecutive rows (node or link series) of one batch element and walks the T steps.  Per step
+//     a = x[t] W + h U + biases          two 16 x 64 x (G*64) products on MFMA, split-bf16 (3 products, fp32 accumulate)
+//     gates, new state h' (and c' for the LSTM) in registers, h' stored as the layer output
+// With weights as the MFMA A operand and the 16 data rows as B, a lane ends up with features 16m + 4qd + {0..3} of row
+// lane & 15 for every 16-feature block m -- which, under this library's k ordering (frag_k: a lane's 8 operand elements are
+// the two 16-byte pieces 32t + 4qd and 32t + 16 + 4qd), is exactly the B-operand fragment of k-step t = m / 2: the new
+// state feeds the next step's `h U` product straight from the accumulator registers, no LDS round trip, no transpose.
+// x[t] is read from HBM in the same fragment shape (64 contiguous bytes per row and instruction), the next step's rows are
+// in flight while the current one is multiplied; the input projection is never written to memory.
+// Weights: W and U as 2*G packed 64 x 64 slices (uds_rowgemm_pack layout, 16 KB each: 96 KB for the GRU, 128 KB for the
+// LSTM) staged once per workgroup in LDS; 4 waves per workgroup, one per SIMD (the gate state + biases take ~200 VGPRs).
+// Gate conventions (TF 2.10 / Keras): GRU reset_after=True, order z, r, h; LSTM order i, f, c, o; sigmoid / tanh.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels_fused.hpp"
+
+namespace uds {
+
+struct RecurrentMfmaArgs {
+  const float *x, *b_in, *b_rec;      // x (B, T, R, 64); biases (G*64), b_rec NULL for the LSTM
+  const uint4 *packed;                 // G slices of W, then G slices of U: [(kt * 4 + m) * 2 + hl] * 64 + lane
+  float *out;                          // (B, T, R, 64)
+  int B, T, R, n_blocks;               // n_blocks = ceil(R / 16)
+};
+
+constexpr int RC_WAVES = 4;
+
+__device__ __forceinline__ float rc_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float rc_tanh(float v) {
+  const float e = __expf(-2.0f * fabsf(v));          // tanh(|v|) = (1 - e) / (1 + e): no overflow, full precision near 0 is not needed at 1e-6
+  const float t = (1.0f - e) / (1.0f + e);
+  return copysignf(t, v);
+}
+
+template <int G>
+__global__ __launch_bounds__(RC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_recurrent_mfma(RecurrentMfmaArgs a) {
+  constexpr int MB = 4, KT = 2, SLICE = KT * MB * 2 * 64;      // uint4 per packed 64 x 64 slice
+  extern __shared__ __attribute__((aligned(16))) uint4 wl_rc[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, qd = lane >> 4;
+  for (int i = tid; i < 2 * G * SLICE; i += RC_WAVES * 64) wl_rc[i] = a.packed[i];
+  __syncthreads();
+  const int unit = blockIdx.x * RC_WAVES + wave;       // (batch element, 16-row block)
+  if (unit >= a.B * a.n_blocks) return;
+  const int b = unit / a.n_blocks, nb = unit - b * a.n_blocks;
+  const int n_valid = min(16, a.R - nb * 16);
+  const bool live = r16 < n_valid;
+  const int64_t row0 = (int64_t)b * a.T * a.R + nb * 16 + min(r16, n_valid - 1);      // this lane's row at t = 0
+  const int64_t t_stride = (int64_t)a.R * 64;
+  const float *xl = a.x + row0 * 64 + 4 * qd;
+  float *ol = a.out + row0 * 64 + 4 * qd;
+
+  // biases in accumulator layout: feature 16 m + 4 qd + q of gate g
+  f32x4 bi[G][MB], br[MB];                             // br: recurrent bias of the candidate gate (GRU: multiplied by r)
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      f32x4 v = *reinterpret_cast<const f32x4 *>(a.b_in + g * 64 + 16 * m + 4 * qd);
+      if (G == 3 && g < 2 && a.b_rec) v += *reinterpret_cast<const f32x4 *>(a.b_rec + g * 64 + 16 * m + 4 * qd);
+      bi[g][m] = v;
+    }
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+    br[m] = (G == 3 && a.b_rec) ? *reinterpret_cast<const f32x4 *>(a.b_rec + 2 * 64 + 16 * m + 4 * qd) : f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int wl_lane = lane;      // laundered once per step: the weight fragments are re-read from LDS every step instead of being
+                           // hoisted out of the time loop (2 * G * 16 fragments = 384+ VGPRs: they would spill)
+  auto wfrag = [&](int mat, int g, int kt, int m, int hl) __attribute__((always_inline)) {
+    return __builtin_bit_cast(bf16x8, wl_rc[(mat * G + g) * SLICE + ((kt * MB + m) * 2 + hl) * 64 + wl_lane]);
+  };
+  // acc[m] += (frags of one 64-wide operand) x (slice `g` of matrix `mat`: 0 = W, 1 = U)
+  auto mult = [&](int mat, int g, f32x4 (&acc)[MB], const bf16x8 (&dh)[KT], const bf16x8 (&dl)[KT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int m = 0; m < MB; ++m) acc[m] = mfma3(wfrag(mat, g, kt, m, 0), wfrag(mat, g, kt, m, 1), dh[kt], dl[kt], acc[m]);
+  };
+
+  f32x4 h[MB], c[MB];
+#pragma unroll
+  for (int m = 0; m < MB; ++m) h[m] = c[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 hh[KT], hl[KT];                               // the state as B-operand fragments (zero at t = 0)
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) hh[kt] = hl[kt] = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
+
+  float4 xn[4];                                        // next step's x rows: pieces 4 qd and 16 + 4 qd of both k-steps
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xn[i] = *reinterpret_cast<const float4 *>(xl + 16 * i);
+  for (int t = 0; t < a.T; ++t) {
+    asm volatile("" : "+v"(wl_lane));
+    bf16x8 xh[KT], xlo[KT];
+    split8(xn[0], xn[1], xh[0], xlo[0]);
+    split8(xn[2], xn[3], xh[1], xlo[1]);
+    if (t + 1 < a.T) {
+      const float *nx = xl + (int64_t)(t + 1) * t_stride;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xn[i] = *reinterpret_cast<const float4 *>(nx + 16 * i);
+    }
+    f32x4 hn[MB];
+    if (G == 3) {
+      f32x4 az[MB], ar[MB], ax[MB], ah[MB];
+#pragma unroll
+      for (int m = 0; m < MB; ++m) az[m] = bi[0][m], ar[m] = bi[1][m], ax[m] = bi[2][m], ah[m] = br[m];
+      mult(0, 0, az, xh, xlo); mult(1, 0, az, hh, hl);
+      mult(0, 1, ar, xh, xlo); mult(1, 1, ar, hh, hl);
+      mult(0, 2, ax, xh, xlo); mult(1, 2, ah, hh, hl);
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float z = rc_sigmoid(az[m][q]), r = rc_sigmoid(ar[m][q]);
+          const float cand = rc_tanh(ax[m][q] + r * ah[m][q]);
+          hn[m][q] = z * h[m][q] + (1.0f - z) * cand;
+        }
+    } else {
+      f32x4 ai[MB], af[MB], ac[MB], ao[MB];
+#pragma unroll
+      for (int m = 0; m < MB; ++m) ai[m] = bi[0][m], af[m] = bi[1][m], ac[m] = bi[2][m], ao[m] = bi[G - 1][m];
+      mult(0, 0, ai, xh, xlo); mult(1, 0, ai, hh, hl);
+      mult(0, 1, af, xh, xlo); mult(1, 1, af, hh, hl);
+      mult(0, 2, ac, xh, xlo); mult(1, 2, ac, hh, hl);
+      mult(0, G - 1, ao, xh, xlo); mult(1, G - 1, ao, hh, hl);
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          c[m][q] = rc_sigmoid(af[m][q]) * c[m][q] + rc_sigmoid(ai[m][q]) * rc_tanh(ac[m][q]);
+          hn[m][q] = rc_sigmoid(ao[m][q]) * rc_tanh(c[m][q]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m) h[m] = hn[m];
+    // the new state in B-operand shape: blocks (0, 1) are k-step 0, (2, 3) k-step 1
+    split8(*reinterpret_cast<const float4 *>(&h[0]), *reinterpret_cast<const float4 *>(&h[1]), hh[0], hl[0]);
+    split8(*reinterpret_cast<const float4 *>(&h[2]), *reinterpret_cast<const float4 *>(&h[3]), hh[1], hl[1]);
+    if (live) {
+      float *o = ol + (int64_t)t * t_stride;
+#pragma unroll
+      for (int m = 0; m < MB; ++m) *reinterpret_cast<f32x4 *>(o + 16 * m) = h[m];
+    }
+  }
+}
+
+inline hipError_t launch_recurrent_mfma(const RecurrentMfmaArgs &a, int G, hipStream_t st) {
+  const int units = a.B * a.n_blocks;
+  const size_t lds = (size_t)2 * G * (2 * 4 * 2 * 64) * sizeof(uint4);
+  const void *fn = G == 3 ? reinterpret_cast<const void *>(&k_recurrent_mfma<3>) : reinterpret_cast<const void *>(&k_recurrent_mfma<4>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const dim3 grid((unsigned)((units + RC_WAVES - 1) / RC_WAVES));
+  if (G == 3) hipLaunchKernelGGL(k_recurrent_mfma<3>, grid, dim3(RC_WAVES * 64), lds, st, a);
+  else hipLaunchKernelGGL(k_recurrent_mfma<4>, grid, dim3(RC_WAVES * 64), lds, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace uds

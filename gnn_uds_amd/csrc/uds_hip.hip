@@ -23,6 +23,7 @@
 #include "kernels_conv_stream.hpp"
 #include "kernels_fused128.hpp"
 #include "kernels_gemm.hpp"
+#include "kernels_recurrent.hpp"
 #include "tile_plan.hpp"
 
 namespace {
@@ -312,6 +313,22 @@ int uds_conv1d_causal(const float *x, int64_t B, int64_t T, int64_t R, int64_t F
   a.t_rows = (int)R;
   hipError_t e = uds::launch_dense_act(a, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(UDS_EHIP, "uds_conv1d_causal: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
+int uds_recurrent_fused(const float *x, const void *packed, const float *b_in, const float *b_rec, int64_t B, int64_t T, int64_t R, int kind,
+                        float *out, uds_stream_t stream) {
+  UDS_REQUIRE(x && packed && b_in && out, "uds_recurrent_fused: NULL argument");
+  UDS_REQUIRE(kind == 0 || kind == 1, "uds_recurrent_fused: kind %d (0 = GRU, 1 = LSTM)", kind);
+  UDS_REQUIRE(B >= 0 && T >= 0 && R >= 0, "uds_recurrent_fused: bad sizes B=%lld T=%lld R=%lld", (long long)B, (long long)T, (long long)R);
+  UDS_REQUIRE(aligned16(x) && aligned16(out) && aligned16(packed) && aligned16(b_in) && aligned16(b_rec),
+              "uds_recurrent_fused: buffers must be 16-byte aligned");
+  if (B == 0 || T == 0 || R == 0) return UDS_OK;
+  const int64_t n_blocks = (R + 15) / 16;
+  UDS_REQUIRE(B * n_blocks < INT32_MAX && T < INT32_MAX, "uds_recurrent_fused: too many rows");
+  uds::RecurrentMfmaArgs a{x, b_in, b_rec, reinterpret_cast<const uint4 *>(packed), out, (int)B, (int)T, (int)R, (int)n_blocks};
+  hipError_t e = uds::launch_recurrent_mfma(a, kind == 0 ? 3 : 4, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_recurrent_fused: launch -> %s", hipGetErrorString(e));
   return UDS_OK;
 }
 

@@ -59,13 +59,14 @@ class Conv1D(nn.Module):
 class _Recurrent(nn.Module):
     """keras GRU / LSTM(units, return_sequences=True) along the time axis of x (B, T, R, F) (emulator.py:158-161): the input
     projection of every time step is one Dense launch, the recurrence one streaming kernel (uds_recurrent_forward), exact
-    fp32.  Parameters keep the Keras names and shapes -- `kernel` (F, G*units), `recurrent_kernel` (units, G*units), `bias`
+    fp32; a 64 -> 64 layer with precision='bf16x3' is ONE launch on the matrix cores (uds_recurrent_fused).  Parameters keep the Keras names and shapes -- `kernel` (F, G*units), `recurrent_kernel` (units, G*units), `bias`
     ((2, 3*units) for the TF2 GRU with reset_after=True: input and recurrent bias; (4*units,) for the LSTM) -- and the
     Keras initialisers (glorot_uniform, orthogonal, zeros with the LSTM's forget-gate bias at one).  Inference only."""
     KIND, G = None, 0
 
-    def __init__(self, units, return_sequences=True, in_features=None, generator=None):
+    def __init__(self, units, return_sequences=True, in_features=None, generator=None, precision='fp32'):
         super().__init__()
+        self.precision, self._packed = precision, None
         if not return_sequences:
             raise NotImplementedError('the emulator uses return_sequences=True (emulator.py:159,161)')
         self.units = int(units)
@@ -84,8 +85,14 @@ class _Recurrent(nn.Module):
         if _ag.grad_on(x, self.kernel, self.recurrent_kernel, self.bias):
             raise NotImplementedError('%s temporal layers are built for inference (no backward kernel)' % self.KIND)
         x = x.contiguous()
-        b_in, b_rec = (self.bias[0], self.bias[1].contiguous()) if self.KIND == 'GRU' else (self.bias, None)
-        xp = _lib.dense_act(x, self.kernel, b_in.contiguous(), 'linear')
+        b_in, b_rec = (self.bias[0].contiguous(), self.bias[1].contiguous()) if self.KIND == 'GRU' else (self.bias, None)
+        if self.precision == 'bf16x3' and x.shape[-1] == 64 and self.units == 64:
+            # the whole layer in one launch on the matrix cores (input projection never written out, state fed back in registers)
+            key = (self.kernel._version, self.recurrent_kernel._version, self.kernel.data_ptr(), self.recurrent_kernel.data_ptr())
+            if self._packed is None or self._packed[0] != key:
+                self._packed = (key, _lib.recurrent_pack(self.kernel, self.recurrent_kernel))
+            return _lib.recurrent_fused(x, self._packed[1], b_in, b_rec, self.KIND)
+        xp = _lib.dense_act(x, self.kernel, b_in, 'linear')
         return _lib.recurrent_forward(xp, self.recurrent_kernel, b_rec, self.KIND)
 
 
@@ -288,7 +295,7 @@ class Emulator(nn.Module):
                 mods = [Conv1D(H, self.kernel_size, 2 ** i, a, in_features=(f if i == 0 else H), generator=gen, precision=pr)
                         for i in range(self.n_tp_layer)]
             elif rec:
-                mods = [(GRU if rec == 'GRU' else LSTM)(H, in_features=(f if i == 0 else H), generator=gen) for i in range(self.n_tp_layer)]
+                mods = [(GRU if rec == 'GRU' else LSTM)(H, in_features=(f if i == 0 else H), generator=gen, precision=pr) for i in range(self.n_tp_layer)]
             else:
                 mods = []                                                                       # no temporal net: widths stay d
             return nn.ModuleList(mods)

@@ -15,7 +15,7 @@ Restates, on torch CPU tensors (fp64 or fp32), `surrogate/emulator.py` of the re
 `args` is any object with the reference's attribute names (`state_shape`, `edge_state_shape`, `seq_in`,
 `embed_size`, `adj`, `edge_adj`, `node_edge`, ... -- `Emulator.__init__`, emulator.py:48-127); `params`
 is the dict made by `init_params` (Keras creation order and initialisers).
-Not restated (the reference's shipped models never use them): use_adj for GCN / Diffusion (per-step re-normalised
+Not restated (none of the reference's shipped model configurations uses them): use_adj for GCN / Diffusion (per-step re-normalised
 filters), GeneralConv, the non-conv MLP variant, training-time dropout.
 """
 import math

@@ -173,6 +173,28 @@ def test_network_forward_diffusion(dev, networks, graph_base):
     close(y, ry, TOL_FWD['bf16x3']); close(ey, rey, TOL_FWD['bf16x3'])
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+@pytest.mark.parametrize('kind', ['GRU', 'LSTM'])
+def test_recurrent_layer_64(dev, kind, precision):
+    """One 64 -> 64 GRU / LSTM layer over (B, T, R, 64) with a ragged row count: the one-launch matrix-core kernel
+    (uds_recurrent_fused, precision bf16x3) and the Dense + exact-fp32 recurrence pair against the step-by-step oracle."""
+    from gnn_uds_amd.emulator import GRU, LSTM
+    g = torch.Generator().manual_seed(21)
+    B, T, R = 2, 11, 37
+    layer = (GRU if kind == 'GRU' else LSTM)(64, in_features=64, generator=g, precision=precision).to(dev)
+    with torch.no_grad():
+        layer.bias.add_(torch.rand(layer.bias.shape, generator=g).to(dev) * 0.2 - 0.1)
+    x = rnd(g, B, T, R, 64) * 2 - 1
+    f = OE.gru_sequence if kind == 'GRU' else OE.lstm_sequence
+    xs = x.permute(0, 2, 1, 3).reshape(B * R, T, 64)
+    ref = f(xs, layer.kernel.double().cpu(), layer.recurrent_kernel.double().cpu(), layer.bias.double().cpu())
+    ref = ref.reshape(B, R, T, 64).permute(0, 2, 1, 3)
+    out = layer(x.float().to(dev))
+    close(out, ref, TOL_FWD[precision])
+    one = layer(x[:, :1].float().to(dev).contiguous())            # T = 1
+    close(one, ref[:, :1], TOL_FWD[precision])
+
+
 @pytest.mark.parametrize('recurrent', ['GRU', 'LSTM', 'None'])
 def test_network_forward_recurrent_variants(dev, networks, recurrent):
     """`get_tem_nets` (emulator.py:154-163): GRU / LSTM temporal layers (uds_recurrent_forward after a Dense input projection)
