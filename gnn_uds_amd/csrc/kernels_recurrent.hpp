@@ -31,11 +31,11 @@ struct RecurrentMfmaArgs {
 
 constexpr int RC_WAVES = 4;
 
-__device__ __forceinline__ float rc_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
+// sigmoid / tanh on v_exp_f32 + v_rcp_f32 (1 ulp each): an IEEE fp32 division costs ten instructions, and a step has 48 of them
+__device__ __forceinline__ float rc_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 __device__ __forceinline__ float rc_tanh(float v) {
-  const float e = __expf(-2.0f * fabsf(v));          // tanh(|v|) = (1 - e) / (1 + e): no overflow, full precision near 0 is not needed at 1e-6
-  const float t = (1.0f - e) / (1.0f + e);
-  return copysignf(t, v);
+  const float e = __expf(-2.0f * fabsf(v));          // tanh(|v|) = (1 - e) / (1 + e): no overflow
+  return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), v);
 }
 
 template <int G>
@@ -76,14 +76,24 @@ __global__ __launch_bounds__(RC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1
   auto wfrag = [&](int mat, int g, int kt, int m, int hl) __attribute__((always_inline)) {
     return __builtin_bit_cast(bf16x8, wl_rc[(mat * G + g) * SLICE + ((kt * MB + m) * 2 + hl) * 64 + wl_lane]);
   };
-  // acc[m] += (frags of one 64-wide operand) x (slice `g` of matrix `mat`: 0 = W, 1 = U)
-  auto mult = [&](int mat, int g, f32x4 (&acc)[MB], const bf16x8 (&dh)[KT], const bf16x8 (&dl)[KT]) __attribute__((always_inline)) {
+  // One GROUP = one k-step of one 64 x 64 slice: 8 weight fragments (4 feature blocks x hi / lo) and 12 MFMAs on four
+  // independent accumulators (hi*lo for all four, lo*hi for all four, hi*hi for all four: a dependent MFMA is four
+  // instructions away).  The fragments of group i+1 are fetched from LDS before the MFMAs of group i are issued
+  // (sched_barrier keeps the compiler from sinking the reads back to their use, where each would expose its full latency
+  // to this SIMD's only wave).
+  bf16x8 fh[2][MB], fl[2][MB];
+  auto load_group = [&](int buf, int mat, int g, int kt) __attribute__((always_inline)) {
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-      for (int m = 0; m < MB; ++m) acc[m] = mfma3(wfrag(mat, g, kt, m, 0), wfrag(mat, g, kt, m, 1), dh[kt], dl[kt], acc[m]);
+    for (int m = 0; m < MB; ++m) fh[buf][m] = wfrag(mat, g, kt, m, 0), fl[buf][m] = wfrag(mat, g, kt, m, 1);
   };
-
+  auto mma_group = [&](int buf, f32x4 (&acc)[MB], const bf16x8 &dh, const bf16x8 &dl) __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[buf][m], dl, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[buf][m], dh, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[buf][m], dh, acc[m], 0, 0, 0);
+  };
   f32x4 h[MB], c[MB];
 #pragma unroll
   for (int m = 0; m < MB; ++m) h[m] = c[m] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -91,51 +101,74 @@ __global__ __launch_bounds__(RC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) hh[kt] = hl[kt] = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
 
-  float4 xn[4];                                        // next step's x rows: pieces 4 qd and 16 + 4 qd of both k-steps
-#pragma unroll
-  for (int i = 0; i < 4; ++i) xn[i] = *reinterpret_cast<const float4 *>(xl + 16 * i);
-  for (int t = 0; t < a.T; ++t) {
-    asm volatile("" : "+v"(wl_lane));
+  // The x part of a step does not depend on the state: it is computed one step AHEAD, issued between the state product and
+  // the gate arithmetic of the current step, so the matrix pipe works on it while the vector ALU does the gates.
+  constexpr int NGH = 2 * G;                          // groups per matrix: gate g = i / 2, k-step i % 2
+  f32x4 pre[G][MB];                                    // biases + x[t] W of the step about to run
+  float4 xn[4];                                        // x rows of the step after that: pieces 4 qd and 16 + 4 qd of both k-steps
+  auto x_part = [&]() __attribute__((always_inline)) { // pre = biases + xn W
     bf16x8 xh[KT], xlo[KT];
     split8(xn[0], xn[1], xh[0], xlo[0]);
     split8(xn[2], xn[3], xh[1], xlo[1]);
-    if (t + 1 < a.T) {
-      const float *nx = xl + (int64_t)(t + 1) * t_stride;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xn[i] = *reinterpret_cast<const float4 *>(nx + 16 * i);
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int m = 0; m < MB; ++m) pre[g][m] = bi[g][m];
+    load_group(0, 0, 0, 0);
+    static_for<NGH>([&](auto i_) {
+      constexpr int I = decltype(i_)::value, g = I / 2, kt = I % 2, buf = I % 2;
+      if (I + 1 < NGH) load_group(buf ^ 1, 0, (I + 1) / 2, (I + 1) % 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_group(buf, pre[g], xh[kt], xlo[kt]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xn[i] = *reinterpret_cast<const float4 *>(xl + 16 * i);
+  x_part();
+  if (a.T > 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xn[i] = *reinterpret_cast<const float4 *>(xl + t_stride + 16 * i);
+  }
+  for (int t = 0; t < a.T; ++t) {
+    asm volatile("" : "+v"(wl_lane));
+    f32x4 acc[G][MB], ah[MB];                          // ah: the candidate gate's recurrent part (GRU: multiplied by r)
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int m = 0; m < MB; ++m) acc[g][m] = pre[g][m];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) ah[m] = br[m];
+    load_group(0, 1, 0, 0);
+    static_for<NGH>([&](auto i_) {
+      constexpr int I = decltype(i_)::value, g = I / 2, kt = I % 2, buf = I % 2;
+      if (I + 1 < NGH) load_group(buf ^ 1, 1, (I + 1) / 2, (I + 1) % 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_group(buf, (G == 3 && g == 2) ? ah : acc[g], hh[kt], hl[kt]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (t + 1 < a.T) {
+      x_part();                                        // next step's x W: in the matrix pipe during the gates below
+      if (t + 2 < a.T) {
+        const float *nx = xl + (int64_t)(t + 2) * t_stride;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xn[i] = *reinterpret_cast<const float4 *>(nx + 16 * i);
+      }
     }
     f32x4 hn[MB];
-    if (G == 3) {
-      f32x4 az[MB], ar[MB], ax[MB], ah[MB];
 #pragma unroll
-      for (int m = 0; m < MB; ++m) az[m] = bi[0][m], ar[m] = bi[1][m], ax[m] = bi[2][m], ah[m] = br[m];
-      mult(0, 0, az, xh, xlo); mult(1, 0, az, hh, hl);
-      mult(0, 1, ar, xh, xlo); mult(1, 1, ar, hh, hl);
-      mult(0, 2, ax, xh, xlo); mult(1, 2, ah, hh, hl);
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
-      for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float z = rc_sigmoid(az[m][q]), r = rc_sigmoid(ar[m][q]);
-          const float cand = rc_tanh(ax[m][q] + r * ah[m][q]);
+      for (int q = 0; q < 4; ++q) {
+        if (G == 3) {
+          const float z = rc_sigmoid(acc[0][m][q]), r = rc_sigmoid(acc[1][m][q]);
+          const float cand = rc_tanh(acc[2][m][q] + r * ah[m][q]);
           hn[m][q] = z * h[m][q] + (1.0f - z) * cand;
+        } else {
+          c[m][q] = rc_sigmoid(acc[1][m][q]) * c[m][q] + rc_sigmoid(acc[0][m][q]) * rc_tanh(acc[2][m][q]);
+          hn[m][q] = rc_sigmoid(acc[G - 1][m][q]) * rc_tanh(c[m][q]);
         }
-    } else {
-      f32x4 ai[MB], af[MB], ac[MB], ao[MB];
-#pragma unroll
-      for (int m = 0; m < MB; ++m) ai[m] = bi[0][m], af[m] = bi[1][m], ac[m] = bi[2][m], ao[m] = bi[G - 1][m];
-      mult(0, 0, ai, xh, xlo); mult(1, 0, ai, hh, hl);
-      mult(0, 1, af, xh, xlo); mult(1, 1, af, hh, hl);
-      mult(0, 2, ac, xh, xlo); mult(1, 2, ac, hh, hl);
-      mult(0, G - 1, ao, xh, xlo); mult(1, G - 1, ao, hh, hl);
-#pragma unroll
-      for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          c[m][q] = rc_sigmoid(af[m][q]) * c[m][q] + rc_sigmoid(ai[m][q]) * rc_tanh(ac[m][q]);
-          hn[m][q] = rc_sigmoid(ao[m][q]) * rc_tanh(c[m][q]);
-        }
-    }
+      }
 #pragma unroll
     for (int m = 0; m < MB; ++m) h[m] = hn[m];
     // the new state in B-operand shape: blocks (0, 1) are k-step 0, (2, 3) k-step 1
