@@ -316,13 +316,15 @@ inline hipError_t launch_recurrent(const RecurrentArgs &a, hipStream_t st) {
   const int64_t total = (int64_t)a.B * a.R;
   const unsigned grid = (unsigned)((total + a.rows - 1) / a.rows);
   const size_t lds = ((size_t)a.H * a.G * a.H + (size_t)a.rows * a.H) * sizeof(float);
-  if (a.G == 3) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k_recurrent<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_recurrent<3>, dim3(grid), dim3(a.rows * a.H), lds, st, a);
-  } else {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k_recurrent<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_recurrent<4>, dim3(grid), dim3(a.rows * a.H), lds, st, a);
+  static size_t attr_lds[2] = {0, 0};                 // raise the dynamic-LDS limit once per size (not inside a stream capture)
+  if (lds > attr_lds[a.G - 3]) {
+    hipError_t e = hipFuncSetAttribute(a.G == 3 ? reinterpret_cast<const void *>(k_recurrent<3>) : reinterpret_cast<const void *>(k_recurrent<4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_lds[a.G - 3] = lds;
   }
+  if (a.G == 3) hipLaunchKernelGGL(k_recurrent<3>, dim3(grid), dim3(a.rows * a.H), lds, st, a);
+  else hipLaunchKernelGGL(k_recurrent<4>, dim3(grid), dim3(a.rows * a.H), lds, st, a);
   return hipGetLastError();
 }
 

@@ -185,9 +185,13 @@ __global__ __launch_bounds__(RC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1
 inline hipError_t launch_recurrent_mfma(const RecurrentMfmaArgs &a, int G, hipStream_t st) {
   const int units = a.B * a.n_blocks;
   const size_t lds = (size_t)2 * G * (2 * 4 * 2 * 64) * sizeof(uint4);
-  const void *fn = G == 3 ? reinterpret_cast<const void *>(&k_recurrent_mfma<3>) : reinterpret_cast<const void *>(&k_recurrent_mfma<4>);
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
+  static bool attr_set[2] = {false, false};           // once per kernel (and never inside a stream capture after the warm-up call)
+  if (!attr_set[G - 3]) {
+    const void *fn = G == 3 ? reinterpret_cast<const void *>(&k_recurrent_mfma<3>) : reinterpret_cast<const void *>(&k_recurrent_mfma<4>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set[G - 3] = true;
+  }
   const dim3 grid((unsigned)((units + RC_WAVES - 1) / RC_WAVES));
   if (G == 3) hipLaunchKernelGGL(k_recurrent_mfma<3>, grid, dim3(RC_WAVES * 64), lds, st, a);
   else hipLaunchKernelGGL(k_recurrent_mfma<4>, grid, dim3(RC_WAVES * 64), lds, st, a);

@@ -427,7 +427,9 @@ def test_graph_captured_rollout_equals_the_eager_loop(dev, networks):
     # the 2nd and 3rd configurations (no control actions) take the fused post-processing + feedback kernels (uds_roll_update):
     # without / with the flood channel, seq_out 2 / 1, window shift by 2 / 1 and seq_out == seq_in (no rows kept)
     for over in (dict(roll=4, seq_in=5, seq_out=1, n_sp_layer=1), dict(roll=3, seq_in=4, seq_out=2, n_sp_layer=1, act=False, if_flood=0),
-                 dict(roll=4, seq_in=5, seq_out=1, n_sp_layer=1, act=False), dict(roll=2, seq_in=3, seq_out=3, n_sp_layer=1, act=False)):
+                 dict(roll=4, seq_in=5, seq_out=1, n_sp_layer=1, act=False), dict(roll=2, seq_in=3, seq_out=3, n_sp_layer=1, act=False),
+                 dict(roll=3, seq_in=5, seq_out=1, n_sp_layer=1, act=False, recurrent='GRU'),       # the reference's default temporal net
+                 dict(roll=3, seq_in=4, seq_out=2, n_sp_layer=1, recurrent='LSTM')):
         args = emulator_args(edges, n, **over)
         norms = emulator_norms(args)
         emul = load_emulator(U.Emulator(args.conv, args.resnet, args.recurrent, args), OE.init_params(args, seed=2), dev)
