@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # UDS_LIB_PATH: a differently built copy of the same library (kernel experiments: tools/variant_bench.py)
 LIB_PATH = os.environ.get('UDS_LIB_PATH') or os.path.join(_HERE, 'libuds_hip.so')
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
 PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
 
@@ -38,7 +38,8 @@ SYMBOLS = {
     'uds_csr_spmm': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_int, _c_ptr, _c_ptr]),
     'uds_conv1d_causal': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr,
                                    _c_ptr]),
-    'uds_recurrent_fused': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
+    'uds_recurrent_fused': (_c_int, [_c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
+    'uds_recurrent_fused_supported': (_c_int, [_c_i64, _c_int]),
     'uds_recurrent_forward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_rowgemm_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
     'uds_rowgemm_pack': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
@@ -350,24 +351,31 @@ def conv1d_causal(x, kernel, bias=None, dilation=1, act='linear'):
     return out
 
 
+def recurrent_fused_supported(F, kind):
+    """Input forms uds_recurrent_fused takes: F = 64 / 128 input rows (W + U must fit the LDS), F = 0 = given projection."""
+    return bool(load().uds_recurrent_fused_supported(int(F), 0 if kind == 'GRU' else 1))
+
+
 def recurrent_pack(kernel, recurrent_kernel):
-    """MFMA fragments of a 64 -> 64 GRU / LSTM layer: the G 64-column slices of `kernel`, then of `recurrent_kernel`."""
-    G = kernel.shape[1] // 64
-    if tuple(kernel.shape) != (64, G * 64) or tuple(recurrent_kernel.shape) != (64, G * 64) or G not in (3, 4):
-        raise UdsError('recurrent_pack: kernel %r / recurrent kernel %r (64 x G*64 with G = 3 or 4)' % (tuple(kernel.shape), tuple(recurrent_kernel.shape)))
-    return torch.cat([rowgemm_pack(m[:, 64 * g:64 * (g + 1)].contiguous()) for m in (kernel, recurrent_kernel) for g in range(G)]).contiguous()
+    """MFMA fragments of a GRU / LSTM layer with 64 units: the G 64-column slices of `kernel` (F, G*64) -- none when kernel is
+    None (the input projection is computed separately) --, then of `recurrent_kernel` (64, G*64)."""
+    G = recurrent_kernel.shape[1] // 64
+    if tuple(recurrent_kernel.shape) != (64, G * 64) or G not in (3, 4) or (kernel is not None and kernel.shape[1] != G * 64):
+        raise UdsError('recurrent_pack: kernel %r / recurrent kernel %r (F x G*64 and 64 x G*64 with G = 3 or 4)'
+                       % (None if kernel is None else tuple(kernel.shape), tuple(recurrent_kernel.shape)))
+    mats = [recurrent_kernel] if kernel is None else [kernel, recurrent_kernel]
+    return torch.cat([rowgemm_pack(m[:, 64 * g:64 * (g + 1)].contiguous()) for m in mats for g in range(G)]).contiguous()
 
 
-def recurrent_fused(x, packed, b_in, b_rec, kind):
-    """Hidden states (B, T, R, 64) of a 64 -> 64 GRU / LSTM layer in one launch (uds_recurrent_fused)."""
+def recurrent_fused(x, packed, b_in, b_rec, kind, projected=False):
+    """Hidden states (B, T, R, 64) of a GRU / LSTM layer with 64 units in one launch (uds_recurrent_fused).  projected=True:
+    x is the input projection (B, T, R, G*64) incl. its bias."""
     lib = load()
     B, T, R, F = x.shape
-    if F != 64:
-        raise UdsError('recurrent_fused: 64-wide rows, got %d' % F)
     out = torch.empty((B, T, R, 64), device=x.device, dtype=torch.float32)
     if out.numel():
-        _check(lib.uds_recurrent_fused(_dev(x, 'x'), packed.data_ptr(), _dev(b_in, 'b_in'), _dev(b_rec, 'b_rec', True), B, T, R,
-                                       0 if kind == 'GRU' else 1, _dev(out, 'out'), _stream()), 'uds_recurrent_fused')
+        _check(lib.uds_recurrent_fused(_dev(x, 'x'), 0 if projected else F, packed.data_ptr(), _dev(b_in, 'b_in', True), _dev(b_rec, 'b_rec', True),
+                                       B, T, R, 0 if kind == 'GRU' else 1, _dev(out, 'out'), _stream()), 'uds_recurrent_fused')
     return out
 
 

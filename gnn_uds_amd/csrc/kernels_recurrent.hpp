@@ -23,8 +23,8 @@
 namespace uds {
 
 struct RecurrentMfmaArgs {
-  const float *x, *b_in, *b_rec;      // x (B, T, R, 64); biases (G*64), b_rec NULL for the LSTM
-  const uint4 *packed;                 // G slices of W, then G slices of U: [(kt * 4 + m) * 2 + hl] * 64 + lane
+  const float *x, *b_in, *b_rec;      // x (B, T, R, 32 KTX) -- or, KTX = 0, the input projection incl. bias (B, T, R, G*64); biases (G*64)
+  const uint4 *packed;                 // G slices of W (KTX k-steps each), then G slices of U (2 k-steps): [(kt * 4 + m) * 2 + hl] * 64 + lane
   float *out;                          // (B, T, R, 64)
   int B, T, R, n_blocks;               // n_blocks = ceil(R / 16)
 };
@@ -38,14 +38,17 @@ __device__ __forceinline__ float rc_tanh(float v) {
   return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), v);
 }
 
-template <int G>
+// KTX: k-steps of the input rows (2: 64-wide, 4: 128-wide -- the first temporal layer of a d = 128 model), 0: the input projection
+// is given (computed by the row-GEMM kernel: any input width, and the LSTM at 128 whose W + U do not fit the LDS together)
+template <int G, int KTX>
 __global__ __launch_bounds__(RC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_recurrent_mfma(RecurrentMfmaArgs a) {
-  constexpr int MB = 4, KT = 2, SLICE = KT * MB * 2 * 64;      // uint4 per packed 64 x 64 slice
+  constexpr int MB = 4, KT = 2, USLICE = KT * MB * 2 * 64, WSLICE = KTX * MB * 2 * 64;      // uint4 per packed slice
+  constexpr int FX = KTX ? 32 * KTX : G * 64, NX = KTX ? 2 * KTX : G * MB;                  // floats per input row, float4 per lane and step
   extern __shared__ __attribute__((aligned(16))) uint4 wl_rc[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, qd = lane >> 4;
-  for (int i = tid; i < 2 * G * SLICE; i += RC_WAVES * 64) wl_rc[i] = a.packed[i];
+  for (int i = tid; i < G * (WSLICE + USLICE); i += RC_WAVES * 64) wl_rc[i] = a.packed[i];
   __syncthreads();
   const int unit = blockIdx.x * RC_WAVES + wave;       // (batch element, 16-row block)
   if (unit >= a.B * a.n_blocks) return;
@@ -53,8 +56,8 @@ __global__ __launch_bounds__(RC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1
   const int n_valid = min(16, a.R - nb * 16);
   const bool live = r16 < n_valid;
   const int64_t row0 = (int64_t)b * a.T * a.R + nb * 16 + min(r16, n_valid - 1);      // this lane's row at t = 0
-  const int64_t t_stride = (int64_t)a.R * 64;
-  const float *xl = a.x + row0 * 64 + 4 * qd;
+  const int64_t t_stride = (int64_t)a.R * 64, x_stride = (int64_t)a.R * FX;
+  const float *xl = a.x + row0 * FX + 4 * qd;
   float *ol = a.out + row0 * 64 + 4 * qd;
 
   // biases in accumulator layout: feature 16 m + 4 qd + q of gate g
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(RC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1
   int wl_lane = lane;      // laundered once per step: the weight fragments are re-read from LDS every step instead of being
                            // hoisted out of the time loop (2 * G * 16 fragments = 384+ VGPRs: they would spill)
   auto wfrag = [&](int mat, int g, int kt, int m, int hl) __attribute__((always_inline)) {
-    return __builtin_bit_cast(bf16x8, wl_rc[(mat * G + g) * SLICE + ((kt * MB + m) * 2 + hl) * 64 + wl_lane]);
+    return __builtin_bit_cast(bf16x8, wl_rc[(mat ? G * WSLICE + g * USLICE : g * WSLICE) + ((kt * MB + m) * 2 + hl) * 64 + wl_lane]);
   };
   // One GROUP = one k-step of one 64 x 64 slice: 8 weight fragments (4 feature blocks x hi / lo) and 12 MFMAs on four
   // independent accumulators (hi*lo for all four, lo*hi for all four, hi*hi for all four: a dependent MFMA is four
@@ -103,33 +106,41 @@ __global__ __launch_bounds__(RC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1
 
   // The x part of a step does not depend on the state: it is computed one step AHEAD, issued between the state product and
   // the gate arithmetic of the current step, so the matrix pipe works on it while the vector ALU does the gates.
-  constexpr int NGH = 2 * G;                          // groups per matrix: gate g = i / 2, k-step i % 2
+  constexpr int NGH = 2 * G, NGX = KTX * G;            // groups of the state product / of the x part: gate g = i / k-steps, k-step i % k-steps
   f32x4 pre[G][MB];                                    // biases + x[t] W of the step about to run
-  float4 xn[4];                                        // x rows of the step after that: pieces 4 qd and 16 + 4 qd of both k-steps
-  auto x_part = [&]() __attribute__((always_inline)) { // pre = biases + xn W
-    bf16x8 xh[KT], xlo[KT];
-    split8(xn[0], xn[1], xh[0], xlo[0]);
-    split8(xn[2], xn[3], xh[1], xlo[1]);
+  float4 xn[NX];                                       // input of the step after that: pieces 4 qd and 16 + 4 qd of every k-step
+  auto load_x = [&](int t) __attribute__((always_inline)) {
+    const float *nx = xl + (int64_t)t * x_stride;
 #pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int m = 0; m < MB; ++m) pre[g][m] = bi[g][m];
-    load_group(0, 0, 0, 0);
-    static_for<NGH>([&](auto i_) {
-      constexpr int I = decltype(i_)::value, g = I / 2, kt = I % 2, buf = I % 2;
-      if (I + 1 < NGH) load_group(buf ^ 1, 0, (I + 1) / 2, (I + 1) % 2);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_group(buf, pre[g], xh[kt], xlo[kt]);
-      __builtin_amdgcn_sched_barrier(0);
-    });
+    for (int i = 0; i < NX; ++i) xn[i] = *reinterpret_cast<const float4 *>(nx + 16 * i);
   };
+  auto x_part = [&]() __attribute__((always_inline)) { // pre = biases + xn W   (KTX = 0: pre = the given projection)
+    if constexpr (KTX == 0) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) xn[i] = *reinterpret_cast<const float4 *>(xl + 16 * i);
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) pre[g][m] = f32x4{xn[g * MB + m].x, xn[g * MB + m].y, xn[g * MB + m].z, xn[g * MB + m].w};
+    } else {
+      bf16x8 xh[KTX ? KTX : 1], xlo[KTX ? KTX : 1];
+#pragma unroll
+      for (int k = 0; k < KTX; ++k) split8(xn[2 * k], xn[2 * k + 1], xh[k], xlo[k]);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) pre[g][m] = bi[g][m];
+      load_group(0, 0, 0, 0);
+      static_for<NGX>([&](auto i_) {
+        constexpr int I = decltype(i_)::value, g = I / (KTX ? KTX : 1), kt = I % (KTX ? KTX : 1), buf = I % 2;
+        if (I + 1 < NGX) load_group(buf ^ 1, 0, (I + 1) / (KTX ? KTX : 1), (I + 1) % (KTX ? KTX : 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mma_group(buf, pre[g], xh[kt], xlo[kt]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+  };
+  load_x(0);
   x_part();
-  if (a.T > 1) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) xn[i] = *reinterpret_cast<const float4 *>(xl + t_stride + 16 * i);
-  }
+  if (a.T > 1) load_x(1);
   for (int t = 0; t < a.T; ++t) {
     asm volatile("" : "+v"(wl_lane));
     f32x4 acc[G][MB], ah[MB];                          // ah: the candidate gate's recurrent part (GRU: multiplied by r)
@@ -149,11 +160,7 @@ __global__ __launch_bounds__(RC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1
     });
     if (t + 1 < a.T) {
       x_part();                                        // next step's x W: in the matrix pipe during the gates below
-      if (t + 2 < a.T) {
-        const float *nx = xl + (int64_t)(t + 2) * t_stride;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xn[i] = *reinterpret_cast<const float4 *>(nx + 16 * i);
-      }
+      if (t + 2 < a.T) load_x(t + 2);
     }
     f32x4 hn[MB];
 #pragma unroll
@@ -182,20 +189,29 @@ __global__ __launch_bounds__(RC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1
   }
 }
 
-inline hipError_t launch_recurrent_mfma(const RecurrentMfmaArgs &a, int G, hipStream_t st) {
-  const int units = a.B * a.n_blocks;
-  const size_t lds = (size_t)2 * G * (2 * 4 * 2 * 64) * sizeof(uint4);
-  static bool attr_set[2] = {false, false};           // once per kernel (and never inside a stream capture after the warm-up call)
-  if (!attr_set[G - 3]) {
-    const void *fn = G == 3 ? reinterpret_cast<const void *>(&k_recurrent_mfma<3>) : reinterpret_cast<const void *>(&k_recurrent_mfma<4>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+// LDS bytes of the (G, KTX) instantiation
+inline size_t recurrent_mfma_lds(int G, int ktx) { return (size_t)G * (ktx + 2) * (4 * 2 * 64) * sizeof(uint4); }
+
+template <int G, int KTX>
+inline hipError_t launch_recurrent_mfma_t(const RecurrentMfmaArgs &a, hipStream_t st) {
+  static bool attr_set = false;                        // once per kernel (never inside a stream capture after the warm-up call)
+  const size_t lds = recurrent_mfma_lds(G, KTX);
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_recurrent_mfma<G, KTX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_set[G - 3] = true;
+    attr_set = true;
   }
-  const dim3 grid((unsigned)((units + RC_WAVES - 1) / RC_WAVES));
-  if (G == 3) hipLaunchKernelGGL(k_recurrent_mfma<3>, grid, dim3(RC_WAVES * 64), lds, st, a);
-  else hipLaunchKernelGGL(k_recurrent_mfma<4>, grid, dim3(RC_WAVES * 64), lds, st, a);
+  const int units = a.B * a.n_blocks;
+  hipLaunchKernelGGL((k_recurrent_mfma<G, KTX>), dim3((unsigned)((units + RC_WAVES - 1) / RC_WAVES)), dim3(RC_WAVES * 64), lds, st, a);
   return hipGetLastError();
+}
+
+// which input forms the one-launch kernel takes: F = 64 / 128 input rows when W + U fit the 160 KiB LDS, F = 0 = given projection
+inline bool recurrent_mfma_supported(int G, int F) { return (F == 0 || F == 64 || F == 128) && recurrent_mfma_lds(G, F / 32) <= 160 * 1024; }
+
+inline hipError_t launch_recurrent_mfma(const RecurrentMfmaArgs &a, int G, int F, hipStream_t st) {
+  if (G == 3) return F == 0 ? launch_recurrent_mfma_t<3, 0>(a, st) : F == 64 ? launch_recurrent_mfma_t<3, 2>(a, st) : launch_recurrent_mfma_t<3, 4>(a, st);
+  return F == 0 ? launch_recurrent_mfma_t<4, 0>(a, st) : launch_recurrent_mfma_t<4, 2>(a, st);
 }
 
 }  // namespace uds

@@ -316,10 +316,13 @@ int uds_conv1d_causal(const float *x, int64_t B, int64_t T, int64_t R, int64_t F
   return UDS_OK;
 }
 
-int uds_recurrent_fused(const float *x, const void *packed, const float *b_in, const float *b_rec, int64_t B, int64_t T, int64_t R, int kind,
-                        float *out, uds_stream_t stream) {
-  UDS_REQUIRE(x && packed && b_in && out, "uds_recurrent_fused: NULL argument");
+int uds_recurrent_fused(const float *x, int64_t F, const void *packed, const float *b_in, const float *b_rec, int64_t B, int64_t T, int64_t R,
+                        int kind, float *out, uds_stream_t stream) {
+  UDS_REQUIRE(x && packed && out && (F == 0 || b_in), "uds_recurrent_fused: NULL argument");
   UDS_REQUIRE(kind == 0 || kind == 1, "uds_recurrent_fused: kind %d (0 = GRU, 1 = LSTM)", kind);
+  const int G = kind == 0 ? 3 : 4;
+  UDS_REQUIRE(uds::recurrent_mfma_supported(G, (int)F), "uds_recurrent_fused: input width %lld (64 or 128 where W + U fit the LDS, 0 = given projection)",
+              (long long)F);
   UDS_REQUIRE(B >= 0 && T >= 0 && R >= 0, "uds_recurrent_fused: bad sizes B=%lld T=%lld R=%lld", (long long)B, (long long)T, (long long)R);
   UDS_REQUIRE(aligned16(x) && aligned16(out) && aligned16(packed) && aligned16(b_in) && aligned16(b_rec),
               "uds_recurrent_fused: buffers must be 16-byte aligned");
@@ -327,10 +330,12 @@ int uds_recurrent_fused(const float *x, const void *packed, const float *b_in, c
   const int64_t n_blocks = (R + 15) / 16;
   UDS_REQUIRE(B * n_blocks < INT32_MAX && T < INT32_MAX, "uds_recurrent_fused: too many rows");
   uds::RecurrentMfmaArgs a{x, b_in, b_rec, reinterpret_cast<const uint4 *>(packed), out, (int)B, (int)T, (int)R, (int)n_blocks};
-  hipError_t e = uds::launch_recurrent_mfma(a, kind == 0 ? 3 : 4, static_cast<hipStream_t>(stream));
+  hipError_t e = uds::launch_recurrent_mfma(a, G, (int)F, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(UDS_EHIP, "uds_recurrent_fused: launch -> %s", hipGetErrorString(e));
   return UDS_OK;
 }
+
+int uds_recurrent_fused_supported(int64_t F, int kind) { return uds::recurrent_mfma_supported(kind == 0 ? 3 : 4, (int)F) ? 1 : 0; }
 
 int uds_recurrent_forward(const float *xp, const float *U, const float *rb, int64_t B, int64_t T, int64_t R, int64_t H, int kind,
                           float *out, uds_stream_t stream) {

@@ -86,12 +86,29 @@ class _Recurrent(nn.Module):
             raise NotImplementedError('%s temporal layers are built for inference (no backward kernel)' % self.KIND)
         x = x.contiguous()
         b_in, b_rec = (self.bias[0].contiguous(), self.bias[1].contiguous()) if self.KIND == 'GRU' else (self.bias, None)
-        if self.precision == 'bf16x3' and x.shape[-1] == 64 and self.units == 64:
-            # the whole layer in one launch on the matrix cores (input projection never written out, state fed back in registers)
-            key = (self.kernel._version, self.recurrent_kernel._version, self.kernel.data_ptr(), self.recurrent_kernel.data_ptr())
+        F = x.shape[-1]
+        if self.precision == 'bf16x3' and self.units == 64 and F % 32 == 0:
+            key = (self.kernel._version, self.recurrent_kernel._version, self.bias._version, self.kernel.data_ptr(), self.recurrent_kernel.data_ptr())
+            direct = _lib.recurrent_fused_supported(F, self.KIND)
             if self._packed is None or self._packed[0] != key:
-                self._packed = (key, _lib.recurrent_pack(self.kernel, self.recurrent_kernel))
-            return _lib.recurrent_fused(x, self._packed[1], b_in, b_rec, self.KIND)
+                if direct:
+                    self._packed = (key, _lib.recurrent_pack(self.kernel, self.recurrent_kernel))
+                else:     # W + U do not fit the LDS together (LSTM at 128) or another width: the projection on the row-GEMM kernel
+                    G = self.G
+                    fold = b_in.clone()
+                    if b_rec is not None:
+                        fold[:2 * 64] += b_rec[:2 * 64]               # the z / r gates add both biases (the candidate's stays apart)
+                    self._packed = (key, _lib.recurrent_pack(None, self.recurrent_kernel),
+                                    [_lib.rowgemm_pack(self.kernel[:, 64 * g:64 * (g + 1)].contiguous()) for g in range(G)], fold)
+            if direct:
+                # the whole layer in one launch on the matrix cores (input projection never written out, state fed back in registers)
+                return _lib.recurrent_fused(x, self._packed[1], b_in, b_rec, self.KIND)
+            if _lib.rowgemm_supported(F, F, 64):
+                _, packed_u, packed_w, fold = self._packed
+                xp = torch.empty(x.shape[:-1] + (self.G * 64,), device=x.device, dtype=torch.float32)
+                for g, pk in enumerate(packed_w):
+                    _lib.rowgemm_cat(x, None, pk, fold[64 * g:64 * (g + 1)].contiguous(), 64, 'linear', out=xp, col0=64 * g)
+                return _lib.recurrent_fused(xp, packed_u, None, b_rec, self.KIND, projected=True)
         xp = _lib.dense_act(x, self.kernel, b_in, 'linear')
         return _lib.recurrent_forward(xp, self.recurrent_kernel, b_rec, self.KIND)
 

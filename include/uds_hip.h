@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 11
+#define UDS_ABI_VERSION 12
 
 enum {
   UDS_OK = 0,
@@ -101,15 +101,20 @@ int uds_conv1d_causal(const float *x, int64_t B, int64_t T, int64_t R, int64_t F
 int uds_recurrent_forward(const float *xp, const float *U, const float *rb, int64_t B, int64_t T, int64_t R, int64_t H,
                           int kind, float *out, uds_stream_t stream);
 
-/* A whole keras GRU / LSTM(64, return_sequences=True) layer on 64-wide rows in ONE launch on the matrix cores (split-bf16,
- * three products, fp32 accumulation): input projection, recurrent product, gates and state update per time step, the state
- * fed back from the accumulator registers; x (B, T, R, 64) -> out (B, T, R, 64) = the hidden state after every step.
- * `packed` = uds_rowgemm_pack of the G 64-column slices of `kernel` (64, G*64), then of `recurrent_kernel` (64, G*64), back to
- * back (2 * G * 16 KiB); b_in (G*64) the input bias; b_rec (G*64) the recurrent bias of the TF2 GRU (reset_after=True) or
- * NULL; kind 0 = GRU (G = 3: z, r, h), 1 = LSTM (G = 4: i, f, c, o).  emulator.py:158-161 (`recurrent: GRU` is the
- * reference's default). */
-int uds_recurrent_fused(const float *x, const void *packed, const float *b_in, const float *b_rec, int64_t B, int64_t T,
-                        int64_t R, int kind, float *out, uds_stream_t stream);
+/* A whole keras GRU / LSTM(64, return_sequences=True) layer in ONE launch on the matrix cores (split-bf16, three products,
+ * fp32 accumulation): input projection, recurrent product, gates and state update per time step, the state fed back from
+ * the accumulator registers; out (B, T, R, 64) = the hidden state after every step.   emulator.py:158-161 (`recurrent: GRU`
+ * is the reference's default).
+ *   F = 64 or 128: x (B, T, R, F) are the input rows; `packed` = uds_rowgemm_pack of the G 64-column slices of `kernel`
+ *                  (F, G*64), then of `recurrent_kernel` (64, G*64), back to back; b_in (G*64) the input bias.
+ *   F = 0:         x (B, T, R, G*64) is the input projection `x @ kernel + bias` itself (any input width, computed by
+ *                  uds_rowgemm_forward_cat); `packed` holds the recurrent slices only; b_in is not read (for the GRU fold the
+ *                  recurrent bias of the z and r gates into the projection's bias).
+ * b_rec (G*64): the recurrent bias of the TF2 GRU (reset_after=True), NULL for the LSTM; kind 0 = GRU (G = 3: z, r, h),
+ * 1 = LSTM (G = 4: i, f, c, o).  uds_recurrent_fused_supported(F, kind): whether W + U of that form fit the LDS. */
+int uds_recurrent_fused_supported(int64_t F, int kind);
+int uds_recurrent_fused(const float *x, int64_t F, const void *packed, const float *b_in, const float *b_rec, int64_t B,
+                        int64_t T, int64_t R, int kind, float *out, uds_stream_t stream);
 
 /* Matrix-core version of uds_dense_act (taps = 1, T = 1: rows = B*R) and uds_conv1d_causal for F % 32 == 0 and
  * f_out <= 64: operands split into bf16 hi + lo, three MFMA products, fp32 accumulation (the fused spatial kernel's

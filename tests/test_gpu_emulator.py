@@ -174,19 +174,23 @@ def test_network_forward_diffusion(dev, networks, graph_base):
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+@pytest.mark.parametrize('F', [64, 128, 96])
 @pytest.mark.parametrize('kind', ['GRU', 'LSTM'])
-def test_recurrent_layer_64(dev, kind, precision):
-    """One 64 -> 64 GRU / LSTM layer over (B, T, R, 64) with a ragged row count: the one-launch matrix-core kernel
-    (uds_recurrent_fused, precision bf16x3) and the Dense + exact-fp32 recurrence pair against the step-by-step oracle."""
+def test_recurrent_layer_64(dev, kind, F, precision):
+    """One F -> 64 GRU / LSTM layer over (B, T, R, F) with a ragged row count against the step-by-step oracle: the one-launch
+    matrix-core kernel on the input rows (uds_recurrent_fused: F = 64, and 128 -- the first temporal layer of a d = 128 model
+    -- where W + U fit the LDS: the GRU), the same kernel on a row-GEMM input projection (LSTM at 128, F = 96), and the Dense +
+    exact-fp32 recurrence pair (precision fp32)."""
     from gnn_uds_amd.emulator import GRU, LSTM
     g = torch.Generator().manual_seed(21)
     B, T, R = 2, 11, 37
-    layer = (GRU if kind == 'GRU' else LSTM)(64, in_features=64, generator=g, precision=precision).to(dev)
+    layer = (GRU if kind == 'GRU' else LSTM)(64, in_features=F, generator=g, precision=precision).to(dev)
     with torch.no_grad():
         layer.bias.add_(torch.rand(layer.bias.shape, generator=g).to(dev) * 0.2 - 0.1)
-    x = rnd(g, B, T, R, 64) * 2 - 1
+    assert _lib.recurrent_fused_supported(F, kind) == (F == 64 or (F == 128 and kind == 'GRU'))
+    x = rnd(g, B, T, R, F) * 2 - 1
     f = OE.gru_sequence if kind == 'GRU' else OE.lstm_sequence
-    xs = x.permute(0, 2, 1, 3).reshape(B * R, T, 64)
+    xs = x.permute(0, 2, 1, 3).reshape(B * R, T, F)
     ref = f(xs, layer.kernel.double().cpu(), layer.recurrent_kernel.double().cpu(), layer.bias.double().cpu())
     ref = ref.reshape(B, R, T, 64).permute(0, 2, 1, 3)
     out = layer(x.float().to(dev))
