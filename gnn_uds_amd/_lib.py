@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # UDS_LIB_PATH: a differently built copy of the same library (kernel experiments: tools/variant_bench.py)
 LIB_PATH = os.environ.get('UDS_LIB_PATH') or os.path.join(_HERE, 'libuds_hip.so')
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
 PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
 
@@ -38,6 +38,7 @@ SYMBOLS = {
     'uds_csr_spmm': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_int, _c_ptr, _c_ptr]),
     'uds_conv1d_causal': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr,
                                    _c_ptr]),
+    'uds_dense_cumsum_heads': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr]),
     'uds_recurrent_fused': (_c_int, [_c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_recurrent_fused_supported': (_c_int, [_c_i64, _c_int]),
     'uds_recurrent_forward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
@@ -542,6 +543,40 @@ def dense_cumsum(x, packed, bias=None, res=None, act='linear'):
         return out
     _check(lib.uds_dense_cumsum(_dev(x, 'x'), B, T, R, packed.data_ptr(), _dev(bias, 'bias', True), _dev(res, 'res', True), ACT[act],
                                 _dev(out, 'out'), _stream()), 'uds_dense_cumsum')
+    return out
+
+
+class _Heads(ctypes.Structure):
+    _fields_ = [('a_packed', ctypes.c_void_p), ('a_bias', ctypes.c_void_p), ('h_packed', ctypes.c_void_p * 3), ('h_bias', ctypes.c_void_p * 3),
+                ('f_packed', ctypes.c_void_p), ('f_bias', ctypes.c_void_p), ('n_a', ctypes.c_int32), ('act_a', ctypes.c_int32),
+                ('n_hidden', ctypes.c_int32), ('act_h', ctypes.c_int32), ('act_f', ctypes.c_int32)]
+
+
+def dense_cumsum_heads(x, packed, bias, res, act, head_a, hidden=(), head_f=None):
+    """uds_dense_cumsum_heads: act(cumsum_t(x @ kernel + bias) + res) consumed by its heads without being written.
+    head_a = (packed (64, n_a), bias, n_a, activation); hidden = [(packed, bias), ...] the Dense(32) layers of the second
+    head with their common activation in hidden_act = head_f[3]; head_f = (packed (32, 1), bias, activation, hidden activation).
+    Returns (B, T, R, n_a + (1 if hidden else 0))."""
+    lib = load()
+    B, T, R, F = x.shape
+    if F != 64:
+        raise UdsError('dense_cumsum_heads: 64 -> 64 only, got %d inputs' % F)
+    if res is not None and tuple(res.shape) != (B, 1, R, 64):
+        raise UdsError('dense_cumsum_heads: res must be %r, got %r' % ((B, 1, R, 64), tuple(res.shape)))
+    hd = _Heads()
+    keep = [head_a[0], head_a[1]]
+    hd.a_packed, hd.a_bias, hd.n_a, hd.act_a = head_a[0].data_ptr(), _dev(head_a[1], 'a_bias', True), int(head_a[2]), ACT[head_a[3]]
+    hd.n_hidden = len(hidden)
+    for i, (pk, bs) in enumerate(hidden):
+        hd.h_packed[i], hd.h_bias[i] = pk.data_ptr(), _dev(bs, 'h_bias', True)
+        keep += [pk, bs]
+    if hidden:
+        hd.f_packed, hd.f_bias, hd.act_f, hd.act_h = head_f[0].data_ptr(), _dev(head_f[1], 'f_bias', True), ACT[head_f[2]], ACT[head_f[3]]
+        keep += [head_f[0], head_f[1]]
+    out = torch.empty((B, T, R, hd.n_a + (1 if hidden else 0)), device=x.device, dtype=torch.float32)
+    if out.numel():
+        _check(lib.uds_dense_cumsum_heads(_dev(x, 'x'), B, T, R, packed.data_ptr(), _dev(bias, 'bias', True), _dev(res, 'res', True), ACT[act],
+                                          ctypes.byref(hd), _dev(out, 'out'), _stream()), 'uds_dense_cumsum_heads')
     return out
 
 

@@ -333,4 +333,190 @@ inline hipError_t launch_dense_cumsum(const DenseCumsumArgs &a, hipStream_t st) 
   return launch_dense_cumsum_a<-1>(a, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_dense_cumsum_stream with the emulator's output heads as its epilogue (emulator.py:313-338): the 64-wide resnet output
+//     y[t] = act(cumsum_t(x W + b) + res)
+// is consumed where it is produced -- by `out` = Dense(n_a <= 4, act_a)(y) and, optionally, the flood chain
+// Dense(32, act) x n_hidden (64 -> 32 -> 32 -> 32) + Dense(1, act_f) -- and only the n_a (+ 1) head outputs per row are written:
+// y never reaches HBM (one 256-byte row write and three row reads fewer per row and step, and five to eight launches fewer).
+// The accumulator layout of one layer (lane (r16, qd): features 16 m + 4 qd + q of row r16) is the B-operand fragment
+// layout of the next (frag_k), so the chain runs from registers: split8 of two accumulator blocks = one k-step.
+struct HeadsArgs {
+  const uint4 *a_packed;            // (64, n_a) padded to 16 outputs: 2 k-steps x 1 block
+  const float *a_bias;              // n_a floats
+  const uint4 *h_packed[3];         // hidden layers: (64, 32), (32, 32), (32, 32)
+  const float *h_bias[3];
+  const uint4 *f_packed;            // (32, 1) padded to 16 outputs
+  const float *f_bias;
+  int n_a, act_a, n_hidden, act_h, act_f;
+};
+
+// two waves per SIMD (the head chain is a serial dependency per step: a second wave fills its gaps): 4 waves per workgroup with a
+// ring of 3 x 4 KiB each + 16 KiB of weights = 64 KiB, two workgroups per CU
+constexpr int DH_WAVES = 4, DH_PREF = 2, DH_RING = DH_PREF + 1;
+
+template <int ACT>
+__global__ __launch_bounds__(DH_WAVES * 64, 2) void k_dense_cumsum_heads(DenseCumsumArgs a, HeadsArgs hd) {
+  constexpr int F = 64, MB = 4, KT = 2;
+  extern __shared__ __attribute__((aligned(16))) float smem_dc[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, qd = lane >> 4;
+  uint4 *wlds = reinterpret_cast<uint4 *>(smem_dc);
+  float *ring = smem_dc + KT * MB * 2 * 64 * 4 + wave * (DH_RING * 1024);
+  for (int i = tid; i < KT * MB * 2 * 64; i += DH_WAVES * 64) wlds[i] = a.packed[i];
+  __syncthreads();
+  const int unit = blockIdx.x * DH_WAVES + wave;
+  if (unit >= a.B * a.n_blocks) return;
+  const int b = unit / a.n_blocks, nb = unit - b * a.n_blocks;
+  const int n_valid = min(16, a.R - nb * 16);
+  const int64_t row0 = (int64_t)b * a.T * a.R + nb * 16;
+  const int my_row = min(r16, n_valid - 1);
+  const float *src_lane = a.x + (row0 + my_row) * F + 4 * qd;
+  const int64_t t_stride = (int64_t)a.R * F;
+  const unsigned my_lds = __builtin_amdgcn_readfirstlane(lds_addr(ring));
+  auto issue = [&](int t, int slot) {
+    const float *s = src_lane + (int64_t)min(t, a.T - 1) * t_stride;
+    const float *pc[4] = {s, s + 16, s + 32, s + 48};
+    glds16_run<4>(pc, my_lds + (unsigned)slot * 4096);
+  };
+#pragma unroll
+  for (int q = 0; q < DH_PREF; ++q) issue(q, q);
+  // the 64 x 64 kernel stays in LDS and is re-read every step (the head fragments take the registers it had in
+  // k_dense_cumsum_stream); the laundered lane index keeps the reads inside the time loop
+  int wl_lane = lane;
+  f32x4 bb[MB], rr[MB], run[MB];
+#pragma unroll
+  for (int m = 0; m < MB; ++m) {
+    bb[m] = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + 16 * m + 4 * qd) : f32x4{0.f, 0.f, 0.f, 0.f};
+    rr[m] = a.res ? *reinterpret_cast<const f32x4 *>(a.res + ((int64_t)b * a.R + nb * 16 + my_row) * F + 16 * m + 4 * qd)
+                  : f32x4{0.f, 0.f, 0.f, 0.f};
+    run[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // head weights as register-resident fragments (22 of them), biases in accumulator layout
+  auto frag = [&](const uint4 *p, int kt, int mb, int m, int hl) __attribute__((always_inline)) {
+    return __builtin_bit_cast(bf16x8, p[((kt * mb + m) * 2 + hl) * 64 + lane]);
+  };
+  auto bias4 = [&](const float *p, int n, int m) __attribute__((always_inline)) {      // features 16 m + 4 qd + q, zero past n
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (p && 16 * m + 4 * qd + q < n) ? p[16 * m + 4 * qd + q] : 0.0f;
+    return v;
+  };
+  bf16x8 ah[KT], al[KT], h1h[KT][2], h1l[KT][2], h2h[2], h2l[2], h3h[2], h3l[2], fh, fl;
+  f32x4 ab = bias4(hd.a_bias, hd.n_a, 0), h1b[2], h2b[2], h3b[2], fb = bias4(hd.f_bias, 1, 0);
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) ah[kt] = frag(hd.a_packed, kt, 1, 0, 0), al[kt] = frag(hd.a_packed, kt, 1, 0, 1);
+  if (hd.n_hidden > 0) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) h1h[kt][m] = frag(hd.h_packed[0], kt, 2, m, 0), h1l[kt][m] = frag(hd.h_packed[0], kt, 2, m, 1);
+      h1b[m] = bias4(hd.h_bias[0], 32, m);
+      if (hd.n_hidden > 1) h2h[m] = frag(hd.h_packed[1], 0, 2, m, 0), h2l[m] = frag(hd.h_packed[1], 0, 2, m, 1), h2b[m] = bias4(hd.h_bias[1], 32, m);
+      if (hd.n_hidden > 2) h3h[m] = frag(hd.h_packed[2], 0, 2, m, 0), h3l[m] = frag(hd.h_packed[2], 0, 2, m, 1), h3b[m] = bias4(hd.h_bias[2], 32, m);
+    }
+    fh = frag(hd.f_packed, 0, 1, 0, 0), fl = frag(hd.f_packed, 0, 1, 0, 1);
+  }
+  const int n_out = hd.n_a + (hd.n_hidden > 0 ? 1 : 0);
+  int slot = 0;
+  for (int t = 0; t < a.T; ++t) {
+    int rs = slot + DH_PREF;
+    rs = rs >= DH_RING ? rs - DH_RING : rs;
+    issue(t + DH_PREF, rs);
+    // x[t] landed once everything older than its 4 pieces is done: younger = 4 pieces per prefetched step (the head outputs are
+    // plain stores of a few bytes per row: they count as vector-memory operations too, one per step, hence the + K below)
+    const int st = min(t, DH_PREF);
+    bool waited = false;
+    static_for<DH_PREF>([&](auto k_) {
+      constexpr int K = decltype(k_)::value;
+      if (st == K) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * DH_PREF) : "memory");
+        waited = true;
+      }
+    });
+    if (!waited) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * DH_PREF) : "memory");
+    const float4 *sl = reinterpret_cast<const float4 *>(ring + slot * 1024) + lane;
+    const float4 v0 = sl[0], v1 = sl[64], v2 = sl[128], v3 = sl[192];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    slot = slot + 1 == DH_RING ? 0 : slot + 1;
+    bf16x8 dh[2], dl[2];
+    split8(v0, v1, dh[0], dl[0]);
+    split8(v2, v3, dh[1], dl[1]);
+    asm volatile("" : "+v"(wl_lane));
+#pragma unroll
+    for (int h = 0; h < KT; ++h)
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+        run[m] = mfma3(__builtin_bit_cast(bf16x8, wlds[((h * MB + m) * 2 + 0) * 64 + wl_lane]),
+                       __builtin_bit_cast(bf16x8, wlds[((h * MB + m) * 2 + 1) * 64 + wl_lane]), dh[h], dl[h], run[m]);
+    const float tb = (float)(t + 1);
+    f32x4 y[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[m][j] = fused_act<ACT>(run[m][j] + fmaf(tb, bb[m][j], rr[m][j]), a.act);
+    bf16x8 yh[KT], yl[KT];
+    split8(*reinterpret_cast<const float4 *>(&y[0]), *reinterpret_cast<const float4 *>(&y[1]), yh[0], yl[0]);
+    split8(*reinterpret_cast<const float4 *>(&y[2]), *reinterpret_cast<const float4 *>(&y[3]), yh[1], yl[1]);
+    f32x4 oa = ab;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) oa = mfma3(ah[kt], al[kt], yh[kt], yl[kt], oa);
+    float of = 0.0f;
+    if (hd.n_hidden > 0) {
+      f32x4 c1[2] = {h1b[0], h1b[1]};
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) c1[m] = mfma3(h1h[kt][m], h1l[kt][m], yh[kt], yl[kt], c1[m]);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c1[m][j] = apply_act(c1[m][j], hd.act_h);
+      bf16x8 ch, cl;
+      split8(*reinterpret_cast<const float4 *>(&c1[0]), *reinterpret_cast<const float4 *>(&c1[1]), ch, cl);
+      if (hd.n_hidden > 1) {
+        f32x4 c2[2] = {h2b[0], h2b[1]};
+#pragma unroll
+        for (int m = 0; m < 2; ++m) c2[m] = mfma3(h2h[m], h2l[m], ch, cl, c2[m]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) c2[m][j] = apply_act(c2[m][j], hd.act_h);
+        split8(*reinterpret_cast<const float4 *>(&c2[0]), *reinterpret_cast<const float4 *>(&c2[1]), ch, cl);
+      }
+      if (hd.n_hidden > 2) {
+        f32x4 c3[2] = {h3b[0], h3b[1]};
+#pragma unroll
+        for (int m = 0; m < 2; ++m) c3[m] = mfma3(h3h[m], h3l[m], ch, cl, c3[m]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) c3[m][j] = apply_act(c3[m][j], hd.act_h);
+        split8(*reinterpret_cast<const float4 *>(&c3[0]), *reinterpret_cast<const float4 *>(&c3[1]), ch, cl);
+      }
+      f32x4 cf = mfma3(fh, fl, ch, cl, fb);
+      of = apply_act(cf[0], hd.act_f);
+    }
+    if (qd == 0 && r16 < n_valid) {       // lane (r16, 0) holds outputs 0..3 of its row
+      float *o = a.out + (row0 + (int64_t)t * a.R + r16) * n_out;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < hd.n_a) o[j] = apply_act(oa[j], hd.act_a);
+      if (hd.n_hidden > 0) o[hd.n_a] = of;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+inline hipError_t launch_dense_cumsum_heads(const DenseCumsumArgs &a, const HeadsArgs &hd, hipStream_t st) {
+  const int units = a.B * a.n_blocks;
+  const dim3 grid((unsigned)((units + DH_WAVES - 1) / DH_WAVES)), block(DH_WAVES * 64);
+  const size_t lds = (size_t)2 * 4 * 2 * 1024 + (size_t)DH_WAVES * DH_RING * 4096;
+  if (a.act == 1) hipLaunchKernelGGL((k_dense_cumsum_heads<1>), grid, block, lds, st, a, hd);
+  else if (a.act == 0) hipLaunchKernelGGL((k_dense_cumsum_heads<0>), grid, block, lds, st, a, hd);
+  else hipLaunchKernelGGL((k_dense_cumsum_heads<-1>), grid, block, lds, st, a, hd);
+  return hipGetLastError();
+}
+
 }  // namespace uds

@@ -477,6 +477,37 @@ int uds_dense_cumsum(const float *x, int64_t B, int64_t T, int64_t R, const void
   return UDS_OK;
 }
 
+int uds_dense_cumsum_heads(const float *x, int64_t B, int64_t T, int64_t R, const void *packed, const float *bias, const float *res, int act,
+                           const uds_heads_t *heads, float *out, uds_stream_t stream) {
+  UDS_REQUIRE(x && packed && out && heads, "uds_dense_cumsum_heads: NULL x/packed/heads/out");
+  UDS_REQUIRE(B >= 0 && T > 0 && R > 0, "uds_dense_cumsum_heads: bad sizes B=%lld T=%lld R=%lld", (long long)B, (long long)T, (long long)R);
+  UDS_REQUIRE(act >= UDS_ACT_LINEAR && act <= UDS_ACT_HARD_SIGMOID, "uds_dense_cumsum_heads: unknown activation %d", act);
+  UDS_REQUIRE(heads->a_packed && heads->n_a >= 1 && heads->n_a <= 4, "uds_dense_cumsum_heads: first head needs 1..4 outputs (got %d)", heads->n_a);
+  UDS_REQUIRE(heads->n_hidden >= 0 && heads->n_hidden <= 3, "uds_dense_cumsum_heads: 0..3 hidden layers in the second head (got %d)", heads->n_hidden);
+  for (int i = 0; i < heads->n_hidden; ++i) UDS_REQUIRE(heads->h_packed[i], "uds_dense_cumsum_heads: hidden layer %d has no weights", i);
+  UDS_REQUIRE(heads->n_hidden == 0 || heads->f_packed, "uds_dense_cumsum_heads: the second head has no output layer");
+  for (int v : {heads->act_a, heads->act_h, heads->act_f})
+    UDS_REQUIRE(v >= UDS_ACT_LINEAR && v <= UDS_ACT_HARD_SIGMOID, "uds_dense_cumsum_heads: unknown head activation %d", v);
+  UDS_REQUIRE(aligned16(x) && aligned16(packed) && aligned16(bias) && aligned16(res) && aligned16(heads->a_packed) && aligned16(heads->f_packed),
+              "uds_dense_cumsum_heads: pointers must be 16-byte aligned");
+  UDS_REQUIRE(B * T * R < INT32_MAX, "uds_dense_cumsum_heads: %lld rows exceed the int32 row index", (long long)(B * T * R));
+  if (B == 0) return UDS_OK;
+  uds::DenseCumsumArgs a{x, bias, res, reinterpret_cast<const uint4 *>(packed), out, (int)B, (int)T, (int)R, act, (int)((R + 15) / 16)};
+  uds::HeadsArgs hd{};
+  hd.a_packed = reinterpret_cast<const uint4 *>(heads->a_packed);
+  hd.a_bias = heads->a_bias;
+  for (int i = 0; i < 3; ++i) {
+    hd.h_packed[i] = reinterpret_cast<const uint4 *>(heads->h_packed[i]);
+    hd.h_bias[i] = heads->h_bias[i];
+  }
+  hd.f_packed = reinterpret_cast<const uint4 *>(heads->f_packed);
+  hd.f_bias = heads->f_bias;
+  hd.n_a = heads->n_a, hd.act_a = heads->act_a, hd.n_hidden = heads->n_hidden, hd.act_h = heads->act_h, hd.act_f = heads->act_f;
+  hipError_t e = uds::launch_dense_cumsum_heads(a, hd, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_dense_cumsum_heads: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
 int uds_cumsum_act(const float *x, const float *res, int64_t B, int64_t T, int64_t R, int64_t F, int act, float *out,
                    uds_stream_t stream) {
   UDS_REQUIRE(x && out, "uds_cumsum_act: NULL x/out");

@@ -393,14 +393,33 @@ class Emulator(nn.Module):
                 return _ag.CumsumActFn.apply(y, lin_last, self.activation)
             return _lib.cumsum_act(y, lin_last, self.activation)
 
-        x, e = res_head(self.res_x, x, x_lin_last), res_head(self.res_e, e, e_lin_last)
-        out = self.out(x)
-        if self.if_flood:
-            f = x
-            for ly in self.flood:
-                f = ly(f)
-            out = torch.cat([out, self.flood_out(f)], dim=-1)         # :330-333
-        return out, self.e_out_layer(e)
+        def fused_heads(layer, t, lin_last, head, hidden, head_f):
+            """Dense + cumsum + residual + activation with the output heads as the epilogue of the same streaming kernel (the 64-wide
+            resnet output never reaches memory); None when the shape or mode is not the one that kernel takes."""
+            pk = lambda m: _packed_kernel(m, m.kernel)
+            ok = (self.resnet and layer.precision == 'bf16x3' and layer.units == 64 and t.shape[-1] == 64 and head.units <= 4
+                  and len(hidden) <= 3 and all(m.units == 32 for m in hidden) and (not hidden or hidden[0].kernel.shape[0] == 64)
+                  and not _ag.grad_on(t, lin_last, *self.parameters()))
+            if not ok:
+                return None
+            return _lib.dense_cumsum_heads(
+                c(t), pk(layer), layer.bias, c(lin_last), self.activation, (pk(head), head.bias, head.units, head.activation),
+                [(pk(m), m.bias) for m in hidden],
+                (pk(head_f), head_f.bias, head_f.activation, hidden[0].activation) if hidden else None)
+
+        out = fused_heads(self.res_x, x, x_lin_last, self.out, list(self.flood), self.flood_out)
+        e_out = fused_heads(self.res_e, e, e_lin_last, self.e_out_layer, [], None)
+        if out is None:
+            x = res_head(self.res_x, x, x_lin_last)
+            out = self.out(x)
+            if self.if_flood:
+                f = x
+                for ly in self.flood:
+                    f = ly(f)
+                out = torch.cat([out, self.flood_out(f)], dim=-1)     # :330-333
+        if e_out is None:
+            e_out = self.e_out_layer(res_head(self.res_e, e, e_lin_last))
+        return out, e_out
 
     model = forward
 
