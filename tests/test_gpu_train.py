@@ -396,3 +396,60 @@ def test_mpc_objective_and_gradient(dev, networks, chunks):
         from tests.util import OBSERVED
         OBSERVED.append((os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0] + ':gradient', 0, err, 2e-3 * gmax))
     assert err <= 2e-3 * gmax, 'gradient err %.3e vs max|grad| %.3e' % (err, gmax)
+
+
+def test_c5_block_diagonal_batch_forward_backward(dev):
+    """BASELINE.json config 5 in its own form -- G mini-graphs as ONE block-diagonal network, training forward + backward of the
+    L-layer spatial block (what `bench.py --workload c5` times, there with 1000 x 2000-node graphs) -- against autograd over the
+    fp64 sparse oracle on the batched network, plus the property the batching rests on: every mini-graph's rows equal those of
+    that graph run alone (no leakage across the diagonal blocks)."""
+    G, n1, e1, d, L = 12, 300, 360, 64, 2
+    nets = [U.synthetic_drainage_network(n1, e1, seed=k) for k in range(G)]
+    g = U.DrainageGraph.from_edges(np.concatenate([ed + n1 * k for k, ed in enumerate(nets)]), n1 * G)
+    assert g.n_node == n1 * G and g.n_edge == e1 * G
+    block = U.SpatialBlock(g, d, L, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1)).to(dev)
+    block.requires_grad_(True)
+    gen = torch.Generator().manual_seed(2)
+    x, e = torch.rand(1, g.n_node, d, generator=gen), torch.rand(1, g.n_edge, d, generator=gen)
+    tx, te = torch.rand(1, g.n_node, d, generator=gen), torch.rand(1, g.n_edge, d, generator=gen)
+    ox, oe = block(x.to(dev), e.to(dev))
+    loss = torch.nn.functional.mse_loss(ox, tx.to(dev)) + torch.nn.functional.mse_loss(oe, te.to(dev))
+    loss.backward()
+    # fp64 oracle with autograd on the same batched network
+    csr = lambda c: (c.rowptr, c.col)
+    ps = []
+    for ly in block.layers:
+        p = {k: (v.double().clone().requires_grad_(True) if v is not None else None) for k, v in ly.export_params().items()}
+        ps.append(p)
+    rx, re = x.double(), e.double()
+    for p in ps:
+        rx, re = OS.spatial_layer_csr(rx, re, p, csr(g.adj), csr(g.edge_adj), csr(g.inc_n), csr(g.inc_e))
+    rloss = torch.nn.functional.mse_loss(rx, tx.double()) + torch.nn.functional.mse_loss(re, te.double())
+    rloss.backward()
+    close(ox.detach(), rx.detach(), 4e-5)
+    assert abs(float(loss.detach()) - float(rloss.detach())) <= 4e-5 * max(1.0, abs(float(rloss.detach())))
+    names = {'xe_k': ('dense_xe', 'kernel'), 'xe_b': ('dense_xe', 'bias'), 'ex_k': ('dense_ex', 'kernel'), 'gx_k': ('gat_x', 'kernel'),
+             'gx_as': ('gat_x', 'attn_kernel_self'), 'ge_an': ('gat_e', 'attn_kernel_neighs'), 'ge_b': ('gat_e', 'bias'),
+             'ne_n_v': ('node_edge_n', 'weight'), 'ne_e_v': ('node_edge_e', 'weight')}
+    worst = max(float(p[k].grad.abs().max()) for p in ps for k in names)
+    for ly, p in zip(block.layers, ps):
+        for k, (mod, attr) in names.items():
+            got, want = getattr(getattr(ly, mod), attr).grad.double().cpu().reshape(p[k].grad.shape), p[k].grad
+            lim = GRAD_TOL['GAT'] * float(want.abs().max()) + 1e-7 * worst
+            assert float((got - want).abs().max()) <= lim, (k, float((got - want).abs().max()), lim)
+    # one mini-graph alone: same rows (forward)
+    k = 5
+    g1 = U.DrainageGraph.from_edges(nets[k], n1)
+    b1 = U.SpatialBlock(g1, d, L, 'relu', sparse_params=True).to(dev)
+    for l1, lb in zip(b1.layers, block.layers):
+        for m in ('dense_xe', 'dense_ex', 'gat_x', 'gat_e'):
+            getattr(l1, m).load_state_dict(getattr(lb, m).state_dict())
+        sel = lambda csr_b, lo, hi: torch.as_tensor(np.nonzero((csr_b.rows() >= lo) & (csr_b.rows() < hi))[0], device=dev)
+        l1.node_edge_n.weight.data = lb.node_edge_n.weight.data[sel(g.inc_n, n1 * k, n1 * (k + 1))].clone()
+        l1.node_edge_e.weight.data = lb.node_edge_e.weight.data[sel(g.inc_e, e1 * k, e1 * (k + 1))].clone()
+        l1.node_edge_n.bias.data = torch.zeros_like(l1.node_edge_n.weight.data)
+        l1.node_edge_e.bias.data = torch.zeros_like(l1.node_edge_e.weight.data)
+    with torch.no_grad():
+        sx, se = b1(x[:, n1 * k:n1 * (k + 1)].to(dev).contiguous(), e[:, e1 * k:e1 * (k + 1)].to(dev).contiguous())
+    assert float((sx - ox[:, n1 * k:n1 * (k + 1)].detach()).abs().max()) <= 4e-5 * max(1.0, float(sx.abs().max()))
+    assert float((se - oe[:, e1 * k:e1 * (k + 1)].detach()).abs().max()) <= 4e-5 * max(1.0, float(se.abs().max()))
