@@ -66,8 +66,11 @@ __global__ __launch_bounds__(RC_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1
   for (int g = 0; g < G; ++g)
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
-      f32x4 v = *reinterpret_cast<const f32x4 *>(a.b_in + g * 64 + 16 * m + 4 * qd);
-      if (G == 3 && g < 2 && a.b_rec) v += *reinterpret_cast<const f32x4 *>(a.b_rec + g * 64 + 16 * m + 4 * qd);
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};             // KTX = 0: the given projection carries its biases (b_in is not read)
+      if constexpr (KTX != 0) {
+        v = *reinterpret_cast<const f32x4 *>(a.b_in + g * 64 + 16 * m + 4 * qd);
+        if (G == 3 && g < 2 && a.b_rec) v += *reinterpret_cast<const f32x4 *>(a.b_rec + g * 64 + 16 * m + 4 * qd);
+      }
       bi[g][m] = v;
     }
 #pragma unroll
