@@ -474,3 +474,20 @@ def test_cpu_tensors_are_refused(dev):
     layer = U.Dense(4, 'relu', in_features=4)
     with pytest.raises(_lib.UdsError):
         layer(torch.zeros(2, 4))
+
+
+def test_spatial_block_graphed_equals_eager(dev):
+    """`SpatialBlock.graphed`: the block forward replayed from one captured HIP graph reads its input buffers in place and gives
+    the eager result bit for bit, also after the inputs were overwritten."""
+    gph = U.DrainageGraph.from_edges(U.synthetic_drainage_network(600, 720, 0))
+    block = U.SpatialBlock(gph, 64, 2, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1)).to(dev)
+    g = torch.Generator().manual_seed(3)
+    x, e = torch.rand(4, 600, 64, generator=g).to(dev), torch.rand(4, 720, 64, generator=g).to(dev)
+    replay = block.graphed(x, e)
+    for _ in range(2):
+        with torch.no_grad():
+            ex, ee = block(x, e)
+        ox, oe = replay()
+        assert torch.equal(ox, ex) and torch.equal(oe, ee)
+        x.copy_(torch.rand(4, 600, 64, generator=g))          # new snapshots into the same buffers
+        e.copy_(torch.rand(4, 720, 64, generator=g))
