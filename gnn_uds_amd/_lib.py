@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # UDS_LIB_PATH: a differently built copy of the same library (kernel experiments: tools/variant_bench.py)
 LIB_PATH = os.environ.get('UDS_LIB_PATH') or os.path.join(_HERE, 'libuds_hip.so')
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
 PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
 
@@ -53,6 +53,8 @@ SYMBOLS = {
     'uds_remainder_workspace_bytes': (_c_i64, [_c_i64, _c_i64, _c_i64]),
     'uds_remainder_forward': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr]),
     'uds_rowgemm_forward': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
+    'uds_rowgemm_forward_pair': (_c_int, [_c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64,
+                                          _c_i64, _c_i64, _c_int, _c_ptr]),
     'uds_rowgemm_forward_cat': (_c_int, [_c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int,
                                          _c_ptr, _c_i64, _c_i64, _c_ptr]),
     'uds_dense_cumsum': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr]),
@@ -504,6 +506,23 @@ def rowgemm_forward(x, packed, bias, f_out, act='linear', taps=1, dilation=1):
     _check(lib.uds_rowgemm_forward(_dev(x, 'x'), B, T, R, F, packed.data_ptr(), _dev(bias, 'bias', True), taps, dilation, f_out,
                                    ACT[act], _dev(out, 'out'), _stream()), 'uds_rowgemm_forward')
     return out
+
+
+def rowgemm_forward_pair(x0, packed0, bias0, x1, packed1, bias1, f_out, act='linear', taps=1, dilation=1):
+    """Two causal Conv1D / Dense problems of one layer shape -- x0 (B,T,R0,F), x1 (B,T,R1,F) -- in one launch when both are small
+    (uds_rowgemm_forward_pair).  Returns (out0, out1)."""
+    lib = load()
+    B, T, R0, F = x0.shape
+    R1 = x1.shape[2]
+    if tuple(x1.shape) != (B, T, R1, F):
+        raise UdsError('rowgemm_forward_pair: x0 %r and x1 %r differ in more than the row count' % (tuple(x0.shape), tuple(x1.shape)))
+    out0 = torch.empty((B, T, R0, f_out), device=x0.device, dtype=torch.float32)
+    out1 = torch.empty((B, T, R1, f_out), device=x0.device, dtype=torch.float32)
+    if out0.numel() and out1.numel():
+        _check(lib.uds_rowgemm_forward_pair(_dev(x0, 'x0'), R0, packed0.data_ptr(), _dev(bias0, 'bias0', True), _dev(out0, 'out0'), _dev(x1, 'x1'), R1,
+                                            packed1.data_ptr(), _dev(bias1, 'bias1', True), _dev(out1, 'out1'), B, T, F, taps, dilation, f_out,
+                                            ACT[act], _stream()), 'uds_rowgemm_forward_pair')
+    return out0, out1
 
 
 def rowgemm_cat(x, x2, packed, bias, f_out, act='linear', out=None, col0=0):

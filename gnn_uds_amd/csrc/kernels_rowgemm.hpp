@@ -276,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void k_rowgemm_mfma(RowGemmArgs a) {
 // while the workgroup stages the weights; blocks are dealt wave-major so every CU gets one before any gets two.
 // Same fragment layout, split and MFMA order as k_rowgemm_mfma: bit-identical results.
 template <int MB, int KT>
-__global__ __launch_bounds__(512) void k_rowgemm_small(RowGemmArgs a) {
+__device__ __forceinline__ void rowgemm_small_body(const RowGemmArgs &a) {
   constexpr int CG = MB >= 2 ? 2 : 1;
   constexpr int LD = 16 * CG + 4;
   extern __shared__ __attribute__((aligned(16))) float smem_rg[];
@@ -333,6 +333,20 @@ __global__ __launch_bounds__(512) void k_rowgemm_small(RowGemmArgs a) {
   rowgemm_epilogue<MB, 1>(a, acc, base, nv, tile, bias_s, lane);
 }
 
+template <int MB, int KT>
+__global__ __launch_bounds__(512) void k_rowgemm_small(RowGemmArgs a) {
+  rowgemm_small_body<MB, KT>(a);
+}
+
+// TWO independent small problems of the same kernel shape in one launch (blockIdx.y picks the problem): the node-side and the
+// link-side temporal layer of an autoregressive step, each a few microseconds on its own -- launch latency, not work, is what
+// such a step pays for.  The body is instantiated once per problem (no run-time selection of the argument block).
+template <int MB, int KT>
+__global__ __launch_bounds__(512) void k_rowgemm_small_pair(RowGemmArgs a0, RowGemmArgs a1) {
+  if (blockIdx.y == 0) rowgemm_small_body<MB, KT>(a0);
+  else rowgemm_small_body<MB, KT>(a1);
+}
+
 constexpr int64_t ROWGEMM_SMALL_ROWS = 16 * 8 * 256;      // one 16-row block per wave of one workgroup per CU
 
 template <int MB, int KT>
@@ -352,6 +366,38 @@ inline hipError_t launch_rowgemm_small_k(const RowGemmArgs &a, hipStream_t st) {
   b.seg = 0;
   hipLaunchKernelGGL((k_rowgemm_small<MB, KT>), dim3((unsigned)grid), dim3(512), lds, st, b);
   return hipGetLastError();
+}
+
+template <int MB, int KT>
+inline hipError_t launch_rowgemm_small_pair_k(const RowGemmArgs &a0, const RowGemmArgs &a1, hipStream_t st) {
+  constexpr int cg = MB >= 2 ? 2 : 1;
+  const size_t lds = (size_t)KT * MB * 2 * 1024 + 256 + 8 * 16 * (16 * cg + 4) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowgemm_small_pair<MB, KT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int64_t n_blocks = std::max((a0.rows + 15) / 16, (a1.rows + 15) / 16);
+  const int64_t grid = std::max<int64_t>(1, std::min<int64_t>(128, n_blocks));      // 128 workgroups per problem: the pair fills the 256 CUs
+  RowGemmArgs b0 = a0, b1 = a1;
+  b0.seg = b1.seg = 0;
+  hipLaunchKernelGGL((k_rowgemm_small_pair<MB, KT>), dim3((unsigned)grid, 2), dim3(512), lds, st, b0, b1);
+  return hipGetLastError();
+}
+
+// both problems small enough for one 16-row block per wave of 128 workgroups each (the two grids share the 256 CUs)
+constexpr int64_t ROWGEMM_PAIR_ROWS = 16 * 8 * 128;
+
+template <int MB>
+inline bool launch_rowgemm_small_pair(const RowGemmArgs &a0, const RowGemmArgs &a1, hipStream_t st, hipError_t &e) {
+  if (a0.rows > ROWGEMM_PAIR_ROWS || a1.rows > ROWGEMM_PAIR_ROWS) return false;
+  switch (a0.taps * a0.F / 32) {
+    case 2: e = launch_rowgemm_small_pair_k<MB, 2>(a0, a1, st); return true;
+    case 6: e = launch_rowgemm_small_pair_k<MB, 6>(a0, a1, st); return true;
+    default: return false;
+  }
 }
 
 // true (and launched) when the problem is small and K / 32 is one of the instantiated depths

@@ -462,6 +462,36 @@ int uds_rowgemm_forward_cat(const float *x, int64_t F1, const float *x2, int64_t
   return UDS_OK;
 }
 
+int uds_rowgemm_forward_pair(const float *x0, int64_t R0, const void *packed0, const float *bias0, float *out0, const float *x1, int64_t R1,
+                             const void *packed1, const float *bias1, float *out1, int64_t B, int64_t T, int64_t F, int64_t taps, int64_t dil,
+                             int64_t f_out, int act, uds_stream_t stream) {
+  UDS_REQUIRE(x0 && x1 && packed0 && packed1 && out0 && out1, "uds_rowgemm_forward_pair: NULL argument");
+  UDS_REQUIRE(B >= 0 && T > 0 && R0 > 0 && R1 > 0 && F > 0 && F % 32 == 0 && taps > 0 && taps <= 16 && dil > 0 && f_out > 0 && f_out <= 64,
+              "uds_rowgemm_forward_pair: needs F %% 32 == 0, f_out <= 64, dil > 0");
+  UDS_REQUIRE(act >= UDS_ACT_LINEAR && act <= UDS_ACT_HARD_SIGMOID, "uds_rowgemm_forward_pair: unknown activation %d", act);
+  UDS_REQUIRE(aligned16(x0) && aligned16(x1) && aligned16(packed0) && aligned16(packed1) && aligned16(out0) && aligned16(out1) && aligned16(bias0) &&
+                  aligned16(bias1), "uds_rowgemm_forward_pair: pointers must be 16-byte aligned");
+  if (B == 0) return UDS_OK;
+  uds::RowGemmArgs a0{x0, bias0, reinterpret_cast<const uint4 *>(packed0), out0, B * T * R0, (int)F, (int)taps, (int)dil, (int)T, (int)R0,
+                      (int)f_out, act, 0, nullptr, 0, (int)f_out, 0};
+  uds::RowGemmArgs a1{x1, bias1, reinterpret_cast<const uint4 *>(packed1), out1, B * T * R1, (int)F, (int)taps, (int)dil, (int)T, (int)R1,
+                      (int)f_out, act, 0, nullptr, 0, (int)f_out, 0};
+  hipError_t e = hipSuccess;
+  bool done = false;
+  switch (uds::rowgemm_mb((int)f_out)) {
+    case 1: done = uds::launch_rowgemm_small_pair<1>(a0, a1, static_cast<hipStream_t>(stream), e); break;
+    case 2: done = uds::launch_rowgemm_small_pair<2>(a0, a1, static_cast<hipStream_t>(stream), e); break;
+    default: done = uds::launch_rowgemm_small_pair<4>(a0, a1, static_cast<hipStream_t>(stream), e); break;
+  }
+  if (!done) {      // too large (or a depth the pair kernel is not built for): the two ordinary launches
+    int rc = uds_rowgemm_forward(x0, B, T, R0, F, packed0, bias0, taps, dil, f_out, act, out0, stream);
+    if (rc != UDS_OK) return rc;
+    return uds_rowgemm_forward(x1, B, T, R1, F, packed1, bias1, taps, dil, f_out, act, out1, stream);
+  }
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_rowgemm_forward_pair: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
 int uds_dense_cumsum(const float *x, int64_t B, int64_t T, int64_t R, const void *packed, const float *bias, const float *res, int act,
                      float *out, uds_stream_t stream) {
   UDS_REQUIRE(x && packed && out, "uds_dense_cumsum: NULL x/packed/out");

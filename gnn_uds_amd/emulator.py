@@ -369,18 +369,33 @@ class Emulator(nn.Module):
                 xs, es = block(r(x, self.n_node), r(e, self.n_edge), r(xb, self.n_node), r(eb, self.n_edge), adj_mask=mask)
             return xs.reshape(nb, T, self.n_node, -1), es.reshape(nb, T, self.n_edge, -1)
 
+        def temporal(mods_x, mods_e, x, e):
+            """The two temporal stacks (:244-257): layer by layer; a pair of small Conv1D layers of one shape goes out as ONE launch."""
+            if len(mods_x) != len(mods_e):
+                for ly in mods_x:
+                    x = ly(x)
+                for ly in mods_e:
+                    e = ly(e)
+                return x, e
+            for lx, le in zip(mods_x, mods_e):
+                kx = lx.kernel.shape if isinstance(lx, Conv1D) else None
+                if (kx is not None and isinstance(le, Conv1D) and le.kernel.shape == kx and lx.dilation_rate == le.dilation_rate
+                        and lx.activation == le.activation and lx.precision == le.precision == 'bf16x3' and x.shape[-1] == e.shape[-1] == kx[1]
+                        and _lib.rowgemm_supported(kx[0] * kx[1], kx[1], kx[2]) and x.shape[0] * x.shape[1] * max(x.shape[2], e.shape[2]) <= 16384
+                        and kx[0] * kx[1] // 32 in (2, 6) and not _ag.grad_on(x, e, lx.kernel, le.kernel, lx.bias, le.bias)):
+                    x, e = _lib.rowgemm_forward_pair(c(x), _packed_kernel(lx, lx.kernel.reshape(kx[0] * kx[1], kx[2])), lx.bias,
+                                                     c(e), _packed_kernel(le, le.kernel.reshape(kx[0] * kx[1], kx[2])), le.bias, kx[2],
+                                                     lx.activation, taps=kx[0], dilation=lx.dilation_rate)
+                else:
+                    x, e = lx(x), le(e)
+            return x, e
+
         x, e = spatial(self.block1, x, e)
-        for ly in self.tem1_x:
-            x = ly(x)
-        for ly in self.tem1_e:
-            e = ly(e)
+        x, e = temporal(self.tem1_x, self.tem1_e, x, e)
         x, e = x[:, -self.seq_out:], e[:, -self.seq_out:]             # :249,256
         # concat([x, b]) / concat([e, ae]) (:260-262) are not materialised: the first layer of block 2 reads both pieces
         x, e = spatial(self.block2, c(x), c(e), b, ae if self.act else None, adj_mask)
-        for ly in self.tem2_x:
-            x = ly(x)
-        for ly in self.tem2_e:
-            e = ly(e)
+        x, e = temporal(self.tem2_x, self.tem2_e, x, e)
         def res_head(layer, t, lin_last):                             # :313-320
             if not self.resnet:
                 return layer(t)

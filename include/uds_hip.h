@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 13
+#define UDS_ABI_VERSION 14
 
 enum {
   UDS_OK = 0,
@@ -125,6 +125,13 @@ int uds_rowgemm_pack(const float *W, int64_t k_total, int64_t f_out, void *packe
 int uds_rowgemm_forward(const float *x, int64_t B, int64_t T, int64_t R, int64_t F, const void *packed,
                         const float *bias, int64_t taps, int64_t dil, int64_t f_out, int act, float *out,
                         uds_stream_t stream);
+
+/* Two uds_rowgemm_forward problems of the same layer shape (B, T, F, taps, dil, f_out, act) in ONE launch when both are
+ * small (<= 16 384 rows each: an autoregressive step on a 2k-node network), else as two launches: the node-side and the
+ * link-side temporal layer of a step (emulator.py:244-257) -- problem i: x_i (B, T, R_i, F) -> out_i (B, T, R_i, f_out). */
+int uds_rowgemm_forward_pair(const float *x0, int64_t R0, const void *packed0, const float *bias0, float *out0,
+                             const float *x1, int64_t R1, const void *packed1, const float *bias1, float *out1, int64_t B,
+                             int64_t T, int64_t F, int64_t taps, int64_t dil, int64_t f_out, int act, uds_stream_t stream);
 
 /* uds_rowgemm_forward whose input row is the concatenation [x (F1) | x2 (F2)] of two tensors (x2 NULL, F2 = 0: one
  * tensor; two tensors need taps = 1) and whose f_out outputs go to columns [col0, col0 + f_out) of rows of `ldo`
