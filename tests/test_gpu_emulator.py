@@ -152,6 +152,37 @@ def test_network_forward_gcn_and_plain_variants(dev, networks):
     close(y, ry, TOL_FWD['fp32']); close(ey, rey, TOL_FWD['fp32'])
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_network_forward_trained_node_edge_bias(dev, networks, precision):
+    """The whole network with reference-TRAINED NodeEdge layers (dense bias non-zero off the incidence support, emulator.py:36-45)
+    in every spatial layer: 64-wide layers on the fused kernel with the remainder GEMM, the 96-wide first layer of block 2
+    (`concat([x, b])`, :260-262) on the unfused chain with the same GEMM -- against the dense oracle, which simply multiplies
+    the full (N, E) matrices."""
+    args, params, emul, _ = _setup(networks, 'shunqing', dev, precision=precision, n_sp_layer=2, n_tp_layer=1, seq_in=4, seq_out=3)
+    g = torch.Generator().manual_seed(17)
+    for blk in ('block1', 'block2'):
+        for q in params[blk]:
+            for key in ('node_edge_n', 'node_edge_e'):
+                q[key]['bias'] = torch.randn(q[key]['bias'].shape, generator=g, dtype=torch.float64) * 0.02
+    load_emulator(emul, params, dev)
+    X, Bd, Ex, a = _inputs(args, 2)
+    AE = OE.get_edge_action(OE.config(args), a)
+    ry, rey = OE.forward(args, params, X, Bd, Ex, AE)
+    f = lambda t: t.float().to(dev)
+    y, ey = emul(f(X), f(Bd), f(Ex), emul.get_edge_action(f(a)))
+    close(y, ry, TOL_FWD[precision]); close(ey, rey, TOL_FWD[precision])
+    paths = [ly.last_path for ly in emul.block1.layers] + [ly.last_path for ly in emul.block2.layers]
+    if precision == 'bf16x3':
+        assert paths == ['fused+remainder', 'fused+remainder', 'unfused', 'fused+remainder'], paths
+    # and the bias matters: the same inputs through the support-only model differ visibly
+    for blk in ('block1', 'block2'):
+        for q in params[blk]:
+            for key in ('node_edge_n', 'node_edge_e'):
+                q[key]['bias'] = torch.zeros_like(q[key]['bias'])
+    r0y, _ = OE.forward(args, params, X, Bd, Ex, AE)
+    assert float((ry - r0y).abs().max()) > 10 * TOL_FWD['bf16x3']
+
+
 @pytest.mark.parametrize('graph_base', [0, 1])
 def test_network_forward_diffusion(dev, networks, graph_base):
     """conv = Diffusion (emulator.py:135-138) through the whole network, two-graph and graph_base forms (parity unpinned)."""
