@@ -260,6 +260,13 @@ class Emulator(nn.Module):
             edge_adj = np.asarray(g('edge_adj', np.eye(self.n_edge)))
             node_edge = np.asarray(g('node_edge'), dtype=np.float64)
             self.graph = DrainageGraph.from_dense(adj, edge_adj, node_edge, self.edges)
+            if self.use_adj:
+                # get_adj_action rewrites entries of the RAW adjacency and casts to int (emulator.py:343-361): with a weighted
+                # adjacency (length > 0: Gaussian kernel values < 1) that cast removes every off-diagonal entry, actuated or
+                # not -- kept as the reference has it: the raw values at the pattern's entries (the forced diagonal reads 0)
+                ga = self.graph.adj
+                rows = np.repeat(np.arange(ga.n_rows), np.diff(ga.rowptr))
+                self._adj_raw = np.asarray(adj, dtype=np.float64)[rows, np.asarray(ga.col, dtype=np.int64)]
             if self.conv_kind != 'GAT':
                 from .layers import DiffusionConv, GCNConv
                 pre = (GCNConv if self.conv_kind == 'GCN' else DiffusionConv).preprocess

@@ -83,3 +83,25 @@ def test_dense_bias_is_not_dropped_silently():
     with pytest.raises(ValueError, match='off the incidence support'):
         sp.load_keras_weights(w)
     _emul().load_keras_weights(w)                  # the dense model keeps it
+
+
+def test_get_adj_action_matches_the_dense_rewrite_on_a_weighted_adjacency():
+    """`get_adj_action` (emulator.py:343-362) as an edge mask over the CSR entries equals the reference's dense rewrite + int cast,
+    also when the adjacency carries weights (entries below 1 vanish in the cast whether actuated or not -- a reference quirk
+    that is kept).  Host logic only: no GPU needed."""
+    from oracle import emulator_ref as OE
+    with open(os.path.join(ROOT, 'tests', 'golden', 'networks.json')) as fh:
+        net = json.load(fh)['astlingen']
+    args = emulator_args(np.array(net['edges']), net['n_node'], use_adj=True)
+    rng = np.random.default_rng(0)
+    args.adj = np.array(args.adj, dtype=float) * (0.5 + 1.5 * rng.random(np.shape(args.adj)))
+    em = U.Emulator(args.conv, args.resnet, args.recurrent, args)
+    a = torch.rand(2, 3, len(args.act_edges), generator=torch.Generator().manual_seed(1)) * 2
+    mask = em.get_adj_action(a)
+    dense = OE.get_adj_action(OE.config(args), a)
+    csr, _, pos = em._adj_pattern()
+    rows, cols = np.repeat(np.arange(csr.n_rows), np.diff(csr.rowptr)), np.asarray(csr.col)
+    off = torch.as_tensor(rows != cols)                          # the diagonal is forced to one afterwards (set_diag)
+    want = (dense[..., rows, cols] != 0).float()
+    assert torch.equal(mask[..., off], want[..., off]) and 0.2 < float(mask[..., off].mean()) < 0.9
+    assert (pos >= 0).all()                                      # every actuated (from, to) pair is an entry of the pattern
