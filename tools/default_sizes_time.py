@@ -22,8 +22,17 @@ def main():
                         model_dir=None)
     X, B, Ex = torch.rand(1, T, N, 5, device=dev), torch.rand(1, T, N, 1, device=dev), torch.rand(1, T, E, 4, device=dev)
     out = {}
-    for rec in ('Conv1D', 'GRU', 'LSTM'):
+    trained = bool(int(os.environ.get('TRAINED', '0')))        # TRAINED=1: dense NodeEdge parameters with a bias trained off the support
+    if trained:
+        a.sparse_params = False
+    for rec in ('Conv1D', 'GRU', 'LSTM')[:1 if trained else 3]:
         emul = U.Emulator('GAT', True, rec, a, generator=torch.Generator().manual_seed(1)).to(dev)
+        if trained:
+            with torch.no_grad():
+                for blk in (emul.block1, emul.block2):
+                    for ly in blk.layers:
+                        ly.node_edge_n.bias.normal_(0.0, 0.01)
+                        ly.node_edge_e.bias.normal_(0.0, 0.01)
         for _ in range(2):
             emul(X, B, Ex)
         torch.cuda.synchronize()
@@ -31,7 +40,9 @@ def main():
         for _ in range(5):
             emul(X, B, Ex)
         torch.cuda.synchronize()
-        out['ms_per_forward_' + rec] = (time.perf_counter() - t0) / 5 * 1e3
+        out['ms_per_forward_' + rec + ('_trained_bias' if trained else '')] = (time.perf_counter() - t0) / 5 * 1e3
+        if trained:
+            out['paths'] = [ly.last_path for ly in emul.block1.layers] + [ly.last_path for ly in emul.block2.layers]
     print(json.dumps(out))
 
 
