@@ -17,7 +17,8 @@ The remaining post-processing is elementwise gating / clipping on tensors alread
 tensor ops (device plumbing).  Training (`fit_eval`, GradNorm), `graph_base` 1 / 2, GCN and DiffusionConv are built.
 `use_adj` (per-time-step adjacency rewritten by the control action) is built for GAT as a mask over the CSR entries.
 GRU / LSTM temporal nets run (inference).  Not built, each raises: training-time dropout, `use_adj` with GCN / Diffusion or under autograd,
-GeneralConv (a sparse-mode-only Spektral layer the reference's dense call cannot run either) and the conv=None dense-MLP variant.
+GeneralConv (a sparse-mode-only Spektral layer the reference's dense call cannot run either).  conv = False -- the reference's non-graph
+baseline, its shipped `*_nncat_*` models -- runs on the same Dense / temporal / cumsum kernels (`_forward_mlp`).
 """
 import os
 
@@ -206,8 +207,11 @@ class Emulator(nn.Module):
         self.conv = False if conv in (None, 'None', 'False', 'NoneType', False) else conv
         self.recurrent = recurrent
         if not self.conv:
-            raise NotImplementedError('the HIP engine builds the graph-convolution emulator (conv=GAT/GCN); the dense MLP variant is not built')
-        if 'GAT' in self.conv:
+            # the reference's non-graph baseline (its shipped `*_nncat_*` models, `conv: 'False'`): node and link states flattened into
+            # one vector per time step, Dense layers instead of graph convolutions (emulator.py:181-182,197-212,236-237); the graph
+            # is still needed by the post-processing (link -> node flow balance)
+            self.conv_kind = 'GAT'
+        elif 'GAT' in self.conv:
             self.conv_kind = 'GAT'
         elif 'GCN' in self.conv:
             self.conv_kind = 'GCN'
@@ -298,6 +302,9 @@ class Emulator(nn.Module):
         d, h, H, L, gen = self.embed_size, self.embed_size // 2, self.hidden_dim, self.n_sp_layer, generator
         a = self.activation
         pr = precision
+        if not self.conv:
+            self._build_mlp(d, h, H, L, a, gen, pr)
+            return
         self.embed_x = Dense(d, 'linear', in_features=self.n_in, generator=gen)                 # emulator.py:198
         self.embed_b = Dense(h, a, in_features=self.b_in, generator=gen)                        # :203
         self.embed_e = Dense(d, 'linear', in_features=self.e_in, generator=gen)                 # :206
@@ -347,10 +354,97 @@ class Emulator(nn.Module):
         self.flood_out = Dense(1, 'sigmoid', in_features=fi, generator=gen, precision=pr) if self.if_flood else None      # :330
         self.e_out_layer = Dense(self.e_out, 'tanh', in_features=d, generator=gen, precision=pr)              # :336
 
+    # ------------------------------------------------------------------ the non-graph baseline (conv False)
+    def _build_mlp(self, d, h, H, L, a, gen, pr):
+        """`build_network(conv=False)` (emulator.py:166-341 with `net = Dense`): every time step's node states (N * n_in values) and link
+        states (E * e_in) are ONE row each; embeddings, `Dense(2 d)(concat([x, e]))` + split in place of the spatial layers, the same
+        temporal nets / resnet head, and heads that emit all N (E) outputs of a step at once.  Same Dense / Conv1D / recurrent /
+        cumsum kernels as the graph model, on (B, T, 1, F) rows."""
+        if self.seq_in != self.seq_out:
+            raise NotImplementedError('conv=False reshapes the boundary input with seq_in (emulator.py:202): it only runs with seq_in == seq_out')
+        N, E = self.n_node, self.n_edge
+        self.embed_x = Dense(d, 'linear', in_features=N * self.n_in, generator=gen)             # :197-198
+        self.embed_b = Dense(h, a, in_features=N * self.b_in, generator=gen)                    # :202-203
+        self.embed_e = Dense(d, 'linear', in_features=E * self.e_in, generator=gen)             # :205-206
+        self.embed_ae = Dense(h, a, in_features=E, generator=gen) if self.act else None         # :211-212
+        rec = self.recurrent if self.recurrent in ('Conv1D', 'GRU', 'LSTM') else None
+
+        def tem(f):
+            if rec == 'Conv1D':
+                return nn.ModuleList([Conv1D(H, self.kernel_size, 2 ** i, a, in_features=(f if i == 0 else H), generator=gen, precision=pr)
+                                      for i in range(self.n_tp_layer)])
+            if rec:
+                return nn.ModuleList([(GRU if rec == 'GRU' else LSTM)(H, in_features=(f if i == 0 else H), generator=gen, precision=pr)
+                                      for i in range(self.n_tp_layer)])
+            return nn.ModuleList([])
+        if not (rec and self.n_tp_layer):
+            H = d
+        self.block1 = nn.ModuleList([Dense(2 * d, a, in_features=2 * d, generator=gen, precision=pr) for _ in range(L)])          # :236-237
+        self.tem1_x, self.tem1_e = tem(d), tem(d)
+        f2 = (H + h) + (H + (h if self.act else 0))
+        self.block2 = nn.ModuleList([Dense(2 * d, a, in_features=(f2 if i == 0 else 2 * d), generator=gen, precision=pr) for i in range(L)])
+        self.tem2_x, self.tem2_e = tem(d), tem(d)
+        self.res_x = Dense(d, 'linear' if self.resnet else a, in_features=H, generator=gen, precision=pr)     # :313
+        self.res_e = Dense(d, 'linear' if self.resnet else a, in_features=H, generator=gen, precision=pr)     # :317
+        self.out = Dense(self.n_out * N, 'hard_sigmoid', in_features=d, generator=gen, precision=pr)          # :322-325
+        fl, fi = [], d
+        for _ in range(self.if_flood):
+            fl.append(Dense(h, a, in_features=fi, generator=gen, precision=pr))
+            fi = h
+        self.flood = nn.ModuleList(fl)
+        self.flood_out = Dense(N, 'sigmoid', in_features=fi, generator=gen, precision=pr) if self.if_flood else None      # :327-330
+        self.e_out_layer = Dense(self.e_out * E, 'tanh', in_features=d, generator=gen, precision=pr)          # :335-337
+
+    def _forward_mlp(self, X, B, E, AE=None):
+        nb, T = X.shape[0], self.seq_out
+        flat = lambda t: t.reshape(t.shape[0], t.shape[1], 1, -1).contiguous()        # (B, T, N, c) -> one row of N * c per step
+        xl = self.embed_x(flat(X), 'linear')
+        x_lin_last, x = xl[:, -1:].contiguous(), self.embed_x(flat(X), self.activation)
+        el = self.embed_e(flat(E), 'linear')
+        e_lin_last, e = el[:, -1:].contiguous(), self.embed_e(flat(E), self.activation)
+        b = self.embed_b(flat(B))
+        ae = self.embed_ae(flat(AE)) if self.act else None
+
+        def spatial(layers, x, e):
+            for ly in layers:
+                z = ly(torch.cat([x, e], dim=-1))
+                x, e = z[..., :z.shape[-1] // 2].contiguous(), z[..., z.shape[-1] // 2:].contiguous()
+            return x, e
+
+        def chain(mods, t):
+            for ly in mods:
+                t = ly(t)
+            return t
+
+        x, e = spatial(self.block1, x, e)
+        x, e = chain(self.tem1_x, x)[:, -T:], chain(self.tem1_e, e)[:, -T:]
+        x = torch.cat([x, b], dim=-1)                                                 # :260
+        if self.act:
+            e = torch.cat([e, ae], dim=-1)                                            # :262
+        x, e = spatial(self.block2, x, e)
+        x, e = chain(self.tem2_x, x), chain(self.tem2_e, e)
+
+        def res_head(layer, t, lin_last):
+            y = layer(t)
+            if not self.resnet:
+                return y
+            if _ag.grad_on(y, lin_last):
+                return _ag.CumsumActFn.apply(y, lin_last, self.activation)
+            return _lib.cumsum_act(y.contiguous(), lin_last.contiguous(), self.activation)
+
+        x, e = res_head(self.res_x, x, x_lin_last), res_head(self.res_e, e, e_lin_last)
+        out = self.out(x).reshape(nb, T, self.n_node, self.n_out)                     # :322-325
+        if self.if_flood:
+            flood = self.flood_out(chain(self.flood, x)).reshape(nb, T, self.n_node, 1)
+            out = torch.cat([out, flood], dim=-1)
+        return out, self.e_out_layer(e).reshape(nb, T, self.n_edge, self.e_out)
+
     # ------------------------------------------------------------------ network forward (build_network)
     def forward(self, X, B, E, AE=None, ADJ=None):
         """ADJ: the per-time-step node adjacency of `use_adj` (emulator.py:178-180,268-271; block 2 only): the edge mask
         (B, T_out, nnz) of `get_adj_action`, or the reference's dense (B, T_out, n, n) integer array (small networks)."""
+        if not self.conv:
+            return self._forward_mlp(X, B, E, AE)
         nb = X.shape[0]
         c = lambda t: t.contiguous()
         adj_mask = None
@@ -941,6 +1035,10 @@ class Emulator(nn.Module):
         conv_w = {'GAT': gat_w, 'GCN': dense_w, 'Diffusion': [('kernel', 'kernel')]}[self.conv_kind]
 
         def spatial(block):
+            if not self.conv:
+                for ly in block:
+                    out.append((name('dense'), ly, dense_w))
+                return
             if self.graph_base:
                 for ly in block.layers:
                     out.append((name(conv_name), ly, conv_w))

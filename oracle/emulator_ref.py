@@ -16,7 +16,7 @@ Restates, on torch CPU tensors (fp64 or fp32), `surrogate/emulator.py` of the re
 `embed_size`, `adj`, `edge_adj`, `node_edge`, ... -- `Emulator.__init__`, emulator.py:48-127); `params`
 is the dict made by `init_params` (Keras creation order and initialisers).
 Not restated (none of the reference's shipped model configurations uses them): use_adj for GCN / Diffusion (per-step re-normalised
-filters), GeneralConv, the non-conv MLP variant, training-time dropout.
+filters), GeneralConv, training-time dropout.
 """
 import math
 from types import SimpleNamespace
@@ -67,6 +67,8 @@ def config(args):
     c.hmax = np.asarray(g('hmax', np.full(c.n_node, 1.5)), dtype=np.float64)
     c.hmin = np.asarray(g('hmin', np.zeros(c.n_node)), dtype=np.float64)
     conv = g('conv', 'GAT')
+    c.mlp = conv in (None, False, 'None', 'False', 'NoneType')          # `net = Dense`: the non-graph baseline (emulator.py:181-182)
+    conv = 'GAT' if c.mlp else conv
     c.conv = 'GCN' if 'GCN' in conv else 'Diffusion' if 'Diff' in conv else 'GAT'     # emulator.py:131-142
     c.resnet = bool(g('resnet', False))
     c.roll = int(g('roll', 0))
@@ -133,6 +135,28 @@ def init_params(args, seed=1, bias_scale=0.05):
             fi = H
         return out
 
+    if c.mlp:            # build_network(conv=False): flattened rows, Dense(2 d) blocks, heads for all nodes / links at once
+        N, E = c.n_node, c.n_edge
+        p = {'embed_x': dense(N * c.n_in, d), 'embed_b': dense(N * c.b_in, h), 'embed_e': dense(E * c.e_in, d)}
+        if c.act:
+            p['embed_ae'] = dense(E, h)
+        p['block1'] = [dense(2 * d, 2 * d) for _ in range(c.L)]
+        p['tem1_x'], p['tem1_e'] = temporal(d), temporal(d)
+        Ht = c.H
+        f2 = (Ht + h) + (Ht + (h if c.act else 0))
+        p['block2'] = [dense(f2 if i == 0 else 2 * d, 2 * d) for i in range(c.L)]
+        p['tem2_x'], p['tem2_e'] = temporal(d), temporal(d)
+        p['res_x'], p['res_e'] = dense(Ht, d), dense(Ht, d)
+        p['out'] = dense(d, c.n_out * N)
+        p['flood'] = []
+        fi = d
+        for _ in range(c.if_flood):
+            p['flood'].append(dense(fi, h))
+            fi = h
+        if c.if_flood:
+            p['flood_out'] = dense(fi, N)
+        p['e_out'] = dense(d, c.e_out * E)
+        return p
     p = {'embed_x': dense(c.n_in, d), 'embed_b': dense(c.b_in, h), 'embed_e': dense(c.e_in, d)}
     if c.act:
         p['embed_ae'] = dense(1, h)
@@ -235,6 +259,54 @@ def _spatial_layer(x, e, p, c, dtype, adj=None):
                                   torch.from_numpy(c.edge_filter).to(dtype), torch.from_numpy(c.node_edge).to(dtype), c.activation, c.conv)
 
 
+def _forward_mlp(c, params, X, B, E, AE, act, D):
+    """`build_network(conv=False)` (emulator.py:166-341, `net = Dense`): the reference's non-graph baseline (`*_nncat_*` models)."""
+    nb = X.shape[0]
+    flat = lambda t: t.reshape(t.shape[0], t.shape[1], -1)        # :197,202,205,211: (B, T, N, c) -> (B, T, N * c)
+    x = D(flat(X), params['embed_x'])
+    res = x[:, -1:]
+    x = act(x)
+    b = D(flat(B), params['embed_b'], c.activation)
+    e = D(flat(E), params['embed_e'])
+    res_e = e[:, -1:]
+    e = act(e)
+    ae = D(flat(AE), params['embed_ae'], c.activation) if c.act else None
+
+    def spatial(x, e, layers):                                    # :236-237
+        for p in layers:
+            z = D(torch.cat([x, e], dim=-1), p, c.activation)
+            x, e = z[..., :z.shape[-1] // 2], z[..., z.shape[-1] // 2:]
+        return x, e
+
+    def temporal(y, layers):                                      # rows are the batch elements: (B, T, F) as it stands
+        for i, p in enumerate(layers):
+            if c.recurrent == 'Conv1D':
+                y = conv1d_causal(y, p['kernel'], p['bias'], 2 ** i, c.activation)
+            else:
+                y = (gru_sequence if c.recurrent == 'GRU' else lstm_sequence)(y, p['kernel'], p['recurrent_kernel'], p['bias'])
+        return y
+
+    x, e = spatial(x, e, params['block1'])
+    x, e = temporal(x, params['tem1_x'])[:, -c.seq_out:], temporal(e, params['tem1_e'])[:, -c.seq_out:]
+    x = torch.cat([x, b], dim=-1)
+    if c.act:
+        e = torch.cat([e, ae], dim=-1)
+    x, e = spatial(x, e, params['block2'])
+    x, e = temporal(x, params['tem2_x']), temporal(e, params['tem2_e'])
+    x_out, e_out = D(x, params['res_x']), D(e, params['res_e'])
+    if c.resnet:
+        x, e = act(torch.cumsum(x_out, dim=1) + res), act(torch.cumsum(e_out, dim=1) + res_e)
+    else:
+        x, e = act(x_out), act(e_out)
+    out = D(x, params['out'], 'hard_sigmoid').reshape(nb, c.seq_out, c.n_node, c.n_out)
+    if c.if_flood:
+        f = x
+        for p in params['flood']:
+            f = D(f, p, c.activation)
+        out = torch.cat([out, D(f, params['flood_out'], 'sigmoid').reshape(nb, c.seq_out, c.n_node, 1)], dim=-1)
+    return out, D(e, params['e_out'], 'tanh').reshape(nb, c.seq_out, c.n_edge, c.e_out)
+
+
 def forward(args, params, X, B, E, AE=None, ADJ=None):
     """`Emulator.build_network` as a function: X (B,T_in,N,n_in), B (B,T_out,N,b_in), E (B,T_in,E,e_in),
     AE (B,T_out,E,1) when act -> out (B,T_out,N,n_out[+1]), e_out (B,T_out,E,e_out).  emulator.py:195-338."""
@@ -242,6 +314,8 @@ def forward(args, params, X, B, E, AE=None, ADJ=None):
     dt = X.dtype
     act = OD.activation(c.activation)
     D = lambda t, p, a='linear': OD.dense(t, p['kernel'], p['bias'], a)
+    if c.mlp:
+        return _forward_mlp(c, params, X, B, E, AE, act, D)
     x = D(X, params['embed_x'])                                   # :198
     res = x[:, -1:]                                               # :200
     x = act(x)

@@ -152,6 +152,28 @@ def test_network_forward_gcn_and_plain_variants(dev, networks):
     close(y, ry, TOL_FWD['fp32']); close(ey, rey, TOL_FWD['fp32'])
 
 
+@pytest.mark.parametrize('over', [dict(), dict(act=False, if_flood=0, resnet=False, recurrent='GRU', embed_size=32, hidden_dim=64, n_tp_layer=1),
+                                  dict(recurrent='None', edge_fusion=False, n_sp_layer=1)])
+def test_network_forward_mlp_baseline(dev, networks, over):
+    """conv = False: the reference's non-graph baseline (`net = Dense`, emulator.py:181-182,197-212,236-237 -- its shipped `*_nncat_*`
+    models): flattened node / link rows, Dense(2 d) blocks, heads for all nodes at once; forward and `predict_tf` (the post-processing
+    still balances link flows on the graph) against the oracle."""
+    args, params, emul, norms = _setup(networks, 'astlingen', dev, conv='False', seq_in=5, seq_out=5, **over)
+    X, Bd, Ex, a = _inputs(args, 3)
+    c = OE.config(args)
+    AE = OE.get_edge_action(c, a) if c.act else None
+    ry, rey = OE.forward(args, params, X, Bd, Ex, AE)
+    f = lambda t: t.float().to(dev)
+    y, ey = emul(f(X), f(Bd), f(Ex), emul.get_edge_action(f(a)) if c.act else None)
+    assert ry.shape == (3, 5, c.n_node, c.n_out + (1 if c.if_flood else 0)) and rey.shape == (3, 5, c.n_edge, c.e_out)
+    close(y, ry, TOL_FWD['bf16x3']); close(ey, rey, TOL_FWD['bf16x3'])
+    names = [n for n, _, _ in emul.keras_layer_map()]
+    assert all(n.startswith(('dense', 'conv1d', 'gru', 'lstm')) for n in names) and 'dense_resx' in names
+    with pytest.raises(NotImplementedError):
+        U.Emulator('False', True, 'Conv1D', emulator_args(np.array(networks['astlingen']['edges']), networks['astlingen']['n_node'], conv='False',
+                                                          seq_in=6, seq_out=2))
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
 def test_network_forward_trained_node_edge_bias(dev, networks, precision):
     """The whole network with reference-TRAINED NodeEdge layers (dense bias non-zero off the incidence support, emulator.py:36-45)
@@ -275,7 +297,7 @@ def test_network_forward_use_adj(dev, networks, graph_base):
     assert ym.shape[:3] == y.shape[:3] and bool(torch.isfinite(ym).all())
 
 
-@pytest.mark.parametrize('variant', ['edge_fusion_act', 'pumps_offset_tide', 'plain'])
+@pytest.mark.parametrize('variant', ['edge_fusion_act', 'pumps_offset_tide', 'plain', 'mlp_baseline'])
 def test_predict_tf(dev, networks, variant):
     """predict_tf (emulator.py:604-641) incl. post_proc_tf / constrain_tf branches; raw states in, physical units out."""
     rng = np.random.default_rng(0)
@@ -288,6 +310,8 @@ def test_predict_tf(dev, networks, variant):
                     epsilon=0.1)
     elif variant == 'plain':
         over = dict(edge_fusion=False, act=False, if_flood=0, epsilon=0.0)
+    elif variant == 'mlp_baseline':      # conv = False (the `*_nncat_*` models) through the same post-processing
+        over = dict(edge_fusion=True, act=True, conv='False')
     args, params, emul, norms = _setup(networks, 'astlingen', dev, 'fp32', **over)
     X, Bd, Ex, a = _inputs(args, 2)
     ry, rey = OE.predict(args, params, norms, X, Bd, a if args.act else None, Ex)

@@ -27,7 +27,7 @@ from oracle import train_ref as OT
 from tests.util import close, emulator_args, emulator_norms, emulator_param_pairs, load_emulator
 
 pytestmark = pytest.mark.gpu
-GRAD_TOL = {'GAT': 1e-3, 'GCN': 5e-3}      # whole-model gradients, relative to the tensor's largest gradient
+GRAD_TOL = {'GAT': 1e-3, 'GCN': 5e-3, 'False': 1e-3}      # whole-model gradients, relative to the tensor's largest gradient
 
 
 @pytest.fixture(scope='module')
@@ -230,7 +230,8 @@ def _problem(networks, name, dev, seed=3, B=2, **over):
                                        ('shunqing', dict()),
                                        ('hague', dict(act=False, if_flood=0, edge_fusion=False, resnet=False, n_sp_layer=1)),
                                        ('astlingen', dict(roll=2, seq_in=4, seq_out=2, n_sp_layer=1)),
-                                       ('astlingen', dict(conv='GCN', act=False, if_flood=0, resnet=False, n_sp_layer=1))])
+                                       ('astlingen', dict(conv='GCN', act=False, if_flood=0, resnet=False, n_sp_layer=1)),
+                                       ('astlingen', dict(conv='False', seq_in=5, seq_out=5, n_sp_layer=2))])      # the non-graph baseline
 def test_emulator_gradients(dev, networks, name, over):
     args, norms, params, emul, cpu_in, dev_in = _problem(networks, name, dev, **over)
     x, a, b, y, ex, ey = cpu_in

@@ -123,6 +123,10 @@ def load_emulator(emul, p, device):
         m.kernel.data, m.bias.data = f32(q['kernel']), f32(q['bias'])
 
     def spatial(block, layers):
+        if not emul.conv:                           # conv=False: the blocks are lists of Dense(2 d) layers
+            for layer, q in zip(block, layers):
+                dense(layer, q)
+            return
         for layer, q in zip(block.layers, layers):
             if 'gat' in q:                      # graph_base: one conv over the stacked node + link rows
                 if 'theta' in q['gat']:
@@ -177,7 +181,7 @@ def emulator_param_pairs(emul, flat):
             if part == 'e_out':
                 m = m.e_out_layer
             elif part in ('block1', 'block2'):
-                m = getattr(m, part).layers
+                m = getattr(m, part).layers if emul.conv else getattr(m, part)      # conv = False: a plain list of Dense layers
             elif part.isdigit():
                 m = m[int(part)]
             elif part == 'gat' and not hasattr(m, 'gat'):
