@@ -152,6 +152,26 @@ def test_network_forward_gcn_and_plain_variants(dev, networks):
     close(y, ry, TOL_FWD['fp32']); close(ey, rey, TOL_FWD['fp32'])
 
 
+def test_network_forward_deep_shipped_configuration(dev, networks):
+    """The deepest configuration the reference ships (`*_5lyrs` models: n_sp_layer = n_tp_layer = 5, if_flood = 5, act, edge fusion,
+    resnet, Gaussian-kernel adjacency `length > 0`): Conv1D dilations up to 16 (beyond the streaming kernel's 1 / 2 / 4: the row-GEMM
+    form), a flood chain of five hidden layers (beyond the fused head epilogue's three: the unfused heads)."""
+    from oracle import graphs as OG
+    net = networks['astlingen']
+    edges = np.array(net['edges'])
+    rng = np.random.default_rng(4)
+    lengths = 50.0 + 400.0 * rng.random(len(edges))
+    over = dict(n_sp_layer=5, n_tp_layer=5, if_flood=5, seq_in=20, seq_out=20, adj=OG.adjacency(edges, length=300.0, lengths=lengths))
+    args, params, emul, _ = _setup(networks, 'astlingen', dev, **over)
+    X, Bd, Ex, a = _inputs(args, 1)
+    AE = OE.get_edge_action(OE.config(args), a)
+    ry, rey = OE.forward(args, params, X, Bd, Ex, AE)
+    f = lambda t: t.float().to(dev)
+    y, ey = emul(f(X), f(Bd), f(Ex), emul.get_edge_action(f(a)))
+    assert len(emul.tem1_x) == 5 and emul.tem1_x[4].dilation_rate == 16 and len(emul.flood) == 5
+    close(y, ry, TOL_FWD['bf16x3']); close(ey, rey, TOL_FWD['bf16x3'])      # 10 spatial + 10 temporal + 5 head layers deep: observed 1.0e-5
+
+
 @pytest.mark.parametrize('over', [dict(), dict(act=False, if_flood=0, resnet=False, recurrent='GRU', embed_size=32, hidden_dim=64, n_tp_layer=1),
                                   dict(recurrent='None', edge_fusion=False, n_sp_layer=1)])
 def test_network_forward_mlp_baseline(dev, networks, over):
