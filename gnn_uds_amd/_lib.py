@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # UDS_LIB_PATH: a differently built copy of the same library (kernel experiments: tools/variant_bench.py)
 LIB_PATH = os.environ.get('UDS_LIB_PATH') or os.path.join(_HERE, 'libuds_hip.so')
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
 PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
 
@@ -566,7 +566,7 @@ def dense_cumsum(x, packed, bias=None, res=None, act='linear'):
 
 
 class _Heads(ctypes.Structure):
-    _fields_ = [('a_packed', ctypes.c_void_p), ('a_bias', ctypes.c_void_p), ('h_packed', ctypes.c_void_p * 3), ('h_bias', ctypes.c_void_p * 3),
+    _fields_ = [('a_packed', ctypes.c_void_p), ('a_bias', ctypes.c_void_p), ('h_packed', ctypes.c_void_p * 5), ('h_bias', ctypes.c_void_p * 5),
                 ('f_packed', ctypes.c_void_p), ('f_bias', ctypes.c_void_p), ('n_a', ctypes.c_int32), ('act_a', ctypes.c_int32),
                 ('n_hidden', ctypes.c_int32), ('act_h', ctypes.c_int32), ('act_f', ctypes.c_int32)]
 

@@ -344,15 +344,15 @@ inline hipError_t launch_dense_cumsum(const DenseCumsumArgs &a, hipStream_t st) 
 struct HeadsArgs {
   const uint4 *a_packed;            // (64, n_a) padded to 16 outputs: 2 k-steps x 1 block
   const float *a_bias;              // n_a floats
-  const uint4 *h_packed[3];         // hidden layers: (64, 32), (32, 32), (32, 32)
-  const float *h_bias[3];
+  const uint4 *h_packed[5];         // hidden layers: (64, 32), then up to four (32, 32)
+  const float *h_bias[5];
   const uint4 *f_packed;            // (32, 1) padded to 16 outputs
   const float *f_bias;
   int n_a, act_a, n_hidden, act_h, act_f;
 };
 
 // two waves per SIMD (the head chain is a serial dependency per step: a second wave fills its gaps): 4 waves per workgroup with a
-// ring of 3 x 4 KiB each + 16 KiB of weights = 64 KiB, two workgroups per CU
+// ring of 3 x 4 KiB each + 16 KiB of weights + 16 KiB for the 32 x 32 hidden layers = 80 KiB, two workgroups per CU
 constexpr int DH_WAVES = 4, DH_PREF = 2, DH_RING = DH_PREF + 1;
 
 template <int ACT>
@@ -363,8 +363,15 @@ __global__ __launch_bounds__(DH_WAVES * 64, 2) void k_dense_cumsum_heads(DenseCu
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, qd = lane >> 4;
   uint4 *wlds = reinterpret_cast<uint4 *>(smem_dc);
-  float *ring = smem_dc + KT * MB * 2 * 64 * 4 + wave * (DH_RING * 1024);
+  uint4 *hlds = wlds + KT * MB * 2 * 64;                          // hidden layers 2..5 of the second head: 4 fragments x 64 lanes each
+  float *hbl = reinterpret_cast<float *>(hlds + 4 * 4 * 64);        // their biases (4 x 32 floats): no global loads inside the time loop,
+                                                                    // whose compiler-placed vmcnt waits would drain the DMA prefetch
+  float *ring = smem_dc + (KT * MB * 2 * 64 + 4 * 4 * 64) * 4 + 128 + wave * (DH_RING * 1024);
   for (int i = tid; i < KT * MB * 2 * 64; i += DH_WAVES * 64) wlds[i] = a.packed[i];
+  for (int l = 1; l < hd.n_hidden; ++l) {
+    for (int i = tid; i < 4 * 64; i += DH_WAVES * 64) hlds[(l - 1) * 256 + i] = hd.h_packed[l][i];
+    if (tid < 32) hbl[(l - 1) * 32 + tid] = hd.h_bias[l] ? hd.h_bias[l][tid] : 0.0f;
+  }
   __syncthreads();
   const int unit = blockIdx.x * DH_WAVES + wave;
   if (unit >= a.B * a.n_blocks) return;
@@ -403,8 +410,8 @@ __global__ __launch_bounds__(DH_WAVES * 64, 2) void k_dense_cumsum_heads(DenseCu
     for (int q = 0; q < 4; ++q) v[q] = (p && 16 * m + 4 * qd + q < n) ? p[16 * m + 4 * qd + q] : 0.0f;
     return v;
   };
-  bf16x8 ah[KT], al[KT], h1h[KT][2], h1l[KT][2], h2h[2], h2l[2], h3h[2], h3l[2], fh, fl;
-  f32x4 ab = bias4(hd.a_bias, hd.n_a, 0), h1b[2], h2b[2], h3b[2], fb = bias4(hd.f_bias, 1, 0);
+  bf16x8 ah[KT], al[KT], h1h[KT][2], h1l[KT][2], fh, fl;
+  f32x4 ab = bias4(hd.a_bias, hd.n_a, 0), h1b[2], fb = bias4(hd.f_bias, 1, 0);
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) ah[kt] = frag(hd.a_packed, kt, 1, 0, 0), al[kt] = frag(hd.a_packed, kt, 1, 0, 1);
   if (hd.n_hidden > 0) {
@@ -413,8 +420,6 @@ __global__ __launch_bounds__(DH_WAVES * 64, 2) void k_dense_cumsum_heads(DenseCu
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) h1h[kt][m] = frag(hd.h_packed[0], kt, 2, m, 0), h1l[kt][m] = frag(hd.h_packed[0], kt, 2, m, 1);
       h1b[m] = bias4(hd.h_bias[0], 32, m);
-      if (hd.n_hidden > 1) h2h[m] = frag(hd.h_packed[1], 0, 2, m, 0), h2l[m] = frag(hd.h_packed[1], 0, 2, m, 1), h2b[m] = bias4(hd.h_bias[1], 32, m);
-      if (hd.n_hidden > 2) h3h[m] = frag(hd.h_packed[2], 0, 2, m, 0), h3l[m] = frag(hd.h_packed[2], 0, 2, m, 1), h3b[m] = bias4(hd.h_bias[2], 32, m);
     }
     fh = frag(hd.f_packed, 0, 1, 0, 0), fl = frag(hd.f_packed, 0, 1, 0, 1);
   }
@@ -475,25 +480,19 @@ __global__ __launch_bounds__(DH_WAVES * 64, 2) void k_dense_cumsum_heads(DenseCu
         for (int j = 0; j < 4; ++j) c1[m][j] = apply_act(c1[m][j], hd.act_h);
       bf16x8 ch, cl;
       split8(*reinterpret_cast<const float4 *>(&c1[0]), *reinterpret_cast<const float4 *>(&c1[1]), ch, cl);
-      if (hd.n_hidden > 1) {
-        f32x4 c2[2] = {h2b[0], h2b[1]};
+      for (int l = 1; l < hd.n_hidden; ++l) {      // 32 -> 32 layers: fragments from LDS (index [(m * 2 + hl) * 64 + lane]), bias from memory
+        f32x4 cn[2];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) c2[m] = mfma3(h2h[m], h2l[m], ch, cl, c2[m]);
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) c2[m][j] = apply_act(c2[m][j], hd.act_h);
-        split8(*reinterpret_cast<const float4 *>(&c2[0]), *reinterpret_cast<const float4 *>(&c2[1]), ch, cl);
-      }
-      if (hd.n_hidden > 2) {
-        f32x4 c3[2] = {h3b[0], h3b[1]};
-#pragma unroll
-        for (int m = 0; m < 2; ++m) c3[m] = mfma3(h3h[m], h3l[m], ch, cl, c3[m]);
+        for (int m = 0; m < 2; ++m) {
+          cn[m] = *reinterpret_cast<const f32x4 *>(hbl + (l - 1) * 32 + 16 * m + 4 * qd);
+          cn[m] = mfma3(__builtin_bit_cast(bf16x8, hlds[(l - 1) * 256 + (m * 2 + 0) * 64 + wl_lane]),
+                        __builtin_bit_cast(bf16x8, hlds[(l - 1) * 256 + (m * 2 + 1) * 64 + wl_lane]), ch, cl, cn[m]);
+        }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) c3[m][j] = apply_act(c3[m][j], hd.act_h);
-        split8(*reinterpret_cast<const float4 *>(&c3[0]), *reinterpret_cast<const float4 *>(&c3[1]), ch, cl);
+          for (int j = 0; j < 4; ++j) cn[m][j] = apply_act(cn[m][j], hd.act_h);
+        split8(*reinterpret_cast<const float4 *>(&cn[0]), *reinterpret_cast<const float4 *>(&cn[1]), ch, cl);
       }
       f32x4 cf = mfma3(fh, fl, ch, cl, fb);
       of = apply_act(cf[0], hd.act_f);
@@ -512,7 +511,7 @@ __global__ __launch_bounds__(DH_WAVES * 64, 2) void k_dense_cumsum_heads(DenseCu
 inline hipError_t launch_dense_cumsum_heads(const DenseCumsumArgs &a, const HeadsArgs &hd, hipStream_t st) {
   const int units = a.B * a.n_blocks;
   const dim3 grid((unsigned)((units + DH_WAVES - 1) / DH_WAVES)), block(DH_WAVES * 64);
-  const size_t lds = (size_t)2 * 4 * 2 * 1024 + (size_t)DH_WAVES * DH_RING * 4096;
+  const size_t lds = (size_t)2 * 4 * 2 * 1024 + (size_t)4 * 4 * 1024 + 512 + (size_t)DH_WAVES * DH_RING * 4096;
   if (a.act == 1) hipLaunchKernelGGL((k_dense_cumsum_heads<1>), grid, block, lds, st, a, hd);
   else if (a.act == 0) hipLaunchKernelGGL((k_dense_cumsum_heads<0>), grid, block, lds, st, a, hd);
   else hipLaunchKernelGGL((k_dense_cumsum_heads<-1>), grid, block, lds, st, a, hd);

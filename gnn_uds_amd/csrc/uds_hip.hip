@@ -513,7 +513,7 @@ int uds_dense_cumsum_heads(const float *x, int64_t B, int64_t T, int64_t R, cons
   UDS_REQUIRE(B >= 0 && T > 0 && R > 0, "uds_dense_cumsum_heads: bad sizes B=%lld T=%lld R=%lld", (long long)B, (long long)T, (long long)R);
   UDS_REQUIRE(act >= UDS_ACT_LINEAR && act <= UDS_ACT_HARD_SIGMOID, "uds_dense_cumsum_heads: unknown activation %d", act);
   UDS_REQUIRE(heads->a_packed && heads->n_a >= 1 && heads->n_a <= 4, "uds_dense_cumsum_heads: first head needs 1..4 outputs (got %d)", heads->n_a);
-  UDS_REQUIRE(heads->n_hidden >= 0 && heads->n_hidden <= 3, "uds_dense_cumsum_heads: 0..3 hidden layers in the second head (got %d)", heads->n_hidden);
+  UDS_REQUIRE(heads->n_hidden >= 0 && heads->n_hidden <= 5, "uds_dense_cumsum_heads: 0..5 hidden layers in the second head (got %d)", heads->n_hidden);
   for (int i = 0; i < heads->n_hidden; ++i) UDS_REQUIRE(heads->h_packed[i], "uds_dense_cumsum_heads: hidden layer %d has no weights", i);
   UDS_REQUIRE(heads->n_hidden == 0 || heads->f_packed, "uds_dense_cumsum_heads: the second head has no output layer");
   for (int v : {heads->act_a, heads->act_h, heads->act_f})
@@ -526,7 +526,7 @@ int uds_dense_cumsum_heads(const float *x, int64_t B, int64_t T, int64_t R, cons
   uds::HeadsArgs hd{};
   hd.a_packed = reinterpret_cast<const uint4 *>(heads->a_packed);
   hd.a_bias = heads->a_bias;
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < 5; ++i) {
     hd.h_packed[i] = reinterpret_cast<const uint4 *>(heads->h_packed[i]);
     hd.h_bias[i] = heads->h_bias[i];
   }

@@ -514,7 +514,7 @@ class Emulator(nn.Module):
             resnet output never reaches memory); None when the shape or mode is not the one that kernel takes."""
             pk = lambda m: _packed_kernel(m, m.kernel)
             ok = (self.resnet and layer.precision == 'bf16x3' and layer.units == 64 and t.shape[-1] == 64 and head.units <= 4
-                  and len(hidden) <= 3 and all(m.units == 32 for m in hidden) and (not hidden or hidden[0].kernel.shape[0] == 64)
+                  and len(hidden) <= 5 and all(m.units == 32 for m in hidden) and (not hidden or hidden[0].kernel.shape[0] == 64)
                   and not _ag.grad_on(t, lin_last, *self.parameters()))
             if not ok:
                 return None

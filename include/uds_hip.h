@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 14
+#define UDS_ABI_VERSION 15
 
 enum {
   UDS_OK = 0,
@@ -184,13 +184,13 @@ int uds_dense_cumsum(const float *x, int64_t B, int64_t T, int64_t R, const void
  *   y = act(cumsum_t(x @ kernel + bias) + res)
  * is consumed where it is produced and never written: out[b,t,r,:] = [ act_a(y @ A + a_bias)  (n_a <= 4 columns)  |
  * act_f(h_n @ F + f_bias)  (1 column, only when n_hidden > 0) ] with h_0 = y, h_i = act_h(h_{i-1} @ H_i + h_bias_i), H_1
- * (64, 32), H_2, H_3 (32, 32): the `out` head + the flood chain on the node side (:324-333), the `e_out` head alone on the
+ * (64, 32), H_2 .. H_5 (32, 32; n_hidden <= 5): the `out` head + the flood chain on the node side (:324-333), the `e_out` head alone on the
  * link side (:336).  Every *_packed is uds_rowgemm_pack of that layer's kernel.  out (B, T, R, n_a + (n_hidden > 0)). */
 typedef struct {
   const void *a_packed;    /* (64, n_a) */
   const float *a_bias;     /* n_a floats or NULL */
-  const void *h_packed[3]; /* (64, 32), (32, 32), (32, 32); unused entries NULL */
-  const float *h_bias[3];  /* 32 floats each or NULL */
+  const void *h_packed[5]; /* (64, 32), then up to four (32, 32); unused entries NULL */
+  const float *h_bias[5];  /* 32 floats each or NULL */
   const void *f_packed;    /* (32, 1) */
   const float *f_bias;     /* 1 float or NULL */
   int32_t n_a, act_a, n_hidden, act_h, act_f;

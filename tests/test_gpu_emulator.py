@@ -155,7 +155,7 @@ def test_network_forward_gcn_and_plain_variants(dev, networks):
 def test_network_forward_deep_shipped_configuration(dev, networks):
     """The deepest configuration the reference ships (`*_5lyrs` models: n_sp_layer = n_tp_layer = 5, if_flood = 5, act, edge fusion,
     resnet, Gaussian-kernel adjacency `length > 0`): Conv1D dilations up to 16 (beyond the streaming kernel's 1 / 2 / 4: the row-GEMM
-    form), a flood chain of five hidden layers (beyond the fused head epilogue's three: the unfused heads)."""
+    form), a flood chain of five hidden layers (the head epilogue's maximum: layers 2..5 read their fragments from LDS)."""
     from oracle import graphs as OG
     net = networks['astlingen']
     edges = np.array(net['edges'])
@@ -168,7 +168,7 @@ def test_network_forward_deep_shipped_configuration(dev, networks):
     ry, rey = OE.forward(args, params, X, Bd, Ex, AE)
     f = lambda t: t.float().to(dev)
     y, ey = emul(f(X), f(Bd), f(Ex), emul.get_edge_action(f(a)))
-    assert len(emul.tem1_x) == 5 and emul.tem1_x[4].dilation_rate == 16 and len(emul.flood) == 5
+    assert len(emul.tem1_x) == 5 and emul.tem1_x[4].dilation_rate == 16 and len(emul.flood) == 5      # five hidden layers: still the fused head epilogue
     close(y, ry, TOL_FWD['bf16x3']); close(ey, rey, TOL_FWD['bf16x3'])      # 10 spatial + 10 temporal + 5 head layers deep: observed 1.0e-5
 
 
