@@ -11,7 +11,7 @@ from .graph import CSR, DrainageGraph, synthetic_drainage_network     # noqa: F4
 from .layers import (Dense, DiffusionConv, GATConv, GCNConv, MixedGAT, NodeEdge,     # noqa: F401
                      SpatialBlock, SpatialLayer)
 
-from .emulator import Conv1D, Emulator                                # noqa: F401,E402
+from .emulator import GRU, LSTM, Conv1D, Emulator                     # noqa: F401,E402
 from . import inp                                                     # noqa: F401,E402
 from .agent import ConvNet, GlobalAttnSumPool                         # noqa: F401,E402
 from . import mpc                                                     # noqa: F401,E402
