@@ -248,14 +248,17 @@ def cpu_baseline(U, g, block_params, d, gpu_out=None, gpu_in=None):
 
 
 def bench_c4(args, U, dist, world, rank, dev):
-    """200k-node network, node-cut over `world` ranks, halo exchange after every layer but the last (strong scaling)."""
+    """200k-node network, node-cut over `world` ranks, halo exchange after every layer but the last (strong scaling).
+    Returns the record on rank 0 (None elsewhere); the caller prints it (`--workload c4`) or embeds it in the headline line."""
     from gnn_uds_amd import dist as D
     nodes = 200000 if args.nodes == 10000 else args.nodes
     links = 240000 if args.links == 12000 else args.links
     S = 8 if args.snapshots == 60 else args.snapshots
     d, L = args.embed, args.layers
     g = U.DrainageGraph.from_edges(U.synthetic_drainage_network(nodes, links, seed=0))
-    prob = D.build_partition_plan(g, world)[rank]
+    part, part_info = D.partition_nodes(g, world, return_info=True)
+    probs = D.build_partition_plan(g, world, part)
+    prob = probs[rank]
     ref = U.SpatialBlock(g, d, L, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1))   # CPU parameters only
     params = [ly.export_params() for ly in ref.layers]
     layers = D.hip_layers(prob, params, d, 'relu', args.precision, dev)
@@ -301,10 +304,11 @@ def bench_c4(args, U, dist, world, rank, dev):
         for ly in layers:
             xx, ee = ly(xx, ee)
     t_comp, t_inorder, t_pipe = timed(compute_only), timed(lambda: block.forward(x, e, stages=1)), timed(lambda: block.forward(x, e))
+    rec = None
     if rank == 0:
         bytes_gs = algorithmic_bytes_per_graph_step(g, d, d)
         achieved = args.steps * L * S * bytes_gs / world / wall / 1e9        # per GPU: each rank streams 1/world of the network
-        print(json.dumps({
+        rec = ({
             'metric': 'graph-steps/sec (forward rollout), 200k-node network partitioned over the GPUs', 'value': args.steps * L * S / wall,
             'unit': 'graph-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else
@@ -313,14 +317,21 @@ def bench_c4(args, U, dist, world, rank, dev):
                                    '%d-way node cut with per-layer halo exchange' % (nodes, links, d, L, S, world),
                        'own_nodes': int(len(prob.own_nodes)), 'halo_nodes': int(len(prob.nodes) - len(prob.own_nodes)),
                        'halo_links': int(len(prob.links) - len(prob.own_links)), 'peers': len(block.exchange.peers),
-                       'halo_bytes_per_layer': block.exchange.bytes_per_layer(S, d), 'precision': args.precision},
+                       'halo_bytes_per_layer': block.exchange.bytes_per_layer(S, d), 'precision': args.precision,
+                       'partition': {'cut_links': part_info['refined'], 'candidates': {k: part_info[k] for k in ('id', 'bfs', 'rcm')},
+                                     'kept': part_info['kept'] + ' + boundary refinement',
+                                     'per_rank': [{'own_nodes': int(len(q.own_nodes)), 'own_links': int(len(q.own_links)),
+                                                   'halo_nodes': int(len(q.nodes) - len(q.own_nodes)),
+                                                   'halo_links': int(len(q.links) - len(q.own_links)),
+                                                   'rows_sent_per_layer': int(sum(len(v) for v in q.send_nodes.values()) +
+                                                                              sum(len(v) for v in q.send_links.values())),
+                                                   'peers': len(set(q.send_nodes) | set(q.recv_nodes))} for q in probs]}},
             'halo': {'compute_only_ms': t_comp, 'in_order_ms': t_inorder, 'pipelined_ms': t_pipe,
                      'halo_ms_per_layer': (t_inorder - t_comp) / max(1, L - 1), 'exposed_ms_per_layer': (t_pipe - t_comp) / max(1, L - 1),
                      'note': 'exchange hidden by pipelining over 2 snapshot groups on a side stream (dist.ShardedSpatialBlock.forward)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
-                         'traffic': None, 'kernel': 'k_fused_tile (per rank, its part of the network)'}}))
-    if dist is not None:
-        dist.destroy_process_group()
+                         'traffic': None, 'kernel': 'k_fused_tile (per rank, its part of the network)'}})
+    return rec
 
 
 def bench_c5(args, U, dist, world, rank, dev):
@@ -408,9 +419,27 @@ def main():
     ap.add_argument('--autoregressive', action='store_true',
                     help='also time the C2 autoregressive rollout (100 fed-back steps, eager and HIP graph); off by default so that '
                          'the rocprofv3 averages of the default command are those of the timed headline launches')
+    ap.add_argument('--no-c4', action='store_true', help='skip the 200k-node partitioned leg of the headline line')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` (how the driver calls it): start the N ranks here, as a CHILD process and before
+        # anything in this process touches the GPU (never exec / fork from a process that has initialised HIP), relay
+        # what they print -- rank 0's one JSON line -- and leave with the launcher's exit code.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or let `python bench.py --gpus N` start them)'
+                         % (args.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
@@ -436,7 +465,12 @@ def main():
     if args.workload == 'c5':
         return bench_c5(args, U, dist if world > 1 else None, world, rank, dev)
     if args.workload == 'c4':
-        return bench_c4(args, U, dist, world, rank, dev)
+        rec = bench_c4(args, U, dist, world, rank, dev)
+        if rank == 0:
+            print(json.dumps(rec))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     g = U.DrainageGraph.from_edges(U.synthetic_drainage_network(args.nodes, args.links, seed=0))
     d, L, S = args.embed, args.layers, args.snapshots
     # random-init weights of the reference architecture (Keras initialisers: glorot_uniform kernels, zero
@@ -476,6 +510,13 @@ def main():
         wall = float(t.item())
     dev_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))      # device time of one step
 
+    # BASELINE.json's partitioned case beside the headline (every N, so that the N = 1 line is the base of the strong-scaling
+    # ratio): the 200k-node network node-cut over the ranks, boundary rows exchanged after every layer
+    c4 = None
+    if not args.no_c4 and args.embed == 64 and args.precision == 'bf16x3' and (args.nodes, args.links) == (10000, 12000):
+        c4 = bench_c4(argparse.Namespace(**dict(vars(args), steps=min(args.steps, 10), warmup=min(args.warmup, 2), snapshots=60)),
+                      U, dist, world, rank, dev)
+
     if rank == 0:
         gsteps = args.steps * L * S * world
         bytes_gs = algorithmic_bytes_per_graph_step(g, d, d)
@@ -505,6 +546,8 @@ def main():
                          'algorithmic_bytes_per_graph_step': bytes_gs, 'device_ms_per_step': dev_ms,
                          'timed_region_ms': wall * 1e3, 'run_to_run_spread': '2-3 % between boxes and runs (DESIGN.md section 7)'},
         }
+        if c4 is not None:
+            out['c4_partitioned'] = {k: c4[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'ms_per_step', 'scaling', 'config', 'halo', 'roofline')}
         if world == 1 and args.embed == 64:
             out['rollout'] = rollout_forward(U, g, args, dev)
             if args.autoregressive:

@@ -164,13 +164,8 @@ inline int64_t conv_stream_lds_bytes() {
 
 template <int D, int ACT>
 inline hipError_t launch_conv_stream_a(const ConvStreamArgs &a, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv3_stream<D, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0;
+  if (hipError_t e = set_max_lds_once(reinterpret_cast<const void *>(&k_conv3_stream<D, ACT>), 160 * 1024, attr_done); e != hipSuccess) return e;
   const int units = a.n_seg * a.B * a.n_blocks;
   hipLaunchKernelGGL((k_conv3_stream<D, ACT>), dim3((unsigned)((units + CS_WAVES - 1) / CS_WAVES)), dim3(CS_WAVES * 64),
                      (size_t)conv_stream_lds_bytes(), st, a);

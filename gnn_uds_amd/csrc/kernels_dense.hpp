@@ -14,6 +14,20 @@
 
 namespace uds {
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: `done` (one static word per kernel instantiation) keeps a
+// bit per device ordinal, so a process that drives several GPUs raises the limit on each of them once.
+inline hipError_t set_max_lds_once(const void *fn, int bytes, unsigned long long &done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done & bit) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done |= bit;
+  return e;
+}
+
+
 struct DenseArgs {
   const float *xa, *xb, *W, *bias, *a_self, *a_nbr;
   float *out, *s_self, *s_nbr;

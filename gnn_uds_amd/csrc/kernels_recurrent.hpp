@@ -197,13 +197,9 @@ inline size_t recurrent_mfma_lds(int G, int ktx) { return (size_t)G * (ktx + 2) 
 
 template <int G, int KTX>
 inline hipError_t launch_recurrent_mfma_t(const RecurrentMfmaArgs &a, hipStream_t st) {
-  static bool attr_set = false;                        // once per kernel (never inside a stream capture after the warm-up call)
+  static unsigned long long attr_done = 0;                        // once per kernel (never inside a stream capture after the warm-up call)
   const size_t lds = recurrent_mfma_lds(G, KTX);
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_recurrent_mfma<G, KTX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = set_max_lds_once(reinterpret_cast<const void *>(&k_recurrent_mfma<G, KTX>), (int)lds, attr_done); e != hipSuccess) return e;
   const int units = a.B * a.n_blocks;
   hipLaunchKernelGGL((k_recurrent_mfma<G, KTX>), dim3((unsigned)((units + RC_WAVES - 1) / RC_WAVES)), dim3(RC_WAVES * 64), lds, st, a);
   return hipGetLastError();

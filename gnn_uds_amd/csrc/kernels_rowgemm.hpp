@@ -353,13 +353,8 @@ template <int MB, int KT>
 inline hipError_t launch_rowgemm_small_k(const RowGemmArgs &a, hipStream_t st) {
   constexpr int cg = MB >= 2 ? 2 : 1;
   const size_t lds = (size_t)KT * MB * 2 * 1024 + 256 + 8 * 16 * (16 * cg + 4) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowgemm_small<MB, KT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0;
+  if (hipError_t e = set_max_lds_once(reinterpret_cast<const void *>(&k_rowgemm_small<MB, KT>), 160 * 1024, attr_done); e != hipSuccess) return e;
   const int64_t n_blocks = (a.rows + 15) / 16;
   const int64_t grid = std::min<int64_t>(256, n_blocks);
   RowGemmArgs b = a;
@@ -372,13 +367,8 @@ template <int MB, int KT>
 inline hipError_t launch_rowgemm_small_pair_k(const RowGemmArgs &a0, const RowGemmArgs &a1, hipStream_t st) {
   constexpr int cg = MB >= 2 ? 2 : 1;
   const size_t lds = (size_t)KT * MB * 2 * 1024 + 256 + 8 * 16 * (16 * cg + 4) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowgemm_small_pair<MB, KT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0;
+  if (hipError_t e = set_max_lds_once(reinterpret_cast<const void *>(&k_rowgemm_small_pair<MB, KT>), 160 * 1024, attr_done); e != hipSuccess) return e;
   const int64_t n_blocks = std::max((a0.rows + 15) / 16, (a1.rows + 15) / 16);
   const int64_t grid = std::max<int64_t>(1, std::min<int64_t>(128, n_blocks));      // 128 workgroups per problem: the pair fills the 256 CUs
   RowGemmArgs b0 = a0, b1 = a1;
@@ -430,13 +420,8 @@ inline int rowgemm_ring(int K, int MB) {
 
 template <int MB, int NB, int RING, bool STAGE = true>
 inline hipError_t launch_rowgemm_r(const RowGemmArgs &a, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowgemm_mfma<MB, NB, RING, STAGE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0;
+  if (hipError_t e = set_max_lds_once(reinterpret_cast<const void *>(&k_rowgemm_mfma<MB, NB, RING, STAGE>), 160 * 1024, attr_done); e != hipSuccess) return e;
   constexpr int64_t WT = NB * 16;                          // rows of a wave-tile
   const int64_t lds = rowgemm_lds_bytes(a.taps * a.F, MB, RING, STAGE);
   RowGemmArgs b = a;

@@ -140,13 +140,8 @@ namespace {
 
 template <int FP, int FS, int ACT>
 hipError_t launch_fused128_act(const uds::FusedArgs &a, int grid, int64_t lds, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&uds::k_fused_cs<128, FP, FS, uds::FUSED_WAVES, ACT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BUDGET);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0;
+  if (hipError_t e = uds::set_max_lds_once(reinterpret_cast<const void *>(&uds::k_fused_cs<128, FP, FS, uds::FUSED_WAVES, ACT>), (int)FUSED_LDS_BUDGET, attr_done); e != hipSuccess) return e;
   hipLaunchKernelGGL((uds::k_fused_cs<128, FP, FS, uds::FUSED_WAVES, ACT>), dim3(grid), dim3(uds::FUSED_WAVES * 64), (size_t)lds, st, a);
   return hipGetLastError();
 }
@@ -159,13 +154,8 @@ hipError_t launch_fused128(const uds::FusedArgs &a, int grid, int64_t lds, hipSt
 
 template <int FP, int FS, int ACT>
 hipError_t launch_fused_act(const uds::FusedArgs &a, int grid, int64_t lds, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&uds::k_fused_tile<FP, FS, ACT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BUDGET);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0;
+  if (hipError_t e = uds::set_max_lds_once(reinterpret_cast<const void *>(&uds::k_fused_tile<FP, FS, ACT>), (int)FUSED_LDS_BUDGET, attr_done); e != hipSuccess) return e;
   hipLaunchKernelGGL((uds::k_fused_tile<FP, FS, ACT>), dim3(grid), dim3(uds::FUSED_WAVES * 64), (size_t)lds, st, a);
   return hipGetLastError();
 }

@@ -30,21 +30,95 @@ from .graph import CSR, DrainageGraph
 I32 = np.int32
 
 
-def partition_nodes(graph, n_parts):
-    """Node -> part (int32): equal contiguous ranges of a depth-first pre-order of a spanning forest.  A range of a tree's
-    pre-order is a union of a few whole subtrees plus a path, so the cut stays small on near-tree networks (200k-node
-    synthetic catchment, 8 parts: 2.2 % of the links cut).  The traversal is scipy's compiled depth_first_order, one call per
-    connected component (0.07 s at 200k nodes); every rank derives the same order from the same network."""
+def _link_matrix(graph):
+    """Symmetric 0/1 node x node matrix of the LINKS themselves (not the `order`-hop GAT pattern): what a node cut cuts."""
     import scipy.sparse as sp
-    from scipy.sparse.csgraph import connected_components, depth_first_order
     n = graph.n_node
-    a = sp.csr_matrix((np.ones(graph.adj.nnz, dtype=np.int8), np.asarray(graph.adj.col), np.asarray(graph.adj.rowptr)), shape=(n, n))
+    e = np.asarray(graph.edges, dtype=np.int64)
+    e = e[e[:, 0] != e[:, 1]]
+    a = sp.coo_matrix((np.ones(2 * len(e), dtype=np.int8), (np.concatenate([e[:, 0], e[:, 1]]), np.concatenate([e[:, 1], e[:, 0]]))),
+                      shape=(n, n)).tocsr()
+    a.data[:] = 1                                                      # parallel links count once
+    return a
+
+
+def _bfs_level_order(a, graph):
+    """Breadth-first order of every connected component, started at its outfall (a node no link leaves; the lowest-numbered
+    node where a component has none): a range of it is a band of tree levels, whose boundary is one level wide."""
+    from scipy.sparse.csgraph import breadth_first_order, connected_components
+    n = a.shape[0]
     _, label = connected_components(a, directed=False)
-    roots = np.unique(label, return_index=True)[1]                    # lowest-numbered node of every component
-    order = np.concatenate([depth_first_order(a, int(r), directed=False, return_predecessors=False) for r in np.sort(roots)])
-    part = np.empty(n, dtype=I32)
-    part[order] = (np.arange(n, dtype=np.int64) * n_parts // n).astype(I32)
+    has_out = np.zeros(n, dtype=bool)
+    has_out[np.asarray(graph.edges, dtype=np.int64)[:, 0]] = True
+    first = np.full(label.max() + 1, n, dtype=np.int64)
+    np.minimum.at(first, label, np.arange(n))
+    sink = np.full(label.max() + 1, n, dtype=np.int64)
+    idx = np.nonzero(~has_out)[0]
+    np.minimum.at(sink, label[idx], idx)
+    roots = np.where(sink < n, sink, first)
+    return np.concatenate([breadth_first_order(a, int(r), directed=False, return_predecessors=False) for r in roots])
+
+
+def _cut_links(graph, part):
+    e = np.asarray(graph.edges, dtype=np.int64)
+    return int((part[e[:, 0]] != part[e[:, 1]]).sum())
+
+
+def _refine_boundary(a, part, n_parts, slack, passes=4):
+    """Greedy boundary refinement (one Kernighan-Lin style sweep per pass): a boundary node moves to the neighbouring part
+    that holds MORE of its links than its own part does, as long as no part leaves [n/P - slack, n/P + slack] nodes.  Nodes are
+    visited in ascending id, gains are re-evaluated at visit time: deterministic, every rank derives the same result."""
+    indptr, indices = a.indptr, a.indices
+    n = a.shape[0]
+    size = np.bincount(part, minlength=n_parts).astype(np.int64)
+    lo, hi = n // n_parts - slack, -(-n // n_parts) + slack
+    for _ in range(passes):
+        src = np.repeat(np.arange(n), np.diff(indptr))
+        boundary = np.unique(src[part[src] != part[indices]])
+        moved = 0
+        for v in boundary:
+            nb = part[indices[indptr[v]:indptr[v + 1]]]
+            own = part[v]
+            cnt = np.bincount(nb, minlength=n_parts)
+            best = int(np.argmax(cnt))                               # lowest part id among ties
+            if best != own and cnt[best] > cnt[own] and size[own] - 1 >= lo and size[best] + 1 <= hi:
+                part[v] = best
+                size[own] -= 1
+                size[best] += 1
+                moved += 1
+        if not moved:
+            break
     return part
+
+
+def partition_nodes(graph, n_parts, return_info=False):
+    """Node -> part (int32), a node cut into `n_parts` parts of n/P nodes (+- 2 %).
+
+    Three candidate orders are cut into equal contiguous ranges -- the node ids as given (SWMM files and the synthetic
+    generator number a network roughly upstream -> downstream, so an id range is already a band of the tree), breadth-first
+    levels from the outfalls, and reverse Cuthill-McKee -- and the one that cuts the fewest links is kept, then improved by a
+    greedy boundary refinement.  (Round 2 used ranges of a DEPTH-first pre-order: on a deep narrow tree such a range cuts
+    about one link per level -- 5 382 cut links 8-way on the 200k-node network against 463 for the plain id ranges.)
+    All of it is deterministic host-side integer work; every rank derives the same partition from the same network."""
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    n = graph.n_node
+    a = _link_matrix(graph)
+    ranges = (np.arange(n, dtype=np.int64) * n_parts // n).astype(I32)
+    orders = {'id': np.arange(n, dtype=np.int64), 'bfs': _bfs_level_order(a, graph),
+              'rcm': np.asarray(reverse_cuthill_mckee(a, symmetric_mode=True), dtype=np.int64)}
+    best, info = None, {}
+    for name, order in orders.items():
+        part = np.empty(n, dtype=I32)
+        part[order] = ranges
+        info[name] = _cut_links(graph, part)
+        if best is None or info[name] < info[best[0]]:
+            best = (name, part)
+    part = _refine_boundary(a, best[1].copy(), n_parts, slack=max(1, n // n_parts // 50))
+    info['refined'] = _cut_links(graph, part)
+    info['kept'] = best[0]
+    if info['refined'] > info[best[0]]:                              # never worse than the best plain range split
+        part, info['refined'] = best[1], info[best[0]]
+    return (part, info) if return_info else part
 
 
 def _rows_union(csr, rows):

@@ -169,6 +169,35 @@ class KerasAdam:
         torch._foreach_addcdiv_(ps, ms, den, value=-lr_t)
 
 
+def _numeric_suffix(name):
+    tail = name.rsplit('_', 1)[-1]
+    return int(tail) if tail.isdigit() else 0
+
+
+def _find_keras_weight(weights, lname, kname):
+    """The array Keras saved for weight `kname` of layer `lname`, or None.  Tried in turn: the exact names (`<layer>/<w>:0`,
+    the HDF5 group path `<layer>/<layer>/<w>:0`, `<layer>/<w>`); for a weight nested in a recurrent cell (`<cell>/<w>`) ANY
+    single `*_cell*` sub-group of the layer (the cell's auto-number depends on how many cells the Keras session had created
+    before, which the checkpoint does not say); for a DiffusionConv kernel the `diffuse_features*` sub-layers' (K + 1,)
+    kernels stacked in numeric order into the (channels, K + 1) array the module keeps."""
+    for key in ('%s/%s:0' % (lname, kname), '%s/%s/%s:0' % (lname, lname, kname), '%s/%s' % (lname, kname)):
+        if key in weights:
+            return weights[key]
+    mine = [k for k in weights if isinstance(k, str) and k.split('/')[0] == lname]
+    if '/' in kname:                                   # '<cell>/<weight>': match the cell sub-group by suffix
+        tail = '/' + kname.split('/', 1)[1]
+        hits = [k for k in mine if '_cell' in k and (k.endswith(tail + ':0') or k.endswith(tail))]
+        if len(hits) == 1:
+            return weights[hits[0]]
+        return None
+    if kname == 'kernel':
+        subs = [k for k in mine if 'diffuse_features' in k and (k.endswith('/kernel:0') or k.endswith('/kernel'))]
+        if subs:
+            subs.sort(key=lambda k: _numeric_suffix([p for p in k.split('/') if p.startswith('diffuse_features')][-1]))
+            return np.stack([np.asarray(weights[k]).reshape(-1) for k in subs])
+    return None
+
+
 class Emulator(nn.Module):
     def __init__(self, conv=None, resnet=False, recurrent=None, args=None, precision='bf16x3', generator=None):
         super().__init__()
@@ -740,8 +769,10 @@ class Emulator(nn.Module):
         x = states[:, -self.seq_in:]
         ex = edge_state[:, -self.seq_in:]
         assert b.shape[1] == self.seq_out
-        ae = self.get_edge_action(a, True) if self.act else None
-        adj = self.get_adj_action(a, True) if self.act and self.use_adj else None        # :612-617
+        # NumPy mode writes the setting INTO the adjacency entry (g=False, :572-574), graph mode multiplies the entry by it
+        # (g=True, :611-613): the two differ on a weighted adjacency (length > 0), where entry * setting truncates to 0
+        ae = self.get_edge_action(a, not np_form) if self.act else None
+        adj = self.get_adj_action(a, not np_form) if self.act and self.use_adj else None
         nb_ = self.normalize(b, 'b')
         y, ey = self.forward(self.normalize(x, 'x'), nb_, self.normalize(ex, 'e'), ae, adj)
         y, ey = self._post_proc((y, ey), a, nb_, np_form)
@@ -1058,7 +1089,9 @@ class Emulator(nn.Module):
         def temporal(mods):
             for m in mods:
                 if isinstance(m, _Recurrent):       # keras nests the weights in the layer's cell: gru/gru_cell/kernel:0, ...
-                    cell = m.KIND.lower() + '_cell'
+                    # the cell objects are auto-numbered by a counter of their own: the k-th GRU layer saves
+                    # 'gru_k/gru_k/gru_cell_k/kernel:0' (Keras 2.10 creates the cell without a name)
+                    cell = name(m.KIND.lower() + '_cell')
                     out.append((name(m.KIND.lower()), m, [(cell + '/kernel', 'kernel'), (cell + '/recurrent_kernel', 'recurrent_kernel'),
                                                          (cell + '/bias', 'bias')]))
                 else:
@@ -1092,11 +1125,7 @@ class Emulator(nn.Module):
         with torch.no_grad():
             for lname, mod, pairs in self.keras_layer_map():
                 for idx, (kname, pname) in enumerate(pairs):
-                    arr = None
-                    for key in ('%s/%s:0' % (lname, kname), '%s/%s/%s:0' % (lname, lname, kname), '%s/%s' % (lname, kname)):
-                        if key in weights:
-                            arr = weights[key]
-                            break
+                    arr = _find_keras_weight(weights, lname, kname)
                     if arr is None and lname in weights and not hasattr(weights[lname], 'shape'):
                         arr = weights[lname][idx]
                     if arr is None:

@@ -198,14 +198,15 @@ def conv1d_causal(x, kernel, bias, dilation, act):
     return OD.activation(act)(out + bias)
 
 
-def get_adj_action(c, a):
+def get_adj_action(c, a, g=True):
     """`get_adj_action` (emulator.py:343-362), GAT branch: a (B, T, n_act) -> (B, T, N, N) integer adjacency with the entry
-    (from_k, to_k) of every actuated link multiplied by its setting (the graph form, `self.adj * gather(...)`, which equals
-    the numpy form `adj[act_edges] = s` on a 0/1 adjacency), then cast to int (truncation)."""
+    (from_k, to_k) of every actuated link multiplied by its setting (g=True: the graph form, `self.adj * gather(...)`,
+    :345-348) or SET to its setting (g=False: the numpy form `adj[act_edges] = s`, :350-354, what `predict` / `simulate` use);
+    the two agree on a 0/1 adjacency.  Then cast to int (truncation, :361)."""
     adj = torch.from_numpy(np.asarray(c.adj, dtype=np.float64))
     out = adj.expand(tuple(a.shape[:-1]) + adj.shape).clone()
     for k, (u, v) in enumerate(np.asarray(c.act_edges, dtype=np.int64)):
-        out[..., u, v] = adj[u, v] * a[..., k].to(torch.float64)
+        out[..., u, v] = (adj[u, v] if g else 1.0) * a[..., k].to(torch.float64)
     return torch.trunc(out)
 
 
@@ -244,7 +245,35 @@ def lstm_sequence(x, kernel, recurrent_kernel, bias):
     return torch.stack(out, dim=1)
 
 
+# Large rollouts (tests/test_gpu_emulator.py::test_c2_rollout_100_fed_back_steps): route the GAT spatial layers through the
+# SPARSE restatement (oracle/sparse_csr.py; tests/test_oracle_dual.py holds the two to 1e-12 of each other in fp64) -- the
+# dense-masked form needs (S, E, E) logits per layer, minutes per step at E = 2 500.
+SPARSE_SPATIAL = False
+_csr_cache = {}
+
+
 def _spatial_layer(x, e, p, c, dtype, adj=None):
+    if SPARSE_SPATIAL and c.conv == 'GAT' and adj is None:
+        from . import sparse_csr as OS
+        key = (id(c.adj), id(c.edge_adj))          # `config` passes an ndarray `args.adj` through as the same object
+        if key not in _csr_cache:
+            _csr_cache.clear()                         # a new network: the per-layer entries below belong to the old one
+            _csr_cache[key] = (OS.csr_from_dense(c.filter, True)[:2], OS.csr_from_dense(c.edge_filter, True)[:2],
+                               torch.from_numpy(c.node_edge), c.adj, c.edge_adj)      # the arrays are kept alive with their ids
+        a_csr, ea_csr, ne = _csr_cache[key][:3]
+        pk = ('layer', id(p['node_edge_n']['weight']))
+        if pk not in _csr_cache:                   # the support form of this layer's dense NodeEdge parameters, once (a bias off the
+            inci = ne.abs()                        # support has no sparse form: the dense restatement must be used for it)
+            rn, cn, vn, rest_n = OS.node_edge_support(inci, p['node_edge_n']['weight'], p['node_edge_n']['bias'])
+            re_, ce, ve, rest_e = OS.node_edge_support(inci.T, p['node_edge_e']['weight'], p['node_edge_e']['bias'])
+            assert rest_n is None and rest_e is None, 'SPARSE_SPATIAL: NodeEdge bias is non-zero off the incidence support'
+            _csr_cache[pk] = ((rn, cn), (re_, ce), vn, ve, p['node_edge_n']['weight'])
+        inc_n, inc_e, vn, ve = _csr_cache[pk][:4]
+        q = {'xe_k': p['dense_xe']['kernel'], 'xe_b': p['dense_xe']['bias'], 'ex_k': p['dense_ex']['kernel'], 'ex_b': p['dense_ex']['bias'],
+             'ne_n_v': vn.to(dtype), 'ne_e_v': ve.to(dtype), 'gx_k': p['gat_x']['kernel'], 'gx_as': p['gat_x']['attn_kernel_self'],
+             'gx_an': p['gat_x']['attn_kernel_neighs'], 'gx_b': p['gat_x']['bias'], 'ge_k': p['gat_e']['kernel'],
+             'ge_as': p['gat_e']['attn_kernel_self'], 'ge_an': p['gat_e']['attn_kernel_neighs'], 'ge_b': p['gat_e']['bias']}
+        return OS.spatial_layer_csr(x, e, q, a_csr, ea_csr, inc_n, inc_e, act=c.activation)
     q = {'xe_k': p['dense_xe']['kernel'], 'xe_b': p['dense_xe']['bias'], 'ex_k': p['dense_ex']['kernel'],
          'ex_b': p['dense_ex']['bias'], 'ne_n_w': p['node_edge_n']['weight'], 'ne_n_b': p['node_edge_n']['bias'],
          'ne_e_w': p['node_edge_e']['weight'], 'ne_e_b': p['node_edge_e']['bias']}

@@ -106,9 +106,9 @@ def test_c4_size_network_properties(dev):
     # the 8-way node cut of this network: a small cut and level parts (what the >= 6x scaling target rests on)
     part = D.partition_nodes(g, 8)
     cut = int((part[g.edges[:, 0]] != part[g.edges[:, 1]]).sum())
-    assert cut <= 0.03 * g.n_edge, cut
+    assert cut <= 600, cut                  # id ranges: 463, round 2's depth-first ranges: 5 382 (tests/test_dist.py has the halo bounds)
     sizes = np.bincount(part, minlength=8)
-    assert sizes.max() - sizes.min() <= 1
+    assert sizes.min() >= 24500 and sizes.max() <= 25500
 
 
 class _MailboxExchange(D.HaloExchange):

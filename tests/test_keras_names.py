@@ -105,3 +105,53 @@ def test_get_adj_action_matches_the_dense_rewrite_on_a_weighted_adjacency():
     want = (dense[..., rows, cols] != 0).float()
     assert torch.equal(mask[..., off], want[..., off]) and 0.2 < float(mask[..., off].mean()) < 0.9
     assert (pos >= 0).all()                                      # every actuated (from, to) pair is an entry of the pattern
+    # the NumPy-mode form (g=False: the setting is WRITTEN into the entry, emulator.py:350-354; `predict` / `simulate`): on a
+    # weighted adjacency an entry below 1 survives whenever the setting is >= 1, where the product form truncates it away
+    mask_np = em.get_adj_action(a, False)
+    want_np = (OE.get_adj_action(OE.config(args), a, g=False)[..., rows, cols] != 0).float()
+    assert torch.equal(mask_np[..., off], want_np[..., off])
+    assert not torch.equal(mask_np, mask)                        # the two forms do differ here
+
+
+def test_keras_numbers_the_recurrent_cells_and_splits_diffusion_kernels(tmp_path):
+    """Names a real Keras 2.10 `model.h5` uses and the builder's own exporter did not produce before: the k-th GRU layer's cell
+    is `gru_cell_k` (`gru_1/gru_1/gru_cell_1/kernel:0`), whatever number the session had reached; DiffusionConv keeps one
+    `diffuse_features_k/kernel:0` of (K + 1,) per channel.  Both go through the HDF5 writer / reader pair."""
+    from tests import h5_writer as W
+    a = _emul(recurrent='GRU', embed_size=32, hidden_dim=16, n_sp_layer=1, n_tp_layer=2, if_flood=0)
+    names = [n for n, m, _ in a.keras_layer_map() if n.startswith('gru')]
+    assert names == ['gru'] + ['gru_%d' % k for k in range(1, 8)]                     # 4 stacks x 2 layers
+    w = a.export_keras_weights()
+    assert 'gru/gru_cell/kernel:0' in w and 'gru_3/gru_cell_3/recurrent_kernel:0' in w and 'gru_7/gru_cell_7/bias:0' in w
+    # a session that had created other cells before: every cell number shifted, the layers' own numbers not
+    shifted = {}
+    for k, v in w.items():
+        parts = k.split('/')
+        if len(parts) == 3 and parts[1].startswith('gru_cell'):
+            n = int(parts[1].rsplit('_', 1)[1]) if parts[1] != 'gru_cell' else 0
+            parts[1] = 'gru_cell_%d' % (n + 11)
+        shifted['/'.join(parts)] = v
+    W.write_tree(str(tmp_path / 'model.h5'), W.keras_tree(shifted), nodes=3)
+    b = _emul(recurrent='GRU', embed_size=32, hidden_dim=16, n_sp_layer=1, n_tp_layer=2, if_flood=0)
+    for q in b.parameters():
+        q.data.zero_()
+    b.load(str(tmp_path / 'model.h5'))
+    for (n1, p1), (n2, p2) in zip(a.named_parameters(), b.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+    # DiffusionConv: per-channel sub-layer kernels, stacked in numeric (not lexicographic) order
+    c = _emul(conv='Diffusion', embed_size=16, hidden_dim=16, n_sp_layer=1, n_tp_layer=1, if_flood=0, act=False)
+    w = c.export_keras_weights()
+    split = {}
+    for k, v in w.items():
+        if k.startswith('diffusion_conv') and k.endswith('/kernel:0'):
+            for ch in range(v.shape[0]):
+                split['%s/diffuse_features%s/kernel:0' % (k.split('/')[0], '' if ch == 0 else '_%d' % ch)] = np.asarray(v[ch])
+        else:
+            split[k] = v
+    assert any('diffuse_features_11/' in k for k in split)                           # 16 channels: _10.. sort after _9, not after _1
+    d = _emul(conv='Diffusion', embed_size=16, hidden_dim=16, n_sp_layer=1, n_tp_layer=1, if_flood=0, act=False)
+    for q in d.parameters():
+        q.data.zero_()
+    d.load_keras_weights(split)
+    for (n1, p1), (n2, p2) in zip(c.named_parameters(), d.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
