@@ -345,6 +345,9 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, qd = lane >> 4;
   const int c16 = r16, rs = qd;                  // P3 mapping: 16 lanes x float4 per output row, 4 rows per group
+#ifdef UDS_PRIO_YOUNG
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // experiment: static priority for the second-dispatched half (MI355X_MICROARCH.md item 4)
+#endif
 
   // XCD-aware bijective remap: workgroups b, b+8, b+16.. share an XCD (round-robin dispatch), give each XCD
   // a contiguous range of work items so neighbouring tiles of one snapshot chunk meet in one L2.

@@ -1,0 +1,591 @@
+// Wave-specialised form of the fused spatial-layer kernel for 64-wide rows (every layer of a d = 64 block but the
+// 96-wide first layer of block 2): same tiles, same tile blocks, same arithmetic and the same results, bit for bit,
+// as k_fused_tile<64, 64> (kernels_fused.hpp) -- what changes is WHO does what and WHEN.
+//
+// k_fused_tile runs its eight waves through the phases in lock-step (all multiply, then all gather), every wave keeps
+// all the weights (128 VGPRs), every input row passes through an LDS stage, and there are two workgroup barriers per
+// snapshot.  Here the workgroup is two teams, software-pipelined over the snapshots, ONE barrier per snapshot:
+//
+//   interval k     "Y" team (waves 0 .. NY-1): the big weights (96 VGPRs)      "X" team (the rest): the small weights (32 VGPRs)
+//                  P2(s):  [prim | agg] @ Wbig -> hx[k & 1], scores[k & 1]      P1(s+1): secondary MLP -> sec[(k+1) & 1]
+//                          prim rows of s+1 -> registers                                 secondary rows of s+2 -> registers
+//                                                                               P3(s-1): softmax + neighbour sum from hx[(k-1) & 1] -> HBM
+//   ---- barrier ----
+//
+// * No input row touches LDS: each Y wave loads the primary blocks it multiplies straight into the registers its split
+//   reads, each X wave the secondary blocks it feeds to the small GEMM, both one interval ahead.  LDS holds only what is
+//   shared: sec (x2), hx (x2), the attention scalars (x2) and the tile block: 135 KB instead of 157, and ~30 % less LDS
+//   traffic per snapshot (the stage's writes and reads are gone).
+// * Registers follow the roles: Y keeps Wbig and no P3 state, X keeps Wsmall, the rows in flight and the P3 state.
+// * One barrier per interval orders everything: P1(s+1) writes the sec buffer P2(s-1) read an interval ago, P2(s) writes
+//   the hx buffer P3(s-2) read an interval ago.
+// * Global accesses: Y's row loads are ordinary loads (it stores nothing: the compiler's vmcnt counting is exact).  X
+//   stores its outputs behind its row loads, and the compiler -- which merges its pending-operation state over the
+//   exec-masked store branches -- would wait vmcnt(0) for those fresh stores before the next P1; X's row loads are
+//   therefore inline asm and their one wait is counted by hand: vmcnt(number of stores issued since).
+#pragma once
+#include "kernels_fused.hpp"
+
+namespace uds {
+
+#ifndef UDS_WS_NY
+#define UDS_WS_NY 4
+#endif
+#ifndef UDS_WS_SLOTS
+#define UDS_WS_SLOTS 4      // measured: 4 slots 257 us, 2 slots 265 us per launch at the headline size (X has the registers: no weights)
+#endif
+constexpr int WS_NY = UDS_WS_NY, WS_NX = FUSED_WAVES - WS_NY;      // team sizes
+constexpr int WS_SLOTS = UDS_WS_SLOTS;                              // neighbour slots per P3 step (reads in flight per row group)
+#ifndef UDS_WS_PRE
+#define UDS_WS_PRE 0
+#endif
+constexpr int WS_PRE = UDS_WS_PRE;      // P3: neighbour slots whose hx rows are fetched BEFORE the softmax chain (their addresses are static)
+static_assert(WS_PRE % WS_SLOTS == 0, "WS_PRE must be a multiple of WS_SLOTS");
+static_assert(WS_NY >= 2 && WS_NY <= 4, "2 .. 4 waves multiply the primary rows");
+
+// LDS bytes: tile block + 2 x (s_self, s_nbr) + attention vectors / bias + 2 x sec rows + 2 x hx rows
+inline int64_t fused_ws_lds_bytes(int p_cap, int q_cap, int meta_cap) {
+  return 4 * ((int64_t)meta_cap + 4 * p_cap + 2 * FUSED_D + FUSED_H + 2 * (int64_t)q_cap * SEC_STRIDE + 2 * (int64_t)p_cap * FUSED_D);
+}
+
+// 16 bytes per lane from base (wave-uniform, SGPR pair) + voff (per-lane byte offset) + IMM, invisible to the compiler's
+// vmcnt bookkeeping (see the header): the value is NOT there when the statement ends -- ws_vmcnt() makes it so.
+template <int IMM>
+__device__ __forceinline__ void ws_gld16(f32x4 &dst, const float *base, unsigned voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+}
+// tie four row registers to a point of the program: nothing that reads them is scheduled above it, nothing that writes them below
+__device__ __forceinline__ void ws_pin4(f32x4 &a0, f32x4 &a1, f32x4 &a2, f32x4 &a3) {
+  asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+}
+// wait until all but the n youngest vector-memory operations of this wave are done (n <= 8, exact)
+__device__ __forceinline__ void ws_vmcnt(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+  }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
+  constexpr int NT = FUSED_WAVES * 64, NY = WS_NY, NX = WS_NX;
+  constexpr int FP = 64, FS = 64;
+  constexpr int KT_S = FS / 32, MB_S = FUSED_H / 16;                    // small GEMM: 64 -> 32
+  constexpr int KT_X = FP / 32, KT_B = KT_X + 1, MB_B = FUSED_D / 16;   // big GEMM: 64 + 32 -> 64
+  constexpr int U = FUSED_U;
+  constexpr int PJ = (8 + NY - 1) / NY;        // primary 16-row blocks per Y wave (p_cap <= 128)
+  constexpr int SJ = (16 + NX - 1) / NX;       // secondary 16-row blocks per X wave (q_cap <= 256)
+  extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool team_y = wave < NY;                 // wave-uniform role
+  const int yw = wave, xw = wave - NY;           // index inside the team
+  const int r16 = lane & 15, qd = lane >> 4;
+  const int c16 = r16, rs = qd;                  // P3 mapping: 16 lanes x float4 per output row, 4 rows per group
+
+  // XCD-aware bijective remap (as k_fused_tile): workgroups b, b+8, .. share an XCD and get a contiguous range of items
+  const int W = gridDim.x, b = blockIdx.x;
+  const int q8 = W / 8, r8 = W % 8, xcd = b % 8;
+  const int w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+  const int tile = w % a.n_tiles;
+  const int chunk_id = w / a.n_tiles;
+  const int s_begin = chunk_id * a.chunk;
+  const int s_end = min(a.S, (chunk_id + 1) * a.chunk);
+  const int sd = __builtin_amdgcn_readfirstlane(a.hdr[tile * TILE_HDR_INTS + 6]);
+  if (!((a.side_mask >> sd) & 1)) return;
+  const FusedSide &S_ = a.side[sd];
+
+  float *s_self = reinterpret_cast<float *>(smem + a.meta_cap);         // [2][p_cap]
+  float *s_nbr = s_self + 2 * a.p_cap;                                   // [2][p_cap]
+  float *attn = s_nbr + 2 * a.p_cap;             // a_self[64] | a_nbr[64] | b_small[32]
+  float *sec = attn + 2 * FUSED_D + FUSED_H;     // [2][q_cap * SEC_STRIDE]
+  float *hx = sec + 2 * a.q_cap * SEC_STRIDE;    // [2][p_cap * 64]
+  const int sec_buf = a.q_cap * SEC_STRIDE, hx_buf = a.p_cap * FUSED_D;
+
+  // ---- set-up: tile block, attention vectors (each team loads its own weights inside its branch) ----
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.blocks + (int64_t)tile * a.meta_cap);
+    uint4 *dst = reinterpret_cast<uint4 *>(smem);
+    for (int i = tid; i < a.meta_cap / 4; i += NT) dst[i] = src[i];
+  }
+  if (tid < FUSED_D) {   // scaled by log2(e): scores are logits in base-2 units, P3 needs no multiply in front of its exp2
+    attn[tid] = S_.a_self[tid] * 1.44269504088896340736f;
+    attn[FUSED_D + tid] = S_.a_nbr[tid] * 1.44269504088896340736f;
+    if (tid < FUSED_H) attn[2 * FUSED_D + tid] = S_.b_small ? S_.b_small[tid] : 0.f;
+  }
+  __syncthreads();
+  const int n_own = __builtin_amdgcn_readfirstlane(smem[0]), n_prim = __builtin_amdgcn_readfirstlane(smem[1]),
+            n_sec = __builtin_amdgcn_readfirstlane(smem[2]), flags = __builtin_amdgcn_readfirstlane(smem[3]),
+            n_ovf = __builtin_amdgcn_readfirstlane(smem[4]), n_adj = __builtin_amdgcn_readfirstlane(smem[5]),
+            inc_width = __builtin_amdgcn_readfirstlane(smem[7]);
+  const EllOffsets off = ell_offsets(n_own, n_prim, n_sec, flags, n_ovf, n_adj);
+  const int32_t *prim_ids = smem + off.prim;
+  const int32_t *sec_ids = smem + off.sec;
+  const uint32_t *inc_loc = reinterpret_cast<const uint32_t *>(smem + off.inc_loc);
+  int32_t *inc_w = smem + off.inc_w;
+  const f32x4 *inc_val4 = reinterpret_cast<const f32x4 *>(inc_w);
+  const unsigned char *adj_b = reinterpret_cast<const unsigned char *>(smem + off.adj);
+  const int32_t *ovf_ptr = smem + off.ovf_ptr, *ovf_loc = smem + off.ovf_loc;
+  int32_t *ovf_w = smem + off.ovf_w;
+  const int32_t *adj_ptr = smem + off.adj_ptr, *adj_loc = smem + off.adj_loc;
+
+  for (int i = tid; i < ELL_INC * n_prim; i += NT) {      // NodeEdge values of the fixed-width lists (0 for padding)
+    const int k = inc_w[i];
+    reinterpret_cast<float *>(inc_w)[i] = k >= 0 ? S_.ne_val[k] : 0.f;
+  }
+  if (flags & ELL_FLAG_INC_OVF)
+    for (int i = tid; i < n_ovf; i += NT) reinterpret_cast<float *>(ovf_w)[i] = S_.ne_val[ovf_w[i]];
+  const float *ovf_val = reinterpret_cast<const float *>(ovf_w);
+
+#ifdef UDS_PHASE_TIMING
+  unsigned long long tm_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = clock64();
+#define WS_STAMP(k) do { const unsigned long long n_ = clock64(); tm_[k] += n_ - tl_; tl_ = n_; } while (0)
+#define WS_DUMP() do { if (a.dbg && lane == 0) { unsigned long long *o = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 16; \
+    for (int q_ = 0; q_ < 7; ++q_) o[q_] = tm_[q_]; o[12] = wave; \
+    o[7] = 1ull | ((unsigned long long)sd << 8) | ((unsigned long long)n_own << 16) | ((unsigned long long)n_prim << 32) | ((unsigned long long)n_sec << 48); } } while (0)
+#else
+#define WS_STAMP(k) do { } while (0)
+#define WS_DUMP() do { } while (0)
+#endif
+  const int64_t sec_stride = (int64_t)S_.n_sec_glob * FS, prim_stride = (int64_t)S_.n_prim_glob * FP;      // floats per snapshot
+  const int n_snap = s_end - s_begin;
+
+  __syncthreads();   // NodeEdge values are in LDS
+  // The two teams run two separate loops (the same number of barriers in each): what a team keeps in registers across the
+  // snapshots -- the big weights here, the small weights, rows in flight and P3 state there -- is live in its own loop only.
+  if (team_y) {
+    // =========================== Y team: P2 ===========================
+    bf16x8 wbh[KT_B][MB_B], wbl[KT_B][MB_B];      // 96 VGPRs, resident across the snapshot loop
+#pragma unroll
+    for (int t = 0; t < KT_B; ++t)
+#pragma unroll
+      for (int m = 0; m < MB_B; ++m) {
+        wbh[t][m] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + m) * 2 + 0) * 64 + lane]);
+        wbl[t][m] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + m) * 2 + 1) * 64 + lane]);
+      }
+    // element offsets of the rows of this wave's primary blocks (blk = yw + NY j); a lane's piece c of a row = floats 16 c + 4 qd
+    unsigned prow[PJ];
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) prow[j] = (unsigned)prim_ids[min((yw + NY * j) * 16 + r16, n_prim - 1)] * FP + 4u * qd;
+    f32x4 pp[PJ][2 * KT_X];       // the primary rows of the snapshot P2 multiplies next (compile-time indices only: registers)
+    // aggregation operands of the primary blocks (static per tile)
+    unsigned ag_locs[PJ];
+    f32x4 ag_vals[PJ];
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+      const int lr = min((yw + NY * j) * 16 + r16, n_prim - 1);
+      ag_locs[j] = inc_loc[lr];
+      ag_vals[j] = inc_val4[lr];
+    }
+    // Drain the set-up loads HERE, on every path, with a wait the compiler's counter bookkeeping sees: a value loaded before
+    // the loop and first used inside it otherwise gets a conservative `s_waitcnt vmcnt(0)` at that use in EVERY iteration
+    // (the pending state survives the merge at the loop header), which would drain the row prefetch each time.
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+    if (n_snap > 0) {
+      const float *base = S_.prim_in + s_begin * prim_stride;
+      static_for<PJ>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        static_for<2 * KT_X>([&](auto c_) {
+          constexpr int c = decltype(c_)::value;
+          pp[j][c] = *reinterpret_cast<const f32x4 *>(base + prow[j] + 16 * c);
+        });
+      });
+    }
+    WS_STAMP(0);
+    lds_barrier();      // the X team has computed the secondary MLP of the first snapshot
+
+    for (int k = 0; k <= n_snap; ++k) {
+#ifdef UDS_WS_ABL_NO_P2
+      if (false) {
+#else
+      if (k < n_snap) {
+#endif
+        // ---------------- P2: [prim | agg] @ Wbig -> hx, attention scalars ----------------
+        const bool more = k + 1 < n_snap;
+        const float *next = S_.prim_in + (s_begin + k + 1) * prim_stride;
+        const float *secr = sec + (k & 1) * sec_buf;
+        float *hxw = hx + (k & 1) * hx_buf;
+        float *ssw = s_self + (k & 1) * a.p_cap, *snw = s_nbr + (k & 1) * a.p_cap;
+        static_for<PJ>([&](auto j_) {
+          constexpr int j = decltype(j_)::value;
+          const int blk = yw + NY * j;
+#ifndef UDS_WS_P2_BRANCH
+          {     // every block unconditionally (rows clamped, stores predicated): one basic block, the scheduler interleaves the blocks (-2 %)
+#else
+          if (blk * 16 < n_prim) {
+#endif
+            bf16x8 dh[KT_B], dl[KT_B];
+            static_for<KT_X>([&](auto t_) {
+              constexpr int t = decltype(t_)::value;
+              const f32x4 u0 = pp[j][2 * t], u1 = pp[j][2 * t + 1];
+              split8(make_float4(u0[0], u0[1], u0[2], u0[3]), make_float4(u1[0], u1[1], u1[2], u1[3]), dh[t], dl[t]);
+            });
+            if (more)      // the registers are free (their values went through the split): the next snapshot's rows, a whole interval ahead
+              static_for<2 * KT_X>([&](auto c_) {
+                constexpr int c = decltype(c_)::value;
+                pp[j][c] = *reinterpret_cast<const f32x4 *>(next + prow[j] + 16 * c);
+              });
+            const int lrow = blk * 16 + r16;
+            const bool valid = lrow < n_prim;
+            const int lr = min(lrow, n_prim - 1);
+            f32x4 acc[MB_B];
+#pragma unroll
+            for (int m = 0; m < MB_B; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < KT_X; ++t)
+#pragma unroll
+              for (int m = 0; m < MB_B; ++m) acc[m] = mfma3(wbh[t][m], wbl[t][m], dh[t], dl[t], acc[m]);
+            const unsigned locs = ag_locs[j];
+            const f32x4 vals = ag_vals[j];
+            float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;   // this lane's 8 aggregate features (fragment shape)
+            auto fma_row = [&](float wv, const float4 &u0, const float4 &u1) {
+              g0.x = fmaf(wv, u0.x, g0.x); g0.y = fmaf(wv, u0.y, g0.y); g0.z = fmaf(wv, u0.z, g0.z); g0.w = fmaf(wv, u0.w, g0.w);
+              g1.x = fmaf(wv, u1.x, g1.x); g1.y = fmaf(wv, u1.y, g1.y); g1.z = fmaf(wv, u1.z, g1.z); g1.w = fmaf(wv, u1.w, g1.w);
+            };
+            auto add2 = [&](unsigned la, float wa, unsigned lb, float wb) {      // two rows: four reads in flight, then the FMAs
+              const float *ra = secr + la * SEC_STRIDE + 4 * qd, *rb = secr + lb * SEC_STRIDE + 4 * qd;
+              const float4 a0 = *reinterpret_cast<const float4 *>(ra), a1 = *reinterpret_cast<const float4 *>(ra + 16);
+              const float4 b0 = *reinterpret_cast<const float4 *>(rb), b1 = *reinterpret_cast<const float4 *>(rb + 16);
+              fma_row(wa, a0, a1);
+              fma_row(wb, b0, b1);
+            };
+            add2(locs & 0xffu, vals[0], (locs >> 8) & 0xffu, vals[1]);
+            if (inc_width > 2) add2((locs >> 16) & 0xffu, vals[2], locs >> 24, vals[3]);
+            if (flags & ELL_FLAG_INC_OVF)      // rows with more than four incident rows (a junction of five or more conduits)
+              for (int p = ovf_ptr[lr]; p < ovf_ptr[lr + 1]; ++p) {
+                const float *ra = secr + ovf_loc[p] * SEC_STRIDE + 4 * qd;
+                fma_row(ovf_val[p], *reinterpret_cast<const float4 *>(ra), *reinterpret_cast<const float4 *>(ra + 16));
+              }
+            split8(g0, g1, dh[KT_X], dl[KT_X]);
+#pragma unroll
+            for (int m = 0; m < MB_B; ++m) acc[m] = mfma3(wbh[KT_X][m], wbl[KT_X][m], dh[KT_X], dl[KT_X], acc[m]);
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 ps2 = {0.f, 0.f}, pn2 = {0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < MB_B; ++m) {
+              const f32x4 as4 = *reinterpret_cast<const f32x4 *>(attn + 16 * m + 4 * qd);
+              const f32x4 an4 = *reinterpret_cast<const f32x4 *>(attn + FUSED_D + 16 * m + 4 * qd);
+              ps2 = __builtin_elementwise_fma(acc[m].xy, as4.xy, ps2);
+              pn2 = __builtin_elementwise_fma(acc[m].xy, an4.xy, pn2);
+              ps2 = __builtin_elementwise_fma(acc[m].zw, as4.zw, ps2);
+              pn2 = __builtin_elementwise_fma(acc[m].zw, an4.zw, pn2);
+            }
+            const float ps = quarters_sum(ps2.x + ps2.y);
+            const float pn = quarters_sum(pn2.x + pn2.y);
+            if (valid) {
+              if (qd == 0) {
+                ssw[lrow] = ps;
+                snw[lrow] = pn;
+              }
+#pragma unroll
+              for (int m = 0; m < MB_B; ++m)   // chunk index XOR (row & 7): the 8 lanes of a write group hit 8 different slots
+                *reinterpret_cast<f32x4 *>(hxw + lrow * FUSED_D + (((4 * m + qd) ^ (lrow & 7)) << 2)) = acc[m];
+            }
+          }
+        });
+      }
+      WS_STAMP(1);
+      lds_barrier();      // hx / scores of snapshot k are in LDS (and the X team's sec rows of snapshot k + 1)
+      WS_STAMP(2);
+    }
+    WS_DUMP();
+  } else {
+    // =========================== X team: P1 and P3 ===========================
+#ifndef UDS_WS_NO_PRIO
+    __builtin_amdgcn_s_setprio(1);      // the longer instruction stream of the two, and the younger half of the workgroup (-2 %)
+#endif
+    bf16x8 wsh[KT_S][MB_S], wsl[KT_S][MB_S];      // 32 VGPRs
+#pragma unroll
+    for (int t = 0; t < KT_S; ++t)
+#pragma unroll
+      for (int m = 0; m < MB_S; ++m) {
+        wsh[t][m] = __builtin_bit_cast(bf16x8, S_.w_small[((t * MB_S + m) * 2 + 0) * 64 + lane]);
+        wsl[t][m] = __builtin_bit_cast(bf16x8, S_.w_small[((t * MB_S + m) * 2 + 1) * 64 + lane]);
+      }
+    // BYTE offsets of the rows of the secondary blocks this wave multiplies (blk = xw + NX j); piece c = bytes 64 c + 16 qd
+    unsigned srow[SJ];
+#pragma unroll
+    for (int j = 0; j < SJ; ++j) srow[j] = ((unsigned)sec_ids[min((xw + NX * j) * 16 + r16, n_sec - 1)] * FS + 4u * qd) * 4u;
+    f32x4 sp[SJ][2 * KT_S];       // the secondary rows of the snapshot P1 multiplies next (asm loads: see the header)
+    auto load_sec = [&](int s) __attribute__((always_inline)) {      // unconditional (rows are clamped): a fixed number of loads
+      const float *base = S_.sec_in + s * sec_stride;
+      static_for<SJ>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        ws_gld16<0>(sp[j][0], base, srow[j]);
+        ws_gld16<64>(sp[j][1], base, srow[j]);
+        ws_gld16<128>(sp[j][2], base, srow[j]);
+        ws_gld16<192>(sp[j][3], base, srow[j]);
+      });
+    };
+    // P3 rows: degree-sorted inside the tile and dealt in 4-row groups: trip t (0, 1), unit u (0..3) -> group NX (2 u + t) + xw,
+    // so both trips and all waves get the same mix of degrees, in descending order.  Static per tile: the (wave-uniform)
+    // largest degree of every group in SGPRs, this lane's neighbour byte of every group in VGPRs.
+    int p3_dmax[2][U];
+    unsigned p3_jb[2][U];
+    int p3_joff[2][U], p3_orow[2][U], p3_ic[2][U];      // static per tile: neighbour's hx offset (swizzled), output row offset, own row
+    int n_st = 0;                 // output-store instructions this wave issues per snapshot (one per group that has a row)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = 4 * (NX * (2 * u + t) + xw) + rs;
+        const int ic = min(i, n_own - 1);
+        int dmx;
+        if (flags & ELL_FLAG_LONG_ROWS) {
+          dmx = i < n_own ? adj_ptr[ic + 1] - adj_ptr[ic] : 0;
+        } else {
+          const unsigned long long m = __ballot(i < n_own && adj_b[ic * ELL_ADJ + c16] != 0xFF);
+          dmx = __builtin_popcountll((m >> (16 * rs)) & 0xffffull);
+        }
+        dmx = max(dmx, __shfl_xor(dmx, 16));
+        dmx = max(dmx, __shfl_xor(dmx, 32));
+        p3_dmax[t][u] = __builtin_amdgcn_readfirstlane(dmx);
+        p3_jb[t][u] = adj_b[ic * ELL_ADJ + c16];
+        {
+          const bool has_ = i < n_own && p3_jb[t][u] != 0xFFu;
+          const int jn_ = has_ ? (int)p3_jb[t][u] : 0;
+          p3_joff[t][u] = jn_ * (FUSED_D * 4) + ((jn_ & 7) << 4);
+          p3_orow[t][u] = prim_ids[ic] * FUSED_D + 4 * c16;
+          p3_ic[t][u] = ic;
+        }
+        if (4 * (NX * (2 * u + t) + xw) < n_own) ++n_st;
+      }
+    f32x4 bo = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (S_.b_out) bo = *reinterpret_cast<const f32x4 *>(S_.b_out + 4 * c16);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): drain the set-up loads on every path (see the Y team's note)
+
+    // ---------------- P1: secondary MLP, registers -> MFMA -> sec ----------------
+    auto phase1 = [&](int buf) __attribute__((always_inline)) {
+      float *secw = sec + buf * sec_buf;
+      static_for<SJ>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        const int blk = xw + NX * j;
+        if (blk * 16 < n_sec) {
+          bf16x8 dh[KT_S], dl[KT_S];
+          static_for<KT_S>([&](auto t_) {
+            constexpr int t = decltype(t_)::value;
+            const f32x4 u0 = sp[j][2 * t], u1 = sp[j][2 * t + 1];
+            split8(make_float4(u0[0], u0[1], u0[2], u0[3]), make_float4(u1[0], u1[1], u1[2], u1[3]), dh[t], dl[t]);
+          });
+          const int lrow = blk * 16 + r16;
+          f32x4 acc[MB_S];
+#pragma unroll
+          for (int m = 0; m < MB_S; ++m) acc[m] = *reinterpret_cast<const f32x4 *>(attn + 2 * FUSED_D + 16 * m + 4 * qd);
+#pragma unroll
+          for (int t = 0; t < KT_S; ++t)
+#pragma unroll
+            for (int m = 0; m < MB_S; ++m) acc[m] = mfma3(wsh[t][m], wsl[t][m], dh[t], dl[t], acc[m]);
+          if (lrow < n_sec) {
+#pragma unroll
+            for (int m = 0; m < MB_S; ++m) {
+              f32x4 o;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o[q] = fused_act<ACT>(acc[m][q], a.act);
+              *reinterpret_cast<f32x4 *>(secw + lrow * SEC_STRIDE + 16 * m + 4 * qd) = o;
+            }
+          }
+        }
+      });
+    };
+    // tie the row registers to a point of the program: nothing that reads them is scheduled above, nothing that writes them below
+    auto pin_rows = [&]() __attribute__((always_inline)) {
+      static_for<SJ>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        ws_pin4(sp[j][0], sp[j][1], sp[j][2], sp[j][3]);
+      });
+    };
+
+    // first snapshot: rows -> registers -> P1 -> sec[0]; the second snapshot's rows into the registers
+    if (n_snap > 0) {
+      load_sec(s_begin);
+      ws_vmcnt(0);
+      pin_rows();
+      phase1(0);
+      if (n_snap > 1) load_sec(s_begin + 1);
+    }
+    WS_STAMP(0);
+    lds_barrier();
+
+    // ---------------- P3: segmented softmax + neighbour sum -> HBM, one trip = 4 row groups of this wave ----------------
+    auto phase3 = [&](auto T_, int s, int buf) __attribute__((always_inline)) {
+      constexpr int TR = decltype(T_)::value;
+      const float *hxr = hx + buf * hx_buf;
+      const float *ssr = s_self + buf * a.p_cap, *snr = s_nbr + buf * a.p_cap;
+      int jn[U], dmax[U], orow[U];
+      float ss[U], lg[U], wgt[U], den[U];
+      bool ok[U], has[U];
+      int dm = 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {   // unconditional loads on clamped indices: the four groups' reads overlap
+        const int i = 4 * (NX * (2 * u + TR) + xw) + rs;
+        const int ic = min(i, n_own - 1);
+        ok[u] = i < n_own;
+        has[u] = ok[u] && p3_jb[TR][u] != 0xFFu;      // neighbour slot c16 of this row exists (slots fill from 0)
+        jn[u] = has[u] ? (int)p3_jb[TR][u] : 0;
+        dmax[u] = p3_dmax[TR][u];
+        ss[u] = ssr[p3_ic[TR][u]];
+        orow[u] = p3_orow[TR][u];
+        dm = max(dm, dmax[u]);
+      }
+      if (dm == 0) return;            // no row of this trip exists
+      f32x4 acc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (dm <= 16) {
+        int d0 = dmax[0], d1 = dmax[1], d2 = dmax[2], d3 = dmax[3];
+        asm volatile("" : "+s"(d0), "+s"(d1), "+s"(d2), "+s"(d3));      // keep the slot tests on the scalar unit (see k_fused_tile)
+        const int e3 = d3, e2 = max(e3, d2), e1 = max(e2, d1), e0 = max(e1, d0);
+        const char *hxb = reinterpret_cast<const char *>(hxr);
+        const int cx = c16 << 4;
+        int joff[U];      // byte offset of the neighbour's hx row with its swizzle key in bits 4-6: j*256 + (j&7)*16
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          joff[u] = p3_joff[TR][u];
+          const float sv = ss[u] + snr[jn[u]];
+          const float sc = fmaxf(sv, 0.2f * sv);      // leaky_relu(0.2)
+          lg[u] = has[u] ? sc : -INFINITY;
+        }
+        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+        constexpr int R = WS_PRE > 0 ? WS_PRE : 1;
+        f32x4 hh0[U][R];
+        auto pre_read = [&](auto K_, auto A_) __attribute__((always_inline)) {      // slot K of the A groups that still have one
+          constexpr int K = decltype(K_)::value, A = decltype(A_)::value;
+          static_for<A>([&](auto u_) {
+            constexpr int u = decltype(u_)::value;
+            hh0[u][K] = *reinterpret_cast<const f32x4 *>(hxb + (row16_bcast<K>(joff[u]) ^ cx));
+          });
+        };
+        if constexpr (WS_PRE > 0)
+          static_for<WS_PRE>([&](auto K_) {
+            constexpr int K = decltype(K_)::value;
+            if (K < e3) pre_read(K_, I4{});
+            else if (K < e2) pre_read(K_, I3{});
+            else if (K < e1) pre_read(K_, I2{});
+            else if (K < e0) pre_read(K_, I1{});
+          });
+        static_assert(U == 4, "the four-at-once reductions below");
+        float mx[U];
+        row16_max4(lg, mx);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float ex = __builtin_amdgcn_exp2f(lg[u] - mx[u]);
+          wgt[u] = has[u] ? ex : 0.f;
+        }
+        row16_sum4(wgt, den);
+        auto pre_fma = [&](auto K_, auto A_) __attribute__((always_inline)) {
+          constexpr int K = decltype(K_)::value, A = decltype(A_)::value;
+          static_for<A>([&](auto u_) {
+            constexpr int u = decltype(u_)::value;
+            const float wv = __int_as_float(row16_bcast<K>(__float_as_int(wgt[u])));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[u][q] = fmaf(wv, hh0[u][K][q], acc[u][q]);
+          });
+        };
+        if constexpr (WS_PRE > 0)
+          static_for<WS_PRE>([&](auto K_) {
+            constexpr int K = decltype(K_)::value;
+            if (K < e3) pre_fma(K_, I4{});
+            else if (K < e2) pre_fma(K_, I3{});
+            else if (K < e1) pre_fma(K_, I2{});
+            else if (K < e0) pre_fma(K_, I1{});
+          });
+        auto step = [&](auto K_, auto A_) __attribute__((always_inline)) {
+          constexpr int K = decltype(K_)::value, A = decltype(A_)::value, Wd = WS_SLOTS;
+          f32x4 hh[A][Wd];
+#pragma unroll
+          for (int u = 0; u < A; ++u)
+            static_for<Wd>([&](auto i_) {
+              constexpr int i = decltype(i_)::value;
+              hh[u][i] = *reinterpret_cast<const f32x4 *>(hxb + (row16_bcast<K + i>(joff[u]) ^ cx));
+            });
+#pragma unroll
+          for (int u = 0; u < A; ++u)
+            static_for<Wd>([&](auto i_) {
+              constexpr int i = decltype(i_)::value;
+              const float wv = __int_as_float(row16_bcast<K + i>(__float_as_int(wgt[u])));
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[u][q] = fmaf(wv, hh[u][i][q], acc[u][q]);
+            });
+        };
+        bool more = e0 > WS_PRE;
+        static_for<(16 - WS_PRE) / WS_SLOTS>([&](auto t_) {
+          constexpr int K = WS_PRE + decltype(t_)::value * WS_SLOTS;
+          if (more) {
+            using IK = std::integral_constant<int, K>;
+            if (K < e3) step(IK{}, I4{});
+            else if (K < e2) step(IK{}, I3{});
+            else if (K < e1) step(IK{}, I2{});
+            else step(IK{}, I1{});
+            more = e0 > K + WS_SLOTS;
+          }
+        });
+      } else {   // some row has more than 16 neighbours: every lane walks its row's whole list (tiles with ELL_FLAG_LONG_ROWS)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = 4 * (NX * (2 * u + TR) + xw) + rs;
+          const int b0 = i < n_own ? adj_ptr[i] : 0;
+          const int dg = i < n_own ? adj_ptr[i + 1] - b0 : 0;
+          float mx = -INFINITY;
+          for (int p = b0; p < b0 + dg; ++p) mx = fmaxf(mx, leaky02(ss[u] + snr[adj_loc[p]]));
+          den[u] = 0.f;
+          for (int p = b0; p < b0 + dg; ++p) {
+            const int jj = adj_loc[p];
+            const float wv = __builtin_amdgcn_exp2f(leaky02(ss[u] + snr[jj]) - mx);
+            const f32x4 hv = *reinterpret_cast<const f32x4 *>(hxr + jj * FUSED_D + ((c16 ^ (jj & 7)) << 2));
+            den[u] += wv;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[u][q] = fmaf(wv, hv[q], acc[u][q]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (ok[u]) {
+          const float inv = __builtin_amdgcn_rcpf(den[u]);
+          f32x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = fused_act<ACT>(fmaf(acc[u][q], inv, bo[q]), a.act);
+          *reinterpret_cast<f32x4 *>(S_.out + ((int64_t)s * S_.n_prim_glob * FUSED_D + orow[u])) = o;
+        }
+      }
+    };
+
+    for (int k = 0; k <= n_snap; ++k) {
+      const int s = s_begin + k;
+      if (k + 1 < n_snap) {
+        // the rows of snapshot k + 1 were requested an interval ago; the only younger vector-memory operations of this wave
+        // are the output stores of the last interval's P3 (none in the first interval)
+        ws_vmcnt(k >= 1 ? n_st : 0);
+        pin_rows();
+#ifndef UDS_WS_ABL_NO_P1
+        phase1((k + 1) & 1);
+#endif
+        if (k + 2 < n_snap) load_sec(s + 2);
+      }
+      WS_STAMP(3);
+#ifndef UDS_WS_ABL_NO_P3
+      if (k >= 1) {
+        phase3(std::integral_constant<int, 0>{}, s - 1, (k - 1) & 1);
+        WS_STAMP(4);
+        phase3(std::integral_constant<int, 1>{}, s - 1, (k - 1) & 1);
+        WS_STAMP(5);
+      }
+#endif
+      WS_STAMP(1);
+      lds_barrier();
+      WS_STAMP(2);
+    }
+    WS_DUMP();
+  }
+}
+
+}  // namespace uds

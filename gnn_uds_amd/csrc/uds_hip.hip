@@ -18,6 +18,7 @@
 #include "kernels_sparse.hpp"
 #include "kernels_backward.hpp"
 #include "kernels_fused.hpp"
+#include "kernels_fused_ws.hpp"
 #include "kernels_rowgemm.hpp"
 #include "kernels_wgrad.hpp"
 #include "kernels_conv_stream.hpp"
@@ -158,6 +159,19 @@ hipError_t launch_fused_act(const uds::FusedArgs &a, int grid, int64_t lds, hipS
   if (hipError_t e = uds::set_max_lds_once(reinterpret_cast<const void *>(&uds::k_fused_tile<FP, FS, ACT>), (int)FUSED_LDS_BUDGET, attr_done); e != hipSuccess) return e;
   hipLaunchKernelGGL((uds::k_fused_tile<FP, FS, ACT>), dim3(grid), dim3(uds::FUSED_WAVES * 64), (size_t)lds, st, a);
   return hipGetLastError();
+}
+
+template <int ACT>
+hipError_t launch_fused_ws_act(const uds::FusedArgs &a, int grid, int64_t lds, hipStream_t st) {
+  static unsigned long long attr_done = 0;
+  if (hipError_t e = uds::set_max_lds_once(reinterpret_cast<const void *>(&uds::k_fused_ws<ACT>), (int)FUSED_LDS_BUDGET, attr_done); e != hipSuccess) return e;
+  hipLaunchKernelGGL((uds::k_fused_ws<ACT>), dim3(grid), dim3(uds::FUSED_WAVES * 64), (size_t)lds, st, a);
+  return hipGetLastError();
+}
+// the wave-specialised kernel (kernels_fused_ws.hpp): 64-wide rows on both sides, one tensor per side
+hipError_t launch_fused_ws(const uds::FusedArgs &a, int grid, int64_t lds, hipStream_t st) {
+  if (a.act == UDS_ACT_RELU) return launch_fused_ws_act<UDS_ACT_RELU>(a, grid, lds, st);
+  return launch_fused_ws_act<-1>(a, grid, lds, st);
 }
 
 // relu (the reference's activation in every shipped model) is compiled in; other activations are decided at run time
@@ -1119,7 +1133,13 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
     if (fx == fe) {
       a.side_mask = 3;
       const int grid = set_chunk(a.n_tiles);
-      he = (fx == 64) ? launch_fused<64, 64>(a, grid, lds_need, st) : launch_fused<96, 96>(a, grid, lds_need, st);
+      const int64_t ws_lds = uds::fused_ws_lds_bytes(a.p_cap, a.q_cap, a.meta_cap);
+      bool ws = fx == 64 && !xb && !eb && ws_lds <= FUSED_LDS_BUDGET && a.p_cap <= 128 && a.q_cap <= 256;
+#ifdef UDS_NO_WS
+      ws = false;
+#endif
+      if (ws) he = launch_fused_ws(a, grid, ws_lds, st);
+      else he = (fx == 64) ? launch_fused<64, 64>(a, grid, lds_need, st) : launch_fused<96, 96>(a, grid, lds_need, st);
     } else {   // node tiles: FP = fx, FS = fe; link tiles: FP = fe, FS = fx -> one launch per side
       a.side_mask = 1;
       use_plan(sl, 0);      // workgroups go round-robin to the XCDs: a grid of working tiles only keeps the XCDs level

@@ -36,7 +36,7 @@ rows = raw[:(len(raw) // 16) * 16].reshape(-1, 16)
 valid = (rows[:, 7] & 1) == 1
 rows = rows[valid]
 print('waves with stamps:', len(rows), 'plan', info)
-names = ['setup', 'wait_stage', 'P1', 'bar1', 'P2', 'bar2', 'P3']
+names = os.environ.get('PHASE_NAMES', 'setup,wait_stage,P1,bar1,P2,bar2,P3').split(',')
 tot = rows[:, :7].sum()
 for side in (0, 1):
     r = rows[((rows[:, 7] >> 8) & 0xff) == side]
