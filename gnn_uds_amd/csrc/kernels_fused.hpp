@@ -336,6 +336,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
   extern __shared__ __attribute__((aligned(16))) int32_t smem[];
 #ifdef UDS_PHASE_TIMING
   unsigned long long tm_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tl_ = clock64();
+  const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime(), mt0_ = tl_;      // 100 MHz wall clock beside the shader-cycle counter: the clock the chip holds
 #define UDS_STAMP(k) do { const unsigned long long n_ = clock64(); tm_[k] += n_ - tl_; tl_ = n_; } while (0)
 #else
 #define UDS_STAMP(k) do { } while (0)
@@ -842,6 +843,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_tile(FusedArgs a)
   if (a.dbg && lane == 0) {
     unsigned long long *o = a.dbg + ((size_t)blockIdx.x * NW + wave) * 16;
     o[12] = wave;
+    o[15] = ((__builtin_amdgcn_s_memrealtime() - rt0_) << 32) | ((clock64() - mt0_) & 0xffffffffull);
     o[13] = tm_[7];
     o[14] = t_loads_issued_ - t_dma_issued_;
     for (int k = 0; k < 7; ++k) o[k] = tm_[k];

@@ -35,6 +35,11 @@ namespace uds {
 #define UDS_WS_SLOTS 4      // measured: 4 slots 257 us, 2 slots 265 us per launch at the headline size (X has the registers: no weights)
 #endif
 constexpr int WS_NY = UDS_WS_NY, WS_NX = FUSED_WAVES - WS_NY;      // team sizes
+#ifdef UDS_WS_YG
+constexpr int WS_YG = UDS_WS_NY;        // experiment: one P3 row group (the NY highest-degree ones) per Y wave, in the time Y waits at the barrier
+#else                                   // (measured: 263 us against 259 us without -- the Y waves' P3 costs the X partner what it saves it)
+constexpr int WS_YG = 0;
+#endif
 constexpr int WS_SLOTS = UDS_WS_SLOTS;                              // neighbour slots per P3 step (reads in flight per row group)
 #ifndef UDS_WS_PRE
 #define UDS_WS_PRE 0
@@ -86,8 +91,15 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef UDS_WS_PAIR_SAME
+  // waves w and w + 4 share a SIMD: put each team on SIMDs of its own (NY = 4: Y on the SIMDs of waves 0/4 and 1/5, X on 2/6 and 3/7)
+  static_assert(NY == 4, "UDS_WS_PAIR_SAME assumes 4 + 4");
+  const bool team_y = (wave & 3) < 2;
+  const int yw = (wave & 1) + 2 * (wave >> 2), xw = ((wave & 3) - 2) + 2 * (wave >> 2);
+#else
   const bool team_y = wave < NY;                 // wave-uniform role
   const int yw = wave, xw = wave - NY;           // index inside the team
+#endif
   const int r16 = lane & 15, qd = lane >> 4;
   const int c16 = r16, rs = qd;                  // P3 mapping: 16 lanes x float4 per output row, 4 rows per group
 
@@ -147,9 +159,11 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
 
 #ifdef UDS_PHASE_TIMING
   unsigned long long tm_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = clock64();
+  const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime(), mt0_ = tl_;
 #define WS_STAMP(k) do { const unsigned long long n_ = clock64(); tm_[k] += n_ - tl_; tl_ = n_; } while (0)
 #define WS_DUMP() do { if (a.dbg && lane == 0) { unsigned long long *o = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 16; \
     for (int q_ = 0; q_ < 7; ++q_) o[q_] = tm_[q_]; o[12] = wave; \
+    o[15] = ((__builtin_amdgcn_s_memrealtime() - rt0_) << 32) | ((clock64() - mt0_) & 0xffffffffull); \
     o[7] = 1ull | ((unsigned long long)sd << 8) | ((unsigned long long)n_own << 16) | ((unsigned long long)n_prim << 32) | ((unsigned long long)n_sec << 48); } } while (0)
 #else
 #define WS_STAMP(k) do { } while (0)
@@ -185,6 +199,86 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
       ag_locs[j] = inc_loc[lr];
       ag_vals[j] = inc_val4[lr];
     }
+    // P3 of ONE 4-row group per Y wave (group yw: the highest degrees of the tile), static per tile
+    const int yg_i = 4 * yw + rs, yg_ic = min(yg_i, n_own - 1);
+    const bool yg_ok = WS_YG > 0 && yg_i < n_own;
+    const unsigned yg_jb = adj_b[yg_ic * ELL_ADJ + c16];
+    const bool yg_has = yg_ok && yg_jb != 0xFFu;
+    const int yg_jn = yg_has ? (int)yg_jb : 0;
+    const int yg_joff = yg_jn * (FUSED_D * 4) + ((yg_jn & 7) << 4);
+    const int yg_orow = prim_ids[yg_ic] * FUSED_D + 4 * c16;
+    int yg_dmax;
+    {
+      int dmx;
+      if (flags & ELL_FLAG_LONG_ROWS) {
+        dmx = yg_i < n_own ? adj_ptr[yg_ic + 1] - adj_ptr[yg_ic] : 0;
+      } else {
+        const unsigned long long m = __ballot(yg_i < n_own && adj_b[yg_ic * ELL_ADJ + c16] != 0xFF);
+        dmx = __builtin_popcountll((m >> (16 * rs)) & 0xffffull);
+      }
+      dmx = max(dmx, __shfl_xor(dmx, 16));
+      dmx = max(dmx, __shfl_xor(dmx, 32));
+      yg_dmax = WS_YG > 0 ? __builtin_amdgcn_readfirstlane(dmx) : 0;
+    }
+    f32x4 bo = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (S_.b_out) bo = *reinterpret_cast<const f32x4 *>(S_.b_out + 4 * c16);
+    auto phase3_y = [&](int s, int buf) __attribute__((always_inline)) {
+      if (yg_dmax == 0) return;
+      const float *hxr = hx + buf * hx_buf;
+      const float *ssr = s_self + buf * a.p_cap, *snr = s_nbr + buf * a.p_cap;
+      const float ss = ssr[yg_ic];
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      float den;
+      if (yg_dmax <= 16) {
+        const float sv = ss + snr[yg_jn];
+        const float lg = yg_has ? fmaxf(sv, 0.2f * sv) : -INFINITY;
+        const float mx = row16_max(lg);
+        const float ex = __builtin_amdgcn_exp2f(lg - mx);
+        const float wgt = yg_has ? ex : 0.f;
+        den = row16_sum(wgt);
+        const char *hxb = reinterpret_cast<const char *>(hxr);
+        const int cx = c16 << 4;
+        int dmx = yg_dmax;
+        asm volatile("" : "+s"(dmx));
+        static_for<16 / WS_SLOTS>([&](auto t_) {
+          constexpr int K = decltype(t_)::value * WS_SLOTS;
+          if (K < dmx) {
+            f32x4 hh[WS_SLOTS];
+            static_for<WS_SLOTS>([&](auto i_) {
+              constexpr int i = decltype(i_)::value;
+              hh[i] = *reinterpret_cast<const f32x4 *>(hxb + (row16_bcast<K + i>(yg_joff) ^ cx));
+            });
+            static_for<WS_SLOTS>([&](auto i_) {
+              constexpr int i = decltype(i_)::value;
+              const float wv = __int_as_float(row16_bcast<K + i>(__float_as_int(wgt)));
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[q] = fmaf(wv, hh[i][q], acc[q]);
+            });
+          }
+        });
+      } else {      // a row with more than 16 neighbours: walk the whole list
+        const int b0 = yg_ok ? adj_ptr[yg_i] : 0;
+        const int dg = yg_ok ? adj_ptr[yg_i + 1] - b0 : 0;
+        float mx = -INFINITY;
+        for (int p = b0; p < b0 + dg; ++p) mx = fmaxf(mx, leaky02(ss + snr[adj_loc[p]]));
+        den = 0.f;
+        for (int p = b0; p < b0 + dg; ++p) {
+          const int jj = adj_loc[p];
+          const float wv = __builtin_amdgcn_exp2f(leaky02(ss + snr[jj]) - mx);
+          const f32x4 hv = *reinterpret_cast<const f32x4 *>(hxr + jj * FUSED_D + ((c16 ^ (jj & 7)) << 2));
+          den += wv;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = fmaf(wv, hv[q], acc[q]);
+        }
+      }
+      if (yg_ok) {
+        const float inv = __builtin_amdgcn_rcpf(den);
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = fused_act<ACT>(fmaf(acc[q], inv, bo[q]), a.act);
+        *reinterpret_cast<f32x4 *>(S_.out + ((int64_t)s * S_.n_prim_glob * FUSED_D + yg_orow)) = o;
+      }
+    };
     // Drain the set-up loads HERE, on every path, with a wait the compiler's counter bookkeeping sees: a value loaded before
     // the loop and first used inside it otherwise gets a conservative `s_waitcnt vmcnt(0)` at that use in EVERY iteration
     // (the pending state survives the merge at the loop header), which would drain the row prefetch each time.
@@ -239,10 +333,15 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
             f32x4 acc[MB_B];
 #pragma unroll
             for (int m = 0; m < MB_B; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifndef UDS_WS_ABL_Y_NO_MFMA
 #pragma unroll
             for (int t = 0; t < KT_X; ++t)
 #pragma unroll
               for (int m = 0; m < MB_B; ++m) acc[m] = mfma3(wbh[t][m], wbl[t][m], dh[t], dl[t], acc[m]);
+#else
+#pragma unroll
+            for (int m = 0; m < MB_B; ++m) acc[m] = f32x4{__builtin_bit_cast(float, (unsigned)dh[0][0] << 16), (float)m, __builtin_bit_cast(float, (unsigned)dl[1][0] << 16), 0.f};
+#endif
             const unsigned locs = ag_locs[j];
             const f32x4 vals = ag_vals[j];
             float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;   // this lane's 8 aggregate features (fragment shape)
@@ -257,16 +356,24 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
               fma_row(wa, a0, a1);
               fma_row(wb, b0, b1);
             };
+#ifndef UDS_WS_ABL_Y_NO_AGG
             add2(locs & 0xffu, vals[0], (locs >> 8) & 0xffu, vals[1]);
             if (inc_width > 2) add2((locs >> 16) & 0xffu, vals[2], locs >> 24, vals[3]);
+#else
+            g0.x = vals[0]; g1.y = vals[1]; g0.z = __uint_as_float(locs);
+#endif
             if (flags & ELL_FLAG_INC_OVF)      // rows with more than four incident rows (a junction of five or more conduits)
               for (int p = ovf_ptr[lr]; p < ovf_ptr[lr + 1]; ++p) {
                 const float *ra = secr + ovf_loc[p] * SEC_STRIDE + 4 * qd;
                 fma_row(ovf_val[p], *reinterpret_cast<const float4 *>(ra), *reinterpret_cast<const float4 *>(ra + 16));
               }
             split8(g0, g1, dh[KT_X], dl[KT_X]);
+#ifndef UDS_WS_ABL_Y_NO_MFMA
 #pragma unroll
             for (int m = 0; m < MB_B; ++m) acc[m] = mfma3(wbh[KT_X][m], wbl[KT_X][m], dh[KT_X], dl[KT_X], acc[m]);
+#else
+            acc[0][3] += __builtin_bit_cast(float, (unsigned)dh[KT_X][0] << 16) + __builtin_bit_cast(float, (unsigned)dl[KT_X][0] << 16);
+#endif
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             f32x2 ps2 = {0.f, 0.f}, pn2 = {0.f, 0.f};
 #pragma unroll
@@ -280,7 +387,11 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
             }
             const float ps = quarters_sum(ps2.x + ps2.y);
             const float pn = quarters_sum(pn2.x + pn2.y);
+#ifdef UDS_WS_ABL_Y_NO_HXW
+            if (valid && ps == 12345.f) {
+#else
             if (valid) {
+#endif
               if (qd == 0) {
                 ssw[lrow] = ps;
                 snw[lrow] = pn;
@@ -292,6 +403,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
           }
         });
       }
+      if (WS_YG > 0 && k >= 1) phase3_y(s_begin + k - 1, (k - 1) & 1);      // this wave's share of P3(s - 1), in the time it would wait at the barrier
       WS_STAMP(1);
       lds_barrier();      // hx / scores of snapshot k are in LDS (and the X team's sec rows of snapshot k + 1)
       WS_STAMP(2);
@@ -336,7 +448,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int i = 4 * (NX * (2 * u + t) + xw) + rs;
+        const int i = 4 * (WS_YG + NX * (2 * u + t) + xw) + rs;
         const int ic = min(i, n_own - 1);
         int dmx;
         if (flags & ELL_FLAG_LONG_ROWS) {
@@ -356,7 +468,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
           p3_orow[t][u] = prim_ids[ic] * FUSED_D + 4 * c16;
           p3_ic[t][u] = ic;
         }
-        if (4 * (NX * (2 * u + t) + xw) < n_own) ++n_st;
+        if (4 * (WS_YG + NX * (2 * u + t) + xw) < n_own) ++n_st;
       }
     f32x4 bo = f32x4{0.f, 0.f, 0.f, 0.f};
     if (S_.b_out) bo = *reinterpret_cast<const f32x4 *>(S_.b_out + 4 * c16);
@@ -415,8 +527,9 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
     lds_barrier();
 
     // ---------------- P3: segmented softmax + neighbour sum -> HBM, one trip = 4 row groups of this wave ----------------
-    auto phase3 = [&](auto T_, int s, int buf) __attribute__((always_inline)) {
-      constexpr int TR = decltype(T_)::value;
+    auto phase3 = [&](int TR, int s, int buf) __attribute__((always_inline)) {      // TR: trip 0 / 1 (a constant after inlining, or the
+                                                                                        // counter of a real loop under UDS_WS_P3_LOOP: half the code)
+#define P3S(arr, u) (TR ? arr[1][u] : arr[0][u])
       const float *hxr = hx + buf * hx_buf;
       const float *ssr = s_self + buf * a.p_cap, *snr = s_nbr + buf * a.p_cap;
       int jn[U], dmax[U], orow[U];
@@ -425,14 +538,14 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
       int dm = 0;
 #pragma unroll
       for (int u = 0; u < U; ++u) {   // unconditional loads on clamped indices: the four groups' reads overlap
-        const int i = 4 * (NX * (2 * u + TR) + xw) + rs;
+        const int i = 4 * (WS_YG + NX * (2 * u + TR) + xw) + rs;
         const int ic = min(i, n_own - 1);
         ok[u] = i < n_own;
-        has[u] = ok[u] && p3_jb[TR][u] != 0xFFu;      // neighbour slot c16 of this row exists (slots fill from 0)
-        jn[u] = has[u] ? (int)p3_jb[TR][u] : 0;
-        dmax[u] = p3_dmax[TR][u];
-        ss[u] = ssr[p3_ic[TR][u]];
-        orow[u] = p3_orow[TR][u];
+        has[u] = ok[u] && P3S(p3_jb, u) != 0xFFu;      // neighbour slot c16 of this row exists (slots fill from 0)
+        jn[u] = has[u] ? (int)P3S(p3_jb, u) : 0;
+        dmax[u] = P3S(p3_dmax, u);
+        ss[u] = ssr[P3S(p3_ic, u)];
+        orow[u] = P3S(p3_orow, u);
         dm = max(dm, dmax[u]);
       }
       if (dm == 0) return;            // no row of this trip exists
@@ -448,7 +561,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
         int joff[U];      // byte offset of the neighbour's hx row with its swizzle key in bits 4-6: j*256 + (j&7)*16
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          joff[u] = p3_joff[TR][u];
+          joff[u] = P3S(p3_joff, u);
           const float sv = ss[u] + snr[jn[u]];
           const float sc = fmaxf(sv, 0.2f * sv);      // leaky_relu(0.2)
           lg[u] = has[u] ? sc : -INFINITY;
@@ -531,7 +644,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
       } else {   // some row has more than 16 neighbours: every lane walks its row's whole list (tiles with ELL_FLAG_LONG_ROWS)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int i = 4 * (NX * (2 * u + TR) + xw) + rs;
+          const int i = 4 * (WS_YG + NX * (2 * u + TR) + xw) + rs;
           const int b0 = i < n_own ? adj_ptr[i] : 0;
           const int dg = i < n_own ? adj_ptr[i + 1] - b0 : 0;
           float mx = -INFINITY;
@@ -574,10 +687,15 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
       WS_STAMP(3);
 #ifndef UDS_WS_ABL_NO_P3
       if (k >= 1) {
-        phase3(std::integral_constant<int, 0>{}, s - 1, (k - 1) & 1);
+#ifdef UDS_WS_P3_LOOP
+#pragma nounroll
+        for (int tr = 0; tr < 2; ++tr) phase3(tr, s - 1, (k - 1) & 1);
+#else
+        phase3(0, s - 1, (k - 1) & 1);
         WS_STAMP(4);
-        phase3(std::integral_constant<int, 1>{}, s - 1, (k - 1) & 1);
+        phase3(1, s - 1, (k - 1) & 1);
         WS_STAMP(5);
+#endif
       }
 #endif
       WS_STAMP(1);

@@ -44,4 +44,8 @@ for side in (0, 1):
 for wv in range(8):
     r = rows[rows[:, 12] == wv]
     print('wave', wv, {n: int(r[:, k].mean()) for k, n in enumerate(names)}, 'P2a..d', [int(r[:, k].mean()) for k in (8, 9, 10, 11)])
+rt, mt = (rows[:, 15] >> 32).astype(np.float64), (rows[:, 15] & 0xffffffff).astype(np.float64)
+ok = rt > 0
+print('in-kernel clock: median %.3f GHz (shader cycles / 100 MHz real-time ticks per workgroup), workgroup life %.1f us median'
+      % (float(np.median(mt[ok] / rt[ok])) * 0.1, float(np.median(rt[ok])) * 0.01))
 print('shares:', {n: round(float(rows[:, k].sum() / tot), 3) for k, n in enumerate(names)})
