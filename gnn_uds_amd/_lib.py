@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # UDS_LIB_PATH: a differently built copy of the same library (kernel experiments: tools/variant_bench.py)
 LIB_PATH = os.environ.get('UDS_LIB_PATH') or os.path.join(_HERE, 'libuds_hip.so')
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
 PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
 
@@ -42,6 +42,8 @@ SYMBOLS = {
     'uds_recurrent_fused': (_c_int, [_c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_recurrent_fused_supported': (_c_int, [_c_i64, _c_int]),
     'uds_recurrent_forward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
+    'uds_recurrent_forward_train': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr]),
+    'uds_recurrent_backward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr]),
     'uds_rowgemm_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
     'uds_rowgemm_pack': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
     'uds_gat_aggregate_masked': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
@@ -380,6 +382,49 @@ def recurrent_fused(x, packed, b_in, b_rec, kind, projected=False):
         _check(lib.uds_recurrent_fused(_dev(x, 'x'), 0 if projected else F, packed.data_ptr(), _dev(b_in, 'b_in', True), _dev(b_rec, 'b_rec', True),
                                        B, T, R, 0 if kind == 'GRU' else 1, _dev(out, 'out'), _stream()), 'uds_recurrent_fused')
     return out
+
+
+def recurrent_forward_train(xp, recurrent_kernel, recurrent_bias, kind):
+    """(h, c): hidden states (B, T, R, H) as recurrent_forward, plus the LSTM's cell states (None for the GRU) -- what
+    recurrent_backward needs from the forward pass."""
+    lib = load()
+    B, T, R, GH = xp.shape
+    G = {'GRU': 3, 'LSTM': 4}[kind]
+    H = GH // G
+    if GH != G * H or tuple(recurrent_kernel.shape) != (H, GH):
+        raise UdsError('recurrent_forward: xp %r, recurrent kernel %r for a %s' % (tuple(xp.shape), tuple(recurrent_kernel.shape), kind))
+    out = torch.empty((B, T, R, H), device=xp.device, dtype=torch.float32)
+    c = torch.empty_like(out) if kind == 'LSTM' else None
+    if out.numel():
+        _check(lib.uds_recurrent_forward_train(_dev(xp, 'xp'), _dev(recurrent_kernel, 'recurrent_kernel'), _dev(recurrent_bias, 'recurrent_bias', True),
+                                               B, T, R, H, 0 if kind == 'GRU' else 1, _dev(out, 'out'), _dev(c, 'c', True), _stream()),
+               'uds_recurrent_forward_train')
+    return out, c
+
+
+def recurrent_pack_bwd(recurrent_kernel):
+    """MFMA fragments for uds_recurrent_backward: the G 64 x 64 slices of U, then of U_g^T (64 units only)."""
+    G = recurrent_kernel.shape[1] // 64
+    if tuple(recurrent_kernel.shape) != (64, G * 64) or G not in (3, 4):
+        raise UdsError('recurrent_pack_bwd: recurrent kernel %r (64 x G*64 with G = 3 or 4)' % (tuple(recurrent_kernel.shape),))
+    sl = [recurrent_kernel[:, 64 * g:64 * (g + 1)] for g in range(G)]
+    return torch.cat([rowgemm_pack(m.contiguous()) for m in sl] + [rowgemm_pack(m.t().contiguous()) for m in sl]).contiguous()
+
+
+def recurrent_backward(xp, packed, recurrent_bias, h, c, gh, kind):
+    """(dxp (B, T, R, G*64), darec (G, B, T, R, 64)) of a 64-unit GRU / LSTM layer: back-propagation through time in one launch."""
+    lib = load()
+    B, T, R, GH = xp.shape
+    G = {'GRU': 3, 'LSTM': 4}[kind]
+    if GH != G * 64 or tuple(h.shape) != (B, T, R, 64) or tuple(gh.shape) != (B, T, R, 64):
+        raise UdsError('recurrent_backward: xp %r, h %r, gh %r for a 64-unit %s' % (tuple(xp.shape), tuple(h.shape), tuple(gh.shape), kind))
+    dxp = torch.empty_like(xp)
+    darec = torch.empty((G, B, T, R, 64), device=xp.device, dtype=torch.float32)
+    if dxp.numel():
+        _check(lib.uds_recurrent_backward(_dev(xp, 'xp'), packed.data_ptr(), _dev(recurrent_bias, 'recurrent_bias', True), _dev(h, 'h'),
+                                          _dev(c, 'c', True), _dev(gh, 'gh'), B, T, R, 0 if kind == 'GRU' else 1, _dev(dxp, 'dxp'),
+                                          _dev(darec, 'darec'), _stream()), 'uds_recurrent_backward')
+    return dxp, darec
 
 
 def recurrent_forward(xp, recurrent_kernel, recurrent_bias, kind):

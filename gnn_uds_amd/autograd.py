@@ -112,6 +112,36 @@ class DenseFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class RecurrentFn(torch.autograd.Function):
+    """The time recurrence of a 64-unit keras GRU / LSTM on the input projection xp (B, T, R, G*64): forward exact fp32
+    (uds_recurrent_forward_train), backward = back-propagation through time in one launch on the matrix cores
+    (uds_recurrent_backward: gates recomputed from the saved xp and h), the recurrent kernel's gradient one split-K weight-
+    gradient call per gate with a time shift of one, the recurrent bias its bias row.  The Dense that made xp carries the
+    rest (kernel, input bias, dx).  Reference: emulator.py:158-161 inside the GradientTape of fit_eval (:457-484)."""
+
+    @staticmethod
+    def forward(ctx, xp, recurrent_kernel, recurrent_bias, kind, precision):
+        xp = xp.contiguous()
+        h, c = _lib.recurrent_forward_train(xp, recurrent_kernel, recurrent_bias, kind)
+        ctx.save_for_backward(xp, recurrent_kernel, recurrent_bias, h, c)
+        ctx.kind, ctx.precision = kind, precision
+        return h
+
+    @staticmethod
+    def backward(ctx, gh):
+        xp, U, rb, h, c = ctx.saved_tensors
+        G = U.shape[1] // 64
+        dxp, darec = _lib.recurrent_backward(xp, _lib.recurrent_pack_bwd(U), rb, h, c, gh.contiguous(), ctx.kind)
+        dU = drb = None
+        if ctx.needs_input_grad[1] or (rb is not None and ctx.needs_input_grad[2]):
+            want_b = rb is not None and ctx.needs_input_grad[2]
+            parts = [weight_grad(h, darec[g], ctx.precision, want_b, shift=1) for g in range(G)]      # dU_g = sum_t h[t-1]^T darec_g[t]
+            dU = torch.cat([p[0] for p in parts], dim=1)
+            if want_b:
+                drb = torch.cat([p[1] if p[1] is not None else darec[g].reshape(-1, 64).sum(0) for g, p in enumerate(parts)])
+        return (dxp if ctx.needs_input_grad[0] else None), dU, drb, None, None
+
+
 class Conv1DFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kernel, bias, module):

@@ -273,6 +273,7 @@ inline hipError_t launch_dense_act(const DenseArgs &a, hipStream_t st) {
 struct RecurrentArgs {
   const float *xp, *U, *rb;
   float *out;
+  float *c_out;                 // LSTM cell state after every step (B, T, R, H), or NULL: what the backward kernel needs besides `out`
   int B, T, R, H, G, rows;      // rows per workgroup; blockDim = rows * H
 };
 
@@ -322,6 +323,7 @@ __global__ void k_recurrent(RecurrentArgs a) {
     __syncthreads();                 // every thread has read the previous state
     hs[row * H + f] = h;
     if (live) a.out[base * H + f] = h;
+    if (G == 4 && live && a.c_out) a.c_out[base * H + f] = c;
     __syncthreads();
   }
 }

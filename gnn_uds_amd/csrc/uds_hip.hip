@@ -25,6 +25,7 @@
 #include "kernels_fused128.hpp"
 #include "kernels_gemm.hpp"
 #include "kernels_recurrent.hpp"
+#include "kernels_recurrent_bwd.hpp"
 #include "tile_plan.hpp"
 
 namespace {
@@ -343,6 +344,11 @@ int uds_recurrent_fused_supported(int64_t F, int kind) { return uds::recurrent_m
 
 int uds_recurrent_forward(const float *xp, const float *U, const float *rb, int64_t B, int64_t T, int64_t R, int64_t H, int kind,
                           float *out, uds_stream_t stream) {
+  return uds_recurrent_forward_train(xp, U, rb, B, T, R, H, kind, out, nullptr, stream);
+}
+
+int uds_recurrent_forward_train(const float *xp, const float *U, const float *rb, int64_t B, int64_t T, int64_t R, int64_t H, int kind,
+                                float *out, float *c_out, uds_stream_t stream) {
   UDS_REQUIRE(xp && U && out, "uds_recurrent_forward: NULL argument");
   UDS_REQUIRE(kind == 0 || kind == 1, "uds_recurrent_forward: kind %d (0 = GRU, 1 = LSTM)", kind);
   UDS_REQUIRE(B >= 0 && T >= 0 && R >= 0 && H > 0 && H <= 256, "uds_recurrent_forward: bad sizes B=%lld T=%lld R=%lld H=%lld", (long long)B,
@@ -354,9 +360,27 @@ int uds_recurrent_forward(const float *xp, const float *U, const float *rb, int6
   UDS_REQUIRE(lds <= 160 * 1024, "uds_recurrent_forward: the recurrent kernel (%lld x %lld floats) does not fit the 160 KiB LDS", (long long)H,
               (long long)(G * H));
   UDS_REQUIRE((B * R + rows - 1) / rows < INT32_MAX, "uds_recurrent_forward: too many rows");
-  uds::RecurrentArgs a{xp, U, rb, out, (int)B, (int)T, (int)R, (int)H, G, rows};
+  uds::RecurrentArgs a{xp, U, rb, out, c_out, (int)B, (int)T, (int)R, (int)H, G, rows};
   hipError_t e = uds::launch_recurrent(a, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(UDS_EHIP, "uds_recurrent_forward: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
+int uds_recurrent_backward(const float *xp, const void *packed, const float *b_rec, const float *h, const float *c, const float *gh,
+                           int64_t B, int64_t T, int64_t R, int kind, float *dxp, float *darec, uds_stream_t stream) {
+  UDS_REQUIRE(xp && packed && h && gh && dxp && darec, "uds_recurrent_backward: NULL argument");
+  UDS_REQUIRE(kind == 0 || kind == 1, "uds_recurrent_backward: kind %d (0 = GRU, 1 = LSTM)", kind);
+  UDS_REQUIRE(kind == 0 || c, "uds_recurrent_backward: the LSTM needs the cell states of the forward pass (uds_recurrent_forward_train)");
+  UDS_REQUIRE(B >= 0 && T >= 0 && R >= 0, "uds_recurrent_backward: bad sizes B=%lld T=%lld R=%lld", (long long)B, (long long)T, (long long)R);
+  UDS_REQUIRE(aligned16(xp) && aligned16(packed) && aligned16(b_rec) && aligned16(h) && aligned16(c) && aligned16(gh) && aligned16(dxp) &&
+                  aligned16(darec), "uds_recurrent_backward: buffers must be 16-byte aligned");
+  if (B == 0 || T == 0 || R == 0) return UDS_OK;
+  const int64_t n_blocks = (R + 15) / 16;
+  UDS_REQUIRE(B * n_blocks < INT32_MAX && T < INT32_MAX, "uds_recurrent_backward: too many rows");
+  uds::RecurrentBwdArgs a{xp, b_rec, reinterpret_cast<const uint4 *>(packed), h, c, gh, dxp, darec, (int)B, (int)T, (int)R, (int)n_blocks};
+  hipError_t e = kind == 0 ? uds::launch_recurrent_bwd_t<3>(a, static_cast<hipStream_t>(stream))
+                           : uds::launch_recurrent_bwd_t<4>(a, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_recurrent_backward: launch -> %s", hipGetErrorString(e));
   return UDS_OK;
 }
 

@@ -57,12 +57,20 @@ class Conv1D(nn.Module):
         return _lib.conv1d_causal(x, self.kernel, self.bias, self.dilation_rate, self.activation)
 
 
+class _DenseShim:
+    """What DenseFn reads of its module, for a bare (kernel, bias) pair."""
+
+    def __init__(self, precision, units):
+        self.precision, self.units = precision, units
+
+
 class _Recurrent(nn.Module):
     """keras GRU / LSTM(units, return_sequences=True) along the time axis of x (B, T, R, F) (emulator.py:158-161): the input
     projection of every time step is one Dense launch, the recurrence one streaming kernel (uds_recurrent_forward), exact
     fp32; a 64 -> 64 layer with precision='bf16x3' is ONE launch on the matrix cores (uds_recurrent_fused).  Parameters keep the Keras names and shapes -- `kernel` (F, G*units), `recurrent_kernel` (units, G*units), `bias`
     ((2, 3*units) for the TF2 GRU with reset_after=True: input and recurrent bias; (4*units,) for the LSTM) -- and the
-    Keras initialisers (glorot_uniform, orthogonal, zeros with the LSTM's forget-gate bias at one).  Inference only."""
+    Keras initialisers (glorot_uniform, orthogonal, zeros with the LSTM's forget-gate bias at one).  Under autograd (training) the
+    layer runs Dense + `RecurrentFn` (autograd.py): back-propagation through time is one HIP launch (uds_recurrent_backward)."""
     KIND, G = None, 0
 
     def __init__(self, units, return_sequences=True, in_features=None, generator=None, precision='fp32'):
@@ -84,7 +92,14 @@ class _Recurrent(nn.Module):
 
     def forward(self, x):
         if _ag.grad_on(x, self.kernel, self.recurrent_kernel, self.bias):
-            raise NotImplementedError('%s temporal layers are built for inference (no backward kernel)' % self.KIND)
+            # training (fit_eval, emulator.py:457-484): input projection through the Dense operator, the recurrence through
+            # RecurrentFn (exact-fp32 forward, back-propagation through time on the matrix cores)
+            if self.units != 64:
+                raise NotImplementedError('the %s backward kernel is built for 64 units (hidden_dim = 64, the reference default)' % self.KIND)
+            b_in, b_rec = (self.bias[0], self.bias[1]) if self.KIND == 'GRU' else (self.bias, None)
+            shim = _DenseShim(self.precision, self.G * self.units)
+            xp = _ag.DenseFn.apply(x, self.kernel, b_in.contiguous(), shim, 'linear')
+            return _ag.RecurrentFn.apply(xp, self.recurrent_kernel, None if b_rec is None else b_rec.contiguous(), self.KIND, self.precision)
         x = x.contiguous()
         b_in, b_rec = (self.bias[0].contiguous(), self.bias[1].contiguous()) if self.KIND == 'GRU' else (self.bias, None)
         F = x.shape[-1]

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 15
+#define UDS_ABI_VERSION 16
 
 enum {
   UDS_OK = 0,
@@ -100,6 +100,23 @@ int uds_conv1d_causal(const float *x, int64_t B, int64_t T, int64_t R, int64_t F
  * after every step, initial state zero.  H <= 256 and H * G*H floats must fit the LDS. */
 int uds_recurrent_forward(const float *xp, const float *U, const float *rb, int64_t B, int64_t T, int64_t R, int64_t H,
                           int kind, float *out, uds_stream_t stream);
+
+/* The same recurrence for a training step (emulator.py:457-484: fit_eval differentiates through the GRU / LSTM layers of
+ * get_tem_nets, emulator.py:158-161; `recurrent: GRU` is the default of every block of utils/config.yaml): c_out (B, T, R, H)
+ * additionally receives the LSTM's cell state after every step (NULL: not kept; ignored for the GRU).
+ *
+ * uds_recurrent_backward: back-propagation through time of a 64-unit layer, one launch on the matrix cores (split-bf16).
+ * xp, h (the forward output), c (the LSTM's cell states, NULL for the GRU) and gh = dL/dh, all (B, T, R, .) as above;
+ * packed = the G 64-column slices of U in uds_rowgemm_pack layout followed by the G slices of U_g^T (16 KiB each).
+ * Outputs: dxp (B, T, R, G*64) = gradient of the input projection (the Dense backward takes it from there: dW = x^T dxp,
+ * d b_in = sum dxp, dx = dxp W^T) and darec (G, B, T, R, 64) = gradient of the recurrent pre-activation h[t-1] U + b_rec,
+ * gate-major so that dU[:, 64g:64g+64] = sum_t h[t-1]^T darec[g][t] is one uds_wgrad call with a time shift of 1 and
+ * d b_rec its bias row. */
+int uds_recurrent_forward_train(const float *xp, const float *U, const float *rb, int64_t B, int64_t T, int64_t R, int64_t H,
+                                int kind, float *out, float *c_out, uds_stream_t stream);
+int uds_recurrent_backward(const float *xp, const void *packed, const float *b_rec, const float *h, const float *c,
+                           const float *gh, int64_t B, int64_t T, int64_t R, int kind, float *dxp, float *darec,
+                           uds_stream_t stream);
 
 /* A whole keras GRU / LSTM(64, return_sequences=True) layer in ONE launch on the matrix cores (split-bf16, three products,
  * fp32 accumulation): input projection, recurrent product, gates and state update per time step, the state fed back from

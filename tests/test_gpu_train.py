@@ -226,7 +226,42 @@ def _problem(networks, name, dev, seed=3, B=2, **over):
     return args, norms, params, emul, (x, a, b, y, ex, ey), tuple(f32(t) for t in (x, a, b, y, ex, ey))
 
 
-@pytest.mark.parametrize('name,over', [('astlingen', dict(embed_size=8, hidden_dim=8, n_sp_layer=1, n_tp_layer=1, if_flood=1)),
+@pytest.mark.parametrize('kind', ['GRU', 'LSTM'])
+def test_recurrent_backward_matches_autograd_of_the_oracle(dev, kind):
+    """Back-propagation through time of a 64-unit GRU / LSTM (uds_recurrent_backward + uds_wgrad with a time shift) against
+    torch autograd over the fp64 step-by-step oracle (oracle.emulator_ref.gru_sequence / lstm_sequence, themselves pinned
+    against torch.nn.GRU / LSTM in tests/test_oracle_emulator.py): ragged row count (37 = 2 blocks + 5), T = 9, two batch
+    elements; gradients of the input, kernel, recurrent kernel and both biases, 1e-3 of each tensor's largest gradient."""
+    from gnn_uds_amd.emulator import GRU, LSTM
+    g = torch.Generator().manual_seed(7)
+    B, T, R, F, H = 2, 9, 37, 64, 64
+    G = 3 if kind == 'GRU' else 4
+    mod = (GRU if kind == 'GRU' else LSTM)(H, in_features=F, generator=g, precision='bf16x3').to(dev)
+    with torch.no_grad():
+        mod.bias.add_(torch.randn(mod.bias.shape, generator=g).to(dev) * 0.1)
+    x = torch.randn(B, T, R, F, generator=g, dtype=torch.float64)
+    gy = torch.randn(B, T, R, H, generator=g, dtype=torch.float64)
+    # fp64 reference: rows are independent series -> (B*R, T, F)
+    ref_p = [p.detach().double().cpu().requires_grad_(True) for p in (mod.kernel, mod.recurrent_kernel, mod.bias)]
+    xr = x.clone().requires_grad_(True)
+    seq = xr.permute(0, 2, 1, 3).reshape(B * R, T, F)
+    fn = OE.gru_sequence if kind == 'GRU' else OE.lstm_sequence
+    yr = fn(seq, *ref_p).reshape(B, R, T, H).permute(0, 2, 1, 3)
+    (yr * gy).sum().backward()
+    xd = x.float().to(dev).requires_grad_(True)
+    mod.requires_grad_(True)
+    yd = mod(xd)
+    close(yd, yr.detach(), 1e-5)
+    (yd * gy.float().to(dev)).sum().backward()
+    for name, got, ref in (('x', xd.grad, xr.grad), ('kernel', mod.kernel.grad, ref_p[0].grad),
+                           ('recurrent_kernel', mod.recurrent_kernel.grad, ref_p[1].grad), ('bias', mod.bias.grad, ref_p[2].grad)):
+        err = float((got.double().cpu() - ref).abs().max())
+        assert err <= 1e-3 * float(ref.abs().max()), '%s %s: grad err %.3e vs max|grad| %.3e' % (kind, name, err, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('name,over', [('astlingen', dict(recurrent='GRU', n_sp_layer=1, n_tp_layer=2)),      # the reference's default temporal net
+                                       ('astlingen', dict(recurrent='LSTM', n_sp_layer=1, n_tp_layer=1, if_flood=0)),
+                                       ('astlingen', dict(embed_size=8, hidden_dim=8, n_sp_layer=1, n_tp_layer=1, if_flood=1)),
                                        ('shunqing', dict()),
                                        ('hague', dict(act=False, if_flood=0, edge_fusion=False, resnet=False, n_sp_layer=1)),
                                        ('astlingen', dict(roll=2, seq_in=4, seq_out=2, n_sp_layer=1)),
