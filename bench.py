@@ -334,6 +334,43 @@ def bench_c4(args, U, dist, world, rank, dev):
     return rec
 
 
+def bench_small(args, U, dev):
+    """The regime the reference actually ships (all five networks have 30-443 nodes): one spatial layer
+    on S = 4 096 snapshots (a batch of rainfall scenarios x time steps) of each shipped network, d = 64 and d = 128
+    (`embed_size` default 128, utils/config.yaml:39).  A small network is one or two tiles, so the launch is
+    (tiles x snapshot chunks) workgroups of the same fused kernels: graph-steps/s, fraction of the HBM roofline, and how full
+    the tiles and the 256 CUs are.  Link lists: tests/golden/networks.json (data extracted from the reference's .inp files)."""
+    with open(os.path.join(ROOT, 'tests', 'golden', 'networks.json')) as fh:
+        nets = json.load(fh)
+    S = 4096 if args.snapshots == 60 else args.snapshots
+    legs = []
+    for name in ('astlingen', 'shunqing', 'chaohu', 'hague', 'RedChicoSur'):
+        net = nets[name]
+        g = U.DrainageGraph.from_edges(np.array(net['edges']), net['n_node'])
+        for d in (64, 128):
+            layer = U.SpatialLayer(g, d, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1), precision=args.precision).to(dev)
+            gen = torch.Generator().manual_seed(2)
+            x, e = torch.rand(S, g.n_node, d, generator=gen).to(dev), torch.rand(S, g.n_edge, d, generator=gen).to(dev)
+            for _ in range(3):
+                layer(x, e)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+            for a_, b_ in ev:
+                a_.record(); layer(x, e); b_.record()
+            torch.cuda.synchronize()
+            ms = float(np.median([a_.elapsed_time(b_) for a_, b_ in ev]))
+            info = layer.network().plan_info()
+            bytes_gs = algorithmic_bytes_per_graph_step(g, d, d)
+            achieved = S * bytes_gs / (ms * 1e-3) / 1e9
+            tiles = info['node_tiles'] + info['link_tiles']
+            legs.append({'network': name, 'nodes': g.n_node, 'links': g.n_edge, 'd': d, 'snapshots': S, 'ms_per_launch': ms,
+                         'graph_steps_per_s': S / (ms * 1e-3), 'achieved_GBps': achieved, 'frac': achieved / HBM_PEAK_GBPS,
+                         'path': layer.last_path, 'tiles': tiles, 'p_cap': info['p_cap'], 'q_cap': info['q_cap'],
+                         'rows_per_tile': (g.n_node + g.n_edge) / max(1, tiles)})
+    print(json.dumps({'metric': 'graph-steps/sec, one spatial layer on the reference\'s shipped networks (30-443 nodes), S=%d snapshots' % S,
+                      'unit': 'graph-steps/s', 'n_gpus': 1, 'dtype': 'f32 storage/accumulate, GEMM operands as bf16 hi+lo split',
+                      'data': 'link lists of the five shipped networks, synthetic features', 'legs': legs}))
+
+
 def bench_c5(args, U, dist, world, rank, dev):
     """BASELINE.json config 5: training forward + backward on a block-diagonal batch of mini-graphs (default 1 000 graphs
     x 2 000 nodes / 2 500 links, split over the ranks), L-layer GAT spatial block, MSE loss, reverse mode through the HIP
@@ -411,7 +448,7 @@ def main():
     ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'fp32'],
                     help="bf16x3: fused kernel, GEMM operands split into bf16 hi+lo (3 MFMA products, fp32 accumulate); "
                          "fp32: exact-fp32 unfused kernels")
-    ap.add_argument('--workload', default='headline', choices=['headline', 'c4', 'c5'],
+    ap.add_argument('--workload', default='headline', choices=['headline', 'c4', 'c5', 'small'],
                     help='c4: 200k-node / 240k-link network partitioned over the ranks with per-layer halo exchange')
     ap.add_argument('--graph', action='store_true', help='replay the L layer launches of a step from one captured HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -462,6 +499,8 @@ def main():
 
     import gnn_uds_amd as U
 
+    if args.workload == 'small':
+        return bench_small(args, U, dev)
     if args.workload == 'c5':
         return bench_c5(args, U, dist if world > 1 else None, world, rank, dev)
     if args.workload == 'c4':

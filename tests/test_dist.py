@@ -211,3 +211,20 @@ def test_gradient_allreduce_two_processes_gloo():
         assert p.exitcode == 0
     err, calls_one, calls_small = result.get(timeout=10)
     assert err < 1e-7 and calls_one == 1 and calls_small == 3
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus N` (how the driver calls it, WORLD_SIZE unset) must start N ranks as a child launcher BEFORE
+    anything touches the GPU, and a rank whose WORLD_SIZE disagrees with --gpus must refuse to run.  On this CPU-only host
+    every rank stops at 'needs an MI355X' -- after the launcher has started both of them."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count('bench.py needs an MI355X') >= 2, r.stderr[-2000:]          # both ranks got as far as the device check
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=dict(env, WORLD_SIZE='3', RANK='0'),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and '--gpus 2 but WORLD_SIZE=3' in r.stderr
