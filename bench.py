@@ -471,7 +471,10 @@ def main():
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
                '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+        res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        for line in res.stdout.splitlines():      # rank 0's JSON line to stdout, anything else the ranks printed (gloo chatter) to stderr
+            print(line, file=sys.stdout if line.startswith('{') else sys.stderr)
+        raise SystemExit(res.returncode)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:

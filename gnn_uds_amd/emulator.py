@@ -681,6 +681,25 @@ class Emulator(nn.Module):
         return table[..., self._dev_index('act_out', out_o, a.device)], table[..., self._dev_index('act_in', out_i, a.device)]
 
     # ------------------------------------------------------------------ post-processing (:680-770)
+    def _from_node_index(self, device):
+        """(idx (E,) int64, ok (E,) float): the node whose incidence entry of link e is positive -- its from-node -- read off the
+        signed incidence CSR (`get_node_edge`, base.py:432-439: +1 at the from-node, then -1 at the to-node; a link from a node to
+        itself therefore has no positive entry: ok = 0, as in the dense `clip(node_edge, 0, 1)`)."""
+        key = ('from_node', str(device))
+        if key not in self._idx_cache:
+            ie = self.graph.inc_e
+            rows, cols, vals = ie.rows(), np.asarray(ie.col, dtype=np.int64), np.asarray(ie.val)
+            idx, ok = np.zeros(self.n_edge, dtype=np.int64), np.zeros(self.n_edge, dtype=np.float32)
+            pos = vals > 0
+            idx[rows[pos]], ok[rows[pos]] = cols[pos], 1.0
+            self._idx_cache[key] = (torch.as_tensor(idx, device=device), torch.as_tensor(ok, device=device))
+        return self._idx_cache[key]
+
+    def _at_from_node(self, v):
+        """v (..., N) -> (..., E): v @ clip(node_edge, 0, 1) without the dense matrix."""
+        idx, ok = self._from_node_index(v.device)
+        return v[..., idx] * ok
+
     def _flow_balance(self, flow):
         """q_in, q_out (B,T,N,1) from de-normalised link flows (B,T,E,1): HIP kernel on the incidence CSR."""
         if self._inc_handle is None:
@@ -715,14 +734,13 @@ class Emulator(nn.Module):
         preds, edge_preds = preds
         pump_override = self._has_link_pump if np_form else self._has_pump      # :656-659 (always with actions) vs :698 (`pump.min() > 0`)
         depth_gate = 0.01 if np_form else 0.0                                      # :664-665 vs :710-711
-        if self.node_edge is None and (self._has_offset or (self.act and pump_override)):
-            raise NotImplementedError('offset / pump gating needs the dense incidence (`args.node_edge`), not built for CSR-only networks')
-        pos = None if self.node_edge is None else self.node_edge.clamp(0, 1)
+        # `v @ clip(node_edge, 0, 1)` (:649,657,689,699): node_edge has one +1 per link, at its from-node (base.py:432-439), so the
+        # dense (N, E) product is a gather of v at the from-nodes -- the same numbers from the incidence CSR, for any N
         if self.tide:
             h = preds[..., 0] * (1 - self.is_outfall) + b[..., -1]
             preds = torch.cat([h.unsqueeze(-1), preds[..., 1:]], dim=-1)
         if self._has_offset:
-            inoff = torch.matmul(self.normalize(preds, 'y', True)[..., 0] - self.hmin, pos)
+            inoff = self._at_from_node(self.normalize(preds, 'y', True)[..., 0] - self.hmin)
             flow, off = edge_preds[..., -1], self.offset
             flow = (flow * (flow > 0).float() * (off > 0).float() * (inoff > off).float() + flow * (flow <= 0).float() * (off > 0).float() +
                     flow * (off == 0).float()).unsqueeze(-1)
@@ -730,7 +748,7 @@ class Emulator(nn.Module):
         if self.act:
             ne_ = self._norm('e', preds.device)
             if pump_override:
-                fl = self.pump * torch.matmul((preds[..., 0] > 0.01).float(), pos)
+                fl = self.pump * self._at_from_node((preds[..., 0] > 0.01).float())
                 fl = fl * (ne_[0, :, 2] > 1e-3).float() / ne_[0, :, 2]
                 flow = (edge_preds[..., -1] * (fl == 0).float() + fl).unsqueeze(-1)
             else:
@@ -795,9 +813,8 @@ class Emulator(nn.Module):
         ey = torch.cat([torch.minimum(ey[..., 0].clamp(min=0), self.ehmax).unsqueeze(-1), ey[..., 1:]], dim=-1)
         y = self.normalize(y, 'y', True)
         if self._has_any_pump:       # pumped-storage depth (:630-638)
-            if self.node_edge is None:
-                raise NotImplementedError('pumped-storage depth needs the dense incidence (`args.node_edge`)')
-            ps = ((self.area * torch.mv(self.node_edge.clamp(0, 1), self.pump)) > 0).float()
+            idx, ok = self._from_node_index(y.device)          # clip(node_edge, 0, 1) @ pump: the pumps leaving every node
+            ps = ((self.area * torch.zeros_like(self.area).index_add_(0, idx, self.pump * ok)) > 0).float()
             h, qin, qout = y[..., 0], y[..., 1], y[..., 2]
             de = []
             for t in range(self.seq_out):

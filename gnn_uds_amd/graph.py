@@ -460,6 +460,22 @@ class DrainageGraph:
     inc_e: CSR
     meta: dict = field(default_factory=dict)
 
+    def replicated(self, k):
+        """k disjoint copies of this network as ONE network (block-diagonal patterns: node c*N + n, link c*E + e of copy c).
+        (S, N, F) features of S = k * S' snapshots ARE (S', k*N, F) features of the replicated network, in place: this is
+        how a small network (30-60 rows: a quarter of a 128-row tile) fills the tiles of the fused kernel."""
+        k = int(k)
+
+        def rep(c):
+            rp = np.asarray(c.rowptr, dtype=np.int64)
+            rowptr = np.concatenate([rp[:-1] + i * c.nnz for i in range(k)] + [np.array([k * c.nnz], dtype=np.int64)])
+            col = np.concatenate([np.asarray(c.col, dtype=np.int64) + i * c.n_cols for i in range(k)])
+            val = None if c.val is None else np.tile(np.asarray(c.val), k)
+            return CSR(rowptr.astype(I32), col.astype(I32), k * c.n_rows, k * c.n_cols, val)
+        edges = np.concatenate([np.asarray(self.edges, dtype=np.int64) + i * self.n_node for i in range(k)]).astype(I32)
+        return DrainageGraph(k * self.n_node, k * self.n_edge, edges, rep(self.adj), rep(self.edge_adj), rep(self.inc_n), rep(self.inc_e),
+                             dict(self.meta, copies=k))
+
     @classmethod
     def from_edges(cls, edges, n_node=None, directed=False, order=1, length=0, lengths=None):
         """Patterns of the GAT filters `(adj > 0)` with forced self loops (`emulator.py:143-145`) for the reference's

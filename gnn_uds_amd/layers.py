@@ -506,6 +506,20 @@ class SpatialLayer(nn.Module):
             self._net = _lib.NetworkHandle(self.graph)
         return self._net
 
+    PACK_ROWS = 128       # rows of a full tile of the fused kernels (csrc/tile_plan.hpp: p_limit)
+
+    def pack_factor(self):
+        """Snapshots of this network that share one tile of the fused kernel: a network of 30 nodes fills a quarter of a
+        128-row tile, and a tile costs its workgroup the same time a quarter full or full (DESIGN.md 5.1), so k = 128 // rows
+        snapshots are laid side by side as k disjoint copies of the network (DrainageGraph.replicated)."""
+        rows = max(self.graph.n_node, self.graph.n_edge)
+        return max(1, self.PACK_ROWS // rows) if rows <= self.PACK_ROWS // 2 else 1
+
+    def _replica(self, k):
+        if getattr(self, '_rep', None) is None or self._rep[0] != k:
+            self._rep = (k, _lib.NetworkHandle(self.graph.replicated(k)))
+        return self._rep[1]
+
     def export_params(self):
         """Parameters as CPU tensors under the key names of uds_spatial_params_t (NodeEdge as
         'ne_*_w'/'ne_*_b' when dense, 'ne_*_v' support values when sparse)."""
@@ -616,9 +630,30 @@ class SpatialLayer(nn.Module):
                 ox = self.gat_x([xs, net.adj], xb=self.node_edge_n(x_e))
                 oe = self.gat_e([es, net.edge_adj], xb=self.node_edge_e(e_x))
                 return ox.reshape(lead_x + ox.shape[-2:]), oe.reshape(lead_e + oe.shape[-2:])
-            ox, oe = _lib.spatial_layer_forward(self.network(), p, xs, es, self.h, self.d, self.activation,
-                                                _lib.PRECISION_FLAGS[self.precision], xb=xbs, eb=ebs)
-            self.last_path = 'fused' if 'packed' in p else 'unfused'
+            k, S = self.pack_factor(), xs.shape[0]
+            if 'packed' in p and k > 1 and S >= 16 * k:      # (a handful of snapshots -- the rollout's windows -- stay one launch)
+                # small network: k snapshots per tile.  (S, N, F) -> (S / k, k N, F) is a view; the NodeEdge values repeat per copy.
+                N, E, Sm = self.graph.n_node, self.graph.n_edge, S // k * k
+                rep = self._replica(k)
+                if self.d == 64:
+                    rep.prepare(fx, fe)
+                else:
+                    rep.prepare(128, fe)
+                pk = dict(p, ne_n_val=vn.repeat(k), ne_e_val=ve.repeat(k))
+                v = lambda t, R: None if t is None else t[:Sm].reshape(Sm // k, k * R, t.shape[-1])
+                ox, oe = _lib.spatial_layer_forward(rep, pk, v(xs, N), v(es, E), self.h, self.d, self.activation,
+                                                    _lib.PRECISION_FLAGS[self.precision], xb=v(xbs, N), eb=v(ebs, E))
+                ox, oe = ox.reshape(Sm, N, self.d), oe.reshape(Sm, E, self.d)
+                if Sm < S:     # the last S mod k snapshots one per tile
+                    t = lambda a: None if a is None else a[Sm:].contiguous()
+                    rx, re = _lib.spatial_layer_forward(self.network(), p, t(xs), t(es), self.h, self.d, self.activation,
+                                                        _lib.PRECISION_FLAGS[self.precision], xb=t(xbs), eb=t(ebs))
+                    ox, oe = torch.cat([ox, rx]), torch.cat([oe, re])
+                self.last_path = 'fused'
+            else:
+                ox, oe = _lib.spatial_layer_forward(self.network(), p, xs, es, self.h, self.d, self.activation,
+                                                    _lib.PRECISION_FLAGS[self.precision], xb=xbs, eb=ebs)
+                self.last_path = 'fused' if 'packed' in p else 'unfused'
         return ox.reshape(lead_x + ox.shape[-2:]), oe.reshape(lead_e + oe.shape[-2:])
 
 

@@ -70,3 +70,19 @@ def objective_and_gradient(emul, y, state, runoff, edge_state, n_step, n_act, r_
     obj = objective_pred(preds[0], st, gamma=gamma, **targets)
     (grad,) = torch.autograd.grad(obj.sum(), y)
     return obj.detach(), grad
+
+
+def hessp(emul, y, p, state, runoff, edge_state, n_step, n_act, r_step, targets, gamma=None, eps=None):
+    """`hessp_fn` (`mpc.py:616-624`, the Hessian-vector product `trust-constr` asks for in `run_ntopt`): H(y) p for every
+    candidate, y and p (pop, n_step*n_act).  The reference nests two GradientTapes; the HIP backward operators are first-order
+    (`torch.autograd.Function`s without a double backward), so the product is the central difference of the GRADIENT along p,
+        H p ~ (grad f(y + eps p) - grad f(y - eps p)) / (2 eps),    eps = 1e-2 / max|p|  (settings live in [0, 1]),
+    two gradient evaluations = two batched forward + backward passes through the same kernels.  The objective is piecewise
+    smooth (relu, |.| of the roughness term, hard gates): like the exact second derivative, the difference is meaningful
+    away from the kinks only.  Returns (pop, n_step*n_act)."""
+    p = p.to(y.dtype)
+    if eps is None:
+        eps = 1e-2 / max(float(p.abs().max()), 1e-12)
+    _, g_hi = objective_and_gradient(emul, y + eps * p, state, runoff, edge_state, n_step, n_act, r_step, targets, gamma)
+    _, g_lo = objective_and_gradient(emul, y - eps * p, state, runoff, edge_state, n_step, n_act, r_step, targets, gamma)
+    return (g_hi - g_lo) / (2.0 * eps)

@@ -111,6 +111,30 @@ def test_c4_size_network_properties(dev):
     assert sizes.min() >= 24500 and sizes.max() <= 25500
 
 
+def test_c3_size_batch_of_32_scenarios(dev):
+    """BASELINE.json config 3 at its stated size: the 50 000-node / 65 000-link catchment with a batch of S = 32 rainfall
+    scenarios through the fused layer: two runs bitwise identical, every snapshot independent of its batch (the batched
+    result of snapshots 0, 13 and 31 equals the same snapshot run alone), and two FULL snapshots against the fp64 oracle."""
+    g = U.DrainageGraph.from_edges(U.synthetic_drainage_network(50000, 65000, 0))
+    d, S = 64, 32
+    layer = U.SpatialLayer(g, d, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1)).to(dev)
+    gen = torch.Generator().manual_seed(2)
+    x, e = torch.rand(S, 50000, d, generator=gen).to(dev), torch.rand(S, 65000, d, generator=gen).to(dev)
+    ox, oe = layer(x, e)
+    assert layer.last_path == 'fused'
+    ox2, oe2 = layer(x, e)
+    assert torch.equal(ox, ox2) and torch.equal(oe, oe2)
+    for s in (0, 13, 31):
+        o1x, o1e = layer(x[s:s + 1].contiguous(), e[s:s + 1].contiguous())
+        assert torch.equal(o1x[0], ox[s]) and torch.equal(o1e[0], oe[s])
+    p = cast(layer.export_params(), torch.float64)
+    sel = [5, 30]
+    rx, re = OS.spatial_layer_csr(x[sel].double().cpu(), e[sel].double().cpu(), p, (g.adj.rowptr, g.adj.col), (g.edge_adj.rowptr, g.edge_adj.col),
+                                  (g.inc_n.rowptr, g.inc_n.col), (g.inc_e.rowptr, g.inc_e.col))
+    close(ox[sel], rx, TOL_BF16X3)
+    close(oe[sel], re, TOL_BF16X3)
+
+
 class _MailboxExchange(D.HaloExchange):
     """The exchange of `dist.HaloExchange` between rank THREADS of one process: the packed rows travel through queues with
     the event that marks them written, the receiver's current stream waits on it.  Same packing, same message order and the

@@ -491,3 +491,31 @@ def test_spatial_block_graphed_equals_eager(dev):
         assert torch.equal(ox, ex) and torch.equal(oe, ee)
         x.copy_(torch.rand(4, 600, 64, generator=g))          # new snapshots into the same buffers
         e.copy_(torch.rand(4, 720, 64, generator=g))
+
+
+@pytest.mark.parametrize('d', [64, 128])
+def test_small_network_snapshots_share_a_tile(dev, d):
+    """A 30-node network fills a quarter of a 128-row tile: with many snapshots the layer lays k = 4 of them side by side as
+    disjoint copies of the network (DrainageGraph.replicated; (S, N, F) -> (S / 4, 4 N, F) is a view).  S = 131 = 32 packed
+    groups + 3 left-over snapshots: against the fp64 oracle, and against the same layer with packing switched off."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'networks.json')) as fh:
+        net = json.load(fh)['astlingen']
+    g = U.DrainageGraph.from_edges(np.array(net['edges']), net['n_node'])
+    S = 131
+    layer = U.SpatialLayer(g, d, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(4)).to(dev)
+    assert layer.pack_factor() == 4
+    gen = torch.Generator().manual_seed(5)
+    x, e = torch.rand(S, g.n_node, d, generator=gen), torch.rand(S, g.n_edge, d, generator=gen)
+    ox, oe = layer(x.to(dev), e.to(dev))
+    assert layer.last_path == 'fused' and layer._rep[0] == 4
+    p = cast(layer.export_params(), torch.float64)
+    rx, re = OS.spatial_layer_csr(x.double(), e.double(), p, (g.adj.rowptr, g.adj.col), (g.edge_adj.rowptr, g.edge_adj.col),
+                                  (g.inc_n.rowptr, g.inc_n.col), (g.inc_e.rowptr, g.inc_e.col))
+    close(ox, rx, TOL_BF16X3)
+    close(oe, re, TOL_BF16X3)
+    layer.PACK_ROWS = 0                      # packing off: one snapshot per tile
+    px, pe = layer(x.to(dev), e.to(dev))
+    assert layer.pack_factor() == 1
+    assert float((px - ox).abs().max()) <= 4e-6 * max(1.0, float(rx.abs().max())) and float((pe - oe).abs().max()) <= 4e-6 * max(1.0, float(re.abs().max()))

@@ -432,6 +432,20 @@ def test_mpc_objective_and_gradient(dev, networks, chunks):
         from tests.util import OBSERVED
         OBSERVED.append((os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0] + ':gradient', 0, err, 2e-3 * gmax))
     assert err <= 2e-3 * gmax, 'gradient err %.3e vs max|grad| %.3e' % (err, gmax)
+    # Hessian-vector product (mpc.py:616-624): central difference of the HIP gradient against the SAME difference of the fp64
+    # oracle's gradient (the scheme is the definition here; the exact product differs from both by O(eps^2) away from kinks)
+    pvec = rnd(g, pop, n_step * n_act) - 0.5
+    eps = 1e-2 / float(pvec.abs().max())
+
+    def oracle_grad(yy):
+        yy = yy.clone().requires_grad_(True)
+        return torch.autograd.grad(OE.mpc_objective(args, params, norms, yy, state, runoff, edge_state, n_step, n_act, r_step, tg, gamma).sum(), yy)[0]
+    href = (oracle_grad(y + eps * pvec) - oracle_grad(y - eps * pvec)) / (2 * eps)
+    hp = M.hessp(emul, f(y), f(pvec), f(state), f(runoff), f(edge_state), n_step, n_act, r_step, tgd, f(gamma))
+    assert tuple(hp.shape) == tuple(y.shape)
+    herr = float((hp.double().cpu() - href).abs().max())
+    # the difference quotient divides the gradient's own error (<= 2e-3 gmax, measured ~2e-4) by 2 eps
+    assert herr <= 2e-3 * gmax / eps, 'hessp err %.3e vs max|Hp| %.3e (max|grad| %.3e, eps %.3e)' % (herr, float(href.abs().max()), gmax, eps)
 
 
 def test_c5_block_diagonal_batch_forward_backward(dev):
@@ -489,3 +503,43 @@ def test_c5_block_diagonal_batch_forward_backward(dev):
         sx, se = b1(x[:, n1 * k:n1 * (k + 1)].to(dev).contiguous(), e[:, e1 * k:e1 * (k + 1)].to(dev).contiguous())
     assert float((sx - ox[:, n1 * k:n1 * (k + 1)].detach()).abs().max()) <= 4e-5 * max(1.0, float(sx.abs().max()))
     assert float((se - oe[:, e1 * k:e1 * (k + 1)].detach()).abs().max()) <= 4e-5 * max(1.0, float(se.abs().max()))
+
+
+def test_c5_at_size_100_minigraphs_of_2000_nodes(dev):
+    """BASELINE.json config 5 at a tenth of its stated batch and its stated graph size: 100 mini-graphs x (2 000 nodes,
+    2 500 links) = 200 000 / 250 000 rows as ONE block-diagonal network, 3-layer block, training forward + backward.  The
+    oracle at that size is the fp64 sparse restatement with autograd on two SAMPLED mini-graphs: block-diagonal batching
+    means a mini-graph's outputs and input gradients are those of the graph run alone with its slice of the parameters."""
+    G, n1, e1, d, L = 100, 2000, 2500, 64, 3
+    nets = [U.synthetic_drainage_network(n1, e1, seed=k) for k in range(G)]
+    g = U.DrainageGraph.from_edges(np.concatenate([ed + n1 * k for k, ed in enumerate(nets)]), n1 * G)
+    block = U.SpatialBlock(g, d, L, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1)).to(dev)
+    block.requires_grad_(True)
+    gen = torch.Generator().manual_seed(2)
+    x, e = torch.rand(1, g.n_node, d, generator=gen), torch.rand(1, g.n_edge, d, generator=gen)
+    gx, ge = torch.rand(1, g.n_node, d, generator=gen) - 0.5, torch.rand(1, g.n_edge, d, generator=gen) - 0.5
+    xd, ed_ = x.to(dev).requires_grad_(True), e.to(dev).requires_grad_(True)
+    ox, oe = block(xd, ed_)
+    ((ox * gx.to(dev)).sum() + (oe * ge.to(dev)).sum()).backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in block.parameters())
+    csr = lambda c: (c.rowptr, c.col)
+    for k in (7, 93):
+        g1 = U.DrainageGraph.from_edges(nets[k], n1)
+        ns, es = slice(n1 * k, n1 * (k + 1)), slice(e1 * k, e1 * (k + 1))
+        sel = lambda c, lo, hi: torch.as_tensor(np.nonzero((c.rows() >= lo) & (c.rows() < hi))[0])
+        ps = []
+        for ly in block.layers:
+            p = {kk: (v.double() if v is not None else None) for kk, v in ly.export_params().items()}
+            p['ne_n_v'] = p['ne_n_v'][sel(g.inc_n, n1 * k, n1 * (k + 1))]
+            p['ne_e_v'] = p['ne_e_v'][sel(g.inc_e, e1 * k, e1 * (k + 1))]
+            ps.append(p)
+        rx, re = x[:, ns].double().requires_grad_(True), e[:, es].double().requires_grad_(True)
+        hx, he = rx, re
+        for p in ps:
+            hx, he = OS.spatial_layer_csr(hx, he, p, csr(g1.adj), csr(g1.edge_adj), csr(g1.inc_n), csr(g1.inc_e))
+        ((hx * gx[:, ns].double()).sum() + (he * ge[:, es].double()).sum()).backward()
+        close(ox[:, ns].detach(), hx.detach(), 4e-5)
+        close(oe[:, es].detach(), he.detach(), 4e-5)
+        for got, want in ((xd.grad[:, ns], rx.grad), (ed_.grad[:, es], re.grad)):
+            err = float((got.double().cpu() - want).abs().max())
+            assert err <= GRAD_TOL['GAT'] * float(want.abs().max()), (k, err, float(want.abs().max()))

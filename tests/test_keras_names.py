@@ -155,3 +155,22 @@ def test_keras_numbers_the_recurrent_cells_and_splits_diffusion_kernels(tmp_path
     d.load_keras_weights(split)
     for (n1, p1), (n2, p2) in zip(c.named_parameters(), d.named_parameters()):
         assert n1 == n2 and torch.equal(p1, p2), n1
+
+
+def test_from_node_gather_equals_the_dense_incidence_product():
+    """`v @ clip(node_edge, 0, 1)` (offset gate, rated pumps, pumped-storage depth: emulator.py:630-638,649,657,689,699) is a
+    gather at the from-nodes: the same numbers from the incidence CSR on all five shipped networks (chaohu has a parallel
+    link), so the gates also run for CSR-only networks, which have no dense (N, E) matrix to multiply by."""
+    from oracle import graphs as OG
+    with open(os.path.join(ROOT, 'tests', 'golden', 'networks.json')) as fh:
+        nets = json.load(fh)
+    for name, net in nets.items():
+        edges, n = np.array(net['edges']), net['n_node']
+        args = emulator_args(edges, n, n_sp_layer=1, n_tp_layer=1, edge_adj=np.eye(len(edges)))     # (the line graph is not needed here)
+        em = U.Emulator(args.conv, args.resnet, args.recurrent, args)
+        v = torch.rand(3, 2, n, generator=torch.Generator().manual_seed(1))
+        pos = torch.as_tensor(OG.node_edge_incidence(n, edges), dtype=torch.float32).clamp(0, 1)
+        assert torch.equal(em._at_from_node(v), torch.matmul(v, pos)), name
+        idx, ok = em._from_node_index(v.device)
+        pump = torch.rand(len(edges), generator=torch.Generator().manual_seed(2))
+        assert torch.allclose(torch.zeros(n).index_add_(0, idx, pump * ok), torch.mv(pos, pump), atol=1e-6), name

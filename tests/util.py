@@ -92,7 +92,9 @@ def emulator_args(edges, n_node, seed=0, **over):
     n_edge = len(edges)
     a = dict(state_shape=(n_node, 4), edge_state_shape=(n_edge, 4), seq_in=5, seq_out=5, embed_size=64, hidden_dim=64,
              kernel_size=3, n_sp_layer=2, n_tp_layer=2, activation='relu', if_flood=3, epsilon=-1.0, edge_fusion=True,
-             edges=edges, adj=OG.adjacency(edges), edge_adj=OG.edge_adjacency(edges), node_edge=OG.node_edge_incidence(n_node, edges),
+             edges=edges, adj=over['adj'] if 'adj' in over else OG.adjacency(edges),
+             edge_adj=over['edge_adj'] if 'edge_adj' in over else OG.edge_adjacency(edges),      # (networkx refuses chaohu's parallel link)
+             node_edge=OG.node_edge_incidence(n_node, edges),
              act=True, act_edges=edges[[1, 4]], conv='GAT', resnet=True, recurrent='Conv1D', roll=0, model_dir='/tmp/uds_model',
              is_outfall=(np.arange(n_node) == 0).astype(float), hmax=1.0 + rng.random(n_node), hmin=np.zeros(n_node),
              area=np.zeros(n_node), pump=np.zeros(n_edge), pump_in=np.zeros(n_node), pump_out=np.zeros(n_node),
