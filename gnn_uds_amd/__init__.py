@@ -15,5 +15,6 @@ from .emulator import GRU, LSTM, Conv1D, Emulator                     # noqa: F4
 from . import inp                                                     # noqa: F401,E402
 from .agent import ConvNet, GlobalAttnSumPool                         # noqa: F401,E402
 from . import mpc                                                     # noqa: F401,E402
+from . import mbrl                                                    # noqa: F401,E402
 
 __version__ = '0.1.0'

@@ -112,6 +112,32 @@ class DenseFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class RemainderFn(torch.autograd.Function):
+    """`rest @ xs`, rest (R, M) = a dense NodeEdge bias off the incidence support (emulator.py:36-39,44), xs (S, M, h): the two
+    N x E x (S h) products of a training step -- the forward and d xs = rest^T @ g -- run on the split-bf16 MFMA GEMM
+    (uds_remainder_forward, the kernel of the inference path).  d rest = sum_s g_s xs_s^T has the parameter's own (R, M) shape:
+    a plain library GEMM (it exists only for networks small enough to hold dense (R, M) parameters at all)."""
+
+    @staticmethod
+    def forward(ctx, rest, xs):
+        xs = xs.contiguous()
+        ctx.save_for_backward(rest, xs)
+        return _lib.remainder_forward(_lib.remainder_pack(rest.contiguous()), tuple(rest.shape), xs)
+
+    @staticmethod
+    def backward(ctx, g):
+        rest, xs = ctx.saved_tensors
+        g = g.contiguous()
+        dxs = drest = None
+        if ctx.needs_input_grad[1]:
+            rt = rest.t().contiguous()
+            dxs = _lib.remainder_forward(_lib.remainder_pack(rt), tuple(rt.shape), g)
+        if ctx.needs_input_grad[0]:
+            R, M = rest.shape
+            drest = torch.matmul(g.permute(1, 0, 2).reshape(R, -1), xs.permute(1, 0, 2).reshape(M, -1).t())
+        return drest, dxs
+
+
 class RecurrentFn(torch.autograd.Function):
     """The time recurrence of a 64-unit keras GRU / LSTM on the input projection xp (B, T, R, G*64): forward exact fp32
     (uds_recurrent_forward_train), backward = back-propagation through time in one launch on the matrix cores

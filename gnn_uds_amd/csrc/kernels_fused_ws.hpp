@@ -675,9 +675,11 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
     for (int k = 0; k <= n_snap; ++k) {
       const int s = s_begin + k;
       if (k + 1 < n_snap) {
-        // the rows of snapshot k + 1 were requested an interval ago; the only younger vector-memory operations of this wave
-        // are the output stores of the last interval's P3 (none in the first interval)
-        ws_vmcnt(k >= 1 ? n_st : 0);
+        // the rows of snapshot k + 1 were requested in interval k - 1, right after its P1; the only younger vector-memory
+        // operations of this wave are the output stores of THAT interval's P3 -- which exists from interval 1 on.  (k >= 1
+        // here was a race found by the C3-size repeatability test: interval 0 stores nothing, so in interval 1 vmcnt(n_st)
+        // let n_st of the sixteen row loads themselves stay in flight.)
+        ws_vmcnt(k >= 2 ? n_st : 0);
         pin_rows();
 #ifndef UDS_WS_ABL_NO_P1
         phase1((k + 1) & 1);

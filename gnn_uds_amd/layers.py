@@ -421,7 +421,11 @@ class NodeEdge(nn.Module):
                 if self.bias.requires_grad:
                     off = torch.ones_like(self.bias)
                     off.reshape(-1)[flat] = 0.0
-                    out = out + torch.matmul(self.bias * off, xs)
+                    rest = self.bias * off
+                    if self.precision == 'bf16x3' and xs.shape[-1] % 4 == 0 and xs.shape[-1] <= 64:
+                        out = out + _ag.RemainderFn.apply(rest, xs)      # the N x E x (S h) products on the HIP MFMA GEMM
+                    else:
+                        out = out + torch.matmul(rest, xs)
             return out.reshape(lead + out.shape[-2:])
         val, rest = self.support_values()
         out = _lib.csr_spmm(self.handle(), val, xs)

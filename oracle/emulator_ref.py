@@ -642,6 +642,31 @@ def model_rollout(args, params, norms, x, a, b, ex):
     return torch.cat(ys, dim=1).clamp(0, 1), torch.cat(eys, dim=1)                               # :437
 
 
+def mbrl_rollout(args, params, norms, policy, x, a, b, y, ex, n_step, r_step, node_attrs, link_attrs):
+    """`rollout` of mbrl.py:304-347 for a graph agent, restated step by step: observation (time sum of the cumulative / volume
+    channels, last step of the others, on normalised states) -> policy -> settings held r_step steps -> `predict` (predict_tf)
+    -> feedback with the flood bit thresholded at 0.5.  `policy(obs_list) -> (B, n_act)` is any function of the observation."""
+    c = config(args)
+    obs_of = lambda dat, attrs: torch.stack([dat[..., i].sum(dim=1) if ('cum' in at or '_vol' in at) else dat[:, -1, :, i]
+                                             for i, at in enumerate(attrs)], dim=-1)
+    xs, exs, settings, perfs = [x], [ex], [a[:, :c.seq_in]], [y[:, :c.seq_in, :, -1:]]
+    for i in range(n_step):
+        bi = b[:, i * r_step:(i + 1) * r_step]
+        obs = [obs_of(normalize(norms, x, 'x'), node_attrs), obs_of(normalize(norms, ex, 'e'), link_attrs)]
+        setting = policy(obs).unsqueeze(1).expand(-1, r_step, -1)
+        settings.append(setting)
+        preds, edge_preds = predict(args, params, norms, x, bi, setting, ex)
+        if c.if_flood:
+            x = torch.cat([preds[..., :-2], (preds[..., -2:-1] > 0.5).to(preds.dtype), bi], dim=-1)
+        else:
+            x = torch.cat([preds[..., :-1], bi], dim=-1)
+        ex = torch.cat([edge_preds, get_edge_action(c, setting)], dim=-1)
+        xs.append(x)
+        exs.append(ex)
+        perfs.append(preds[..., -1:])
+    return [torch.cat(t, dim=1) for t in (xs, exs, settings, perfs)]
+
+
 def convnet_forward(args, params, X, E, B=None):
     """`ConvNet.build_network` of the RL agents (agent.py:65-99): Dense embeddings, the spatial block, then Spektral's
     GlobalAttnSumPool (softmax over the stacked node + link rows of x @ attn_kernel, weighted sum) -> (batch, conv_dim).

@@ -509,11 +509,14 @@ def test_c5_at_size_100_minigraphs_of_2000_nodes(dev):
     """BASELINE.json config 5 at a tenth of its stated batch and its stated graph size: 100 mini-graphs x (2 000 nodes,
     2 500 links) = 200 000 / 250 000 rows as ONE block-diagonal network, 3-layer block, training forward + backward.  The
     oracle at that size is the fp64 sparse restatement with autograd on two SAMPLED mini-graphs: block-diagonal batching
-    means a mini-graph's outputs and input gradients are those of the graph run alone with its slice of the parameters."""
-    G, n1, e1, d, L = 100, 2000, 2500, 64, 3
+    means a mini-graph's outputs and input gradients are those of the graph run alone with its slice of the parameters.
+    Activation tanh: among the 38 M relu outputs of this batch a few lie within rounding of zero, where the fp32 and the fp64
+    masks differ and a gradient entry is off by a whole term (observed: 3.8e-6 on a largest gradient of 6.7e-4) -- a property
+    of the kink, not of the kernels (test_conv1d_backward makes the same choice at 6 M outputs)."""
+    G, n1, e1, d, L, ACT = 100, 2000, 2500, 64, 3, 'tanh'
     nets = [U.synthetic_drainage_network(n1, e1, seed=k) for k in range(G)]
     g = U.DrainageGraph.from_edges(np.concatenate([ed + n1 * k for k, ed in enumerate(nets)]), n1 * G)
-    block = U.SpatialBlock(g, d, L, 'relu', sparse_params=True, generator=torch.Generator().manual_seed(1)).to(dev)
+    block = U.SpatialBlock(g, d, L, ACT, sparse_params=True, generator=torch.Generator().manual_seed(1)).to(dev)
     block.requires_grad_(True)
     gen = torch.Generator().manual_seed(2)
     x, e = torch.rand(1, g.n_node, d, generator=gen), torch.rand(1, g.n_edge, d, generator=gen)
@@ -536,7 +539,7 @@ def test_c5_at_size_100_minigraphs_of_2000_nodes(dev):
         rx, re = x[:, ns].double().requires_grad_(True), e[:, es].double().requires_grad_(True)
         hx, he = rx, re
         for p in ps:
-            hx, he = OS.spatial_layer_csr(hx, he, p, csr(g1.adj), csr(g1.edge_adj), csr(g1.inc_n), csr(g1.inc_e))
+            hx, he = OS.spatial_layer_csr(hx, he, p, csr(g1.adj), csr(g1.edge_adj), csr(g1.inc_n), csr(g1.inc_e), act=ACT)
         ((hx * gx[:, ns].double()).sum() + (he * ge[:, es].double()).sum()).backward()
         close(ox[:, ns].detach(), hx.detach(), 4e-5)
         close(oe[:, es].detach(), he.detach(), 4e-5)
