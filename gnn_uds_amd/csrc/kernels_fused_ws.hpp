@@ -634,10 +634,14 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
           constexpr int K = WS_PRE + decltype(t_)::value * WS_SLOTS;
           if (more) {
             using IK = std::integral_constant<int, K>;
+#ifdef UDS_WS_P3_FLAT
+            step(IK{}, I4{});      // experiment: all four groups at every step (exhausted groups read row 0 with weight 0): no if-chain, a quarter of the code
+#else
             if (K < e3) step(IK{}, I4{});
             else if (K < e2) step(IK{}, I3{});
             else if (K < e1) step(IK{}, I2{});
             else step(IK{}, I1{});
+#endif
             more = e0 > K + WS_SLOTS;
           }
         });
