@@ -11,8 +11,12 @@ operator of the forward carries its own backward, so `loss.backward()` on an `Em
     FlowBalanceFn  post_proc_tf incidence sums     gather along the link end nodes
     SpatialLayerFn the fused spatial layer forward, backward through the unfused chain above (intermediates recomputed)
 
-Weight gradients are plain GEMMs with a huge reduction dimension (rows) and tiny outputs: they go to rocBLAS through
-`torch.mm` (a library GEMM, not a hot-path kernel).  Activations are differentiated from their outputs.
+    RecurrentFn    GRU / LSTM time recurrence     back-propagation through time in one launch (uds_recurrent_backward)
+    RemainderFn    dense off-support NodeEdge bias  forward and d x on the split-bf16 MFMA GEMM (uds_remainder_forward)
+
+Weight gradients are GEMMs with a huge reduction dimension (rows) and tiny outputs: the split-K MFMA kernel uds_wgrad
+(`weight_grad`; shapes it does not take fall back to a library GEMM through `torch.mm`).  Activations are differentiated
+from their outputs.
 """
 import torch
 

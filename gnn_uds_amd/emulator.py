@@ -16,7 +16,7 @@ Conv1D, the resnet prefix sum) and the link->node flow balance of post_proc_tf a
 The remaining post-processing is elementwise gating / clipping on tensors already in HBM and is written with torch
 tensor ops (device plumbing).  Training (`fit_eval`, GradNorm), `graph_base` 1 / 2, GCN and DiffusionConv are built.
 `use_adj` (per-time-step adjacency rewritten by the control action) is built for GAT as a mask over the CSR entries.
-GRU / LSTM temporal nets run (inference).  Not built, each raises: training-time dropout, `use_adj` with GCN / Diffusion or under autograd,
+GRU / LSTM temporal nets run (inference and, at 64 units, training).  Not built, each raises: training-time dropout, `use_adj` with GCN / Diffusion or under autograd,
 GeneralConv (a sparse-mode-only Spektral layer the reference's dense call cannot run either).  conv = False -- the reference's non-graph
 baseline, its shipped `*_nncat_*` models -- runs on the same Dense / temporal / cumsum kernels (`_forward_mlp`).
 """

@@ -338,8 +338,8 @@ class NodeEdge(nn.Module):
 
     `weight`, `bias` keep the reference's dense (R, M) shape by default.  The product is evaluated on
     the incidence support with the CSR kernel; a trained `bias` that is non-zero OFF the support makes
-    the matrix genuinely dense, and that remainder is added with one rocBLAS GEMM (the check is
-    re-done whenever the parameters change).  For networks where an (R, M) parameter cannot exist
+    the matrix genuinely dense, and that remainder is added by the hand-written split-bf16 MFMA GEMM
+    (`remainder`: uds_remainder_forward; the check is re-done whenever the parameters change).  For networks where an (R, M) parameter cannot exist
     (N = 50k: 13 GB each) pass sparse=True: parameters then have one entry per support element
     (columns ascending inside a row)."""
 
