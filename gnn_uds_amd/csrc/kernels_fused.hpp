@@ -51,6 +51,7 @@ struct FusedSide {
   const float *prim_in2, *sec_in2;
   float *out;
   const uint4 *w_small, *w_big;   // packed bf16 hi/lo fragments (k_pack_weight_frags)
+  const uint4 *w_big32, *w_small32;      // both kernels as 32x32x16 A-operand fragments (k_pack_weight_frags32): k_fused_ws only, else NULL
   const float *b_small, *a_self, *a_nbr, *b_out, *ne_val;
   int n_prim_glob, n_sec_glob;
 };
@@ -79,6 +80,26 @@ __global__ void k_pack_weight_frags(const float *__restrict__ W, int K, int F_ou
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) {
     const float w = W[(int64_t)frag_k(t, qd, jj) * F_out + f];
+    const __bf16 h = (__bf16)w;
+    hi[jj] = h;
+    lo[jj] = (__bf16)(w - (float)h);
+  }
+  out[((t * MB + m) * 2 + 0) * 64 + lane] = __builtin_bit_cast(uint4, hi);
+  out[((t * MB + m) * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
+}
+
+// The same for v_mfma_f32_32x32x16_bf16 (lane l: r = l & 31, hf = l >> 5 holds A[row r][k = 8 hf + j]): W (K x F_out, K % 16 == 0,
+// F_out % 32 == 0) -> out[((t*MB + m)*2 + hl)*64 + lane] = 8 bf16 {W[16 t + 8 hf + jj][32 m + r]}, MB = F_out / 32.
+__global__ void k_pack_weight_frags32(const float *__restrict__ W, int K, int F_out, uint4 *__restrict__ out) {
+  const int MB = F_out / 32, KT = K / 16;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= KT * MB * 64) return;
+  const int lane = idx & 63, m = (idx >> 6) % MB, t = (idx >> 6) / MB;
+  const int hf = lane >> 5, f = 32 * m + (lane & 31);
+  bf16x8 hi, lo;
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {
+    const float w = W[(int64_t)(16 * t + 8 * hf + jj) * F_out + f];
     const __bf16 h = (__bf16)w;
     hi[jj] = h;
     lo[jj] = (__bf16)(w - (float)h);

@@ -176,6 +176,139 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
   // The two teams run two separate loops (the same number of barriers in each): what a team keeps in registers across the
   // snapshots -- the big weights here, the small weights, rows in flight and P3 state there -- is live in its own loop only.
   if (team_y) {
+#ifndef UDS_WS_MFMA16
+    // =========================== Y team: P2 on v_mfma_f32_32x32x16_bf16 ===========================
+    // One 32-row block per wave (rows 32 yw ..).  Same flops per cycle as the 16x16x32 form, but an MFMA holds its SIMD's
+    // vector issue for 8 of its 32 cycles instead of 8 of 16 (MI355X_MICROARCH.md): the X wave on this SIMD -- the long
+    // instruction stream of the kernel -- loses half as many issue slots to this wave's matrix work.  Lane l: n = l & 31 is
+    // the row, hf = l >> 5 the k half: B fragment of k-step t = floats 16 t + 8 hf .. + 7 of the row; the accumulators hold
+    // features (r & 3) + 8 (r >> 2) + 4 hf (+ 32 m) of row n (cdna_hip_programming.md section 3).
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr int KT32 = (FP + FUSED_H) / 16, KX32 = FP / 16, MB32 = FUSED_D / 32;      // 6 k-steps (4 of x, 2 of agg), 2 feature blocks
+    static_assert(NY == 4, "one 32-row block per Y wave: four waves cover p_cap = 128");
+    const int n32 = lane & 31, hf = lane >> 5;
+    bf16x8 wh[KT32][MB32], wl[KT32][MB32];       // 96 VGPRs, resident across the snapshot loop
+#pragma unroll
+    for (int t = 0; t < KT32; ++t)
+#pragma unroll
+      for (int m = 0; m < MB32; ++m) {
+        wh[t][m] = __builtin_bit_cast(bf16x8, S_.w_big32[((t * MB32 + m) * 2 + 0) * 64 + lane]);
+        wl[t][m] = __builtin_bit_cast(bf16x8, S_.w_big32[((t * MB32 + m) * 2 + 1) * 64 + lane]);
+      }
+    const int lrow = 32 * yw + n32;
+    const bool valid = lrow < n_prim;
+    const int lr = min(lrow, n_prim - 1);
+    const unsigned prow = (unsigned)prim_ids[lr] * FP + 8u * hf;      // element offset of this lane's 8-float piece of k-step 0
+    f32x4 pp[2 * KX32];           // the primary row of the snapshot P2 multiplies next: piece i = floats 16 (i >> 1) + 8 hf + 4 (i & 1)
+    const unsigned ag_locs = inc_loc[lr];
+    const f32x4 ag_vals = inc_val4[lr];
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): drain the set-up loads on every path (see the X team's note)
+    if (n_snap > 0) {
+      const float *base = S_.prim_in + s_begin * prim_stride;
+      static_for<2 * KX32>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        pp[i] = *reinterpret_cast<const f32x4 *>(base + prow + 16 * (i >> 1) + 4 * (i & 1));
+      });
+    }
+    WS_STAMP(0);
+    lds_barrier();      // the X team has computed the secondary MLP of the first snapshot
+
+    auto mfma3_32 = [&](const bf16x8 &a_h, const bf16x8 &a_l, const bf16x8 &d_h, const bf16x8 &d_l, f32x16 acc) __attribute__((always_inline)) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, d_l, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, d_h, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, d_h, acc, 0, 0, 0);
+      return acc;
+    };
+    for (int k = 0; k <= n_snap; ++k) {
+#ifdef UDS_WS_ABL_NO_P2
+      if (false) {
+#else
+      if (k < n_snap && 32 * yw < n_prim) {
+#endif
+        const bool more = k + 1 < n_snap;
+        const float *next = S_.prim_in + (s_begin + k + 1) * prim_stride;
+        const float *secr = sec + (k & 1) * sec_buf;
+        float *hxw = hx + (k & 1) * hx_buf;
+        float *ssw = s_self + (k & 1) * a.p_cap, *snw = s_nbr + (k & 1) * a.p_cap;
+        bf16x8 dh[KT32], dl[KT32];
+        static_for<KX32>([&](auto t_) {
+          constexpr int t = decltype(t_)::value;
+          const f32x4 u0 = pp[2 * t], u1 = pp[2 * t + 1];
+          split8(make_float4(u0[0], u0[1], u0[2], u0[3]), make_float4(u1[0], u1[1], u1[2], u1[3]), dh[t], dl[t]);
+        });
+        if (more)      // the registers are free: the next snapshot's row, a whole interval ahead
+          static_for<2 * KX32>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            pp[i] = *reinterpret_cast<const f32x4 *>(next + prow + 16 * (i >> 1) + 4 * (i & 1));
+          });
+        f32x16 acc[MB32];
+#pragma unroll
+        for (int m = 0; m < MB32; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < KX32; ++t)
+#pragma unroll
+          for (int m = 0; m < MB32; ++m) acc[m] = mfma3_32(wh[t][m], wl[t][m], dh[t], dl[t], acc[m]);
+        // NodeEdge aggregate of this row in fragment shape: features 8 hf .. + 7 (k-step 4) and 16 + 8 hf .. + 7 (k-step 5)
+        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0, g3 = g0;
+        auto fma4 = [&](float4 &g, float wv, const float4 &u) { g.x = fmaf(wv, u.x, g.x); g.y = fmaf(wv, u.y, g.y); g.z = fmaf(wv, u.z, g.z); g.w = fmaf(wv, u.w, g.w); };
+        auto add_row = [&](unsigned la, float wa) {
+          const float *ra = secr + la * SEC_STRIDE + 8 * hf;
+          const float4 u0 = *reinterpret_cast<const float4 *>(ra), u1 = *reinterpret_cast<const float4 *>(ra + 4);
+          const float4 u2 = *reinterpret_cast<const float4 *>(ra + 16), u3 = *reinterpret_cast<const float4 *>(ra + 20);
+          fma4(g0, wa, u0); fma4(g1, wa, u1); fma4(g2, wa, u2); fma4(g3, wa, u3);
+        };
+        add_row(ag_locs & 0xffu, ag_vals[0]);
+        add_row((ag_locs >> 8) & 0xffu, ag_vals[1]);
+        if (inc_width > 2) {
+          add_row((ag_locs >> 16) & 0xffu, ag_vals[2]);
+          add_row(ag_locs >> 24, ag_vals[3]);
+        }
+        if (flags & ELL_FLAG_INC_OVF)      // rows with more than four incident rows
+          for (int p = ovf_ptr[lr]; p < ovf_ptr[lr + 1]; ++p) add_row((unsigned)ovf_loc[p], ovf_val[p]);
+        split8(g0, g1, dh[KX32], dl[KX32]);
+        split8(g2, g3, dh[KX32 + 1], dl[KX32 + 1]);
+#pragma unroll
+        for (int t = KX32; t < KT32; ++t)
+#pragma unroll
+          for (int m = 0; m < MB32; ++m) acc[m] = mfma3_32(wh[t][m], wl[t][m], dh[t], dl[t], acc[m]);
+        // attention scalars: this lane holds 32 of the row's 64 features, lane l ^ 32 the others
+        float ps = 0.f, pn = 0.f;
+#pragma unroll
+        for (int m = 0; m < MB32; ++m)
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 as4 = *reinterpret_cast<const f32x4 *>(attn + 32 * m + 8 * gq + 4 * hf);
+            const f32x4 an4 = *reinterpret_cast<const f32x4 *>(attn + FUSED_D + 32 * m + 8 * gq + 4 * hf);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              ps = fmaf(acc[m][4 * gq + q], as4[q], ps);
+              pn = fmaf(acc[m][4 * gq + q], an4[q], pn);
+            }
+          }
+        ps += __shfl_xor(ps, 32);
+        pn += __shfl_xor(pn, 32);
+        if (valid) {
+          if (hf == 0) {
+            ssw[lrow] = ps;
+            snw[lrow] = pn;
+          }
+#pragma unroll
+          for (int m = 0; m < MB32; ++m)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {      // 16-byte chunk 8 m + 2 gq + hf of the row, XOR (row & 7): as the 16x16x32 form writes it
+              const f32x4 o = {acc[m][4 * gq], acc[m][4 * gq + 1], acc[m][4 * gq + 2], acc[m][4 * gq + 3]};
+              *reinterpret_cast<f32x4 *>(hxw + lrow * FUSED_D + (((8 * m + 2 * gq + hf) ^ (lrow & 7)) << 2)) = o;
+            }
+        }
+      }
+      WS_STAMP(1);
+      lds_barrier();      // hx / scores of snapshot k are in LDS (and the X team's sec rows of snapshot k + 1)
+      WS_STAMP(2);
+    }
+    WS_DUMP();
+#else
     // =========================== Y team: P2 ===========================
     bf16x8 wbh[KT_B][MB_B], wbl[KT_B][MB_B];      // 96 VGPRs, resident across the snapshot loop
 #pragma unroll
@@ -409,11 +542,43 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
       WS_STAMP(2);
     }
     WS_DUMP();
+#endif
   } else {
     // =========================== X team: P1 and P3 ===========================
 #ifndef UDS_WS_NO_PRIO
     __builtin_amdgcn_s_setprio(1);      // the longer instruction stream of the two, and the younger half of the workgroup (-2 %)
 #endif
+#ifndef UDS_WS_MFMA16
+    // P1 on v_mfma_f32_32x32x16_bf16 too: half as many matrix instructions in this team's (issue-bound) stream.  32-row blocks
+    // blk = xw + NX j; lane l: n = l & 31 the row, hf = l >> 5: piece i of the row = floats 16 (i >> 1) + 8 hf + 4 (i & 1).
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr int KS32 = FS / 16, SJ32 = (8 + NX - 1) / NX;      // 4 k-steps; 32-row secondary blocks per X wave (q_cap <= 256)
+    const int n32 = lane & 31, hf = lane >> 5;
+    bf16x8 w1h[KS32], w1l[KS32];      // 32 VGPRs
+#pragma unroll
+    for (int t = 0; t < KS32; ++t) {
+      w1h[t] = __builtin_bit_cast(bf16x8, S_.w_small32[(t * 2 + 0) * 64 + lane]);
+      w1l[t] = __builtin_bit_cast(bf16x8, S_.w_small32[(t * 2 + 1) * 64 + lane]);
+    }
+    unsigned srow[SJ32];              // BYTE offsets of this lane's rows
+#pragma unroll
+    for (int j = 0; j < SJ32; ++j) srow[j] = ((unsigned)sec_ids[min((xw + NX * j) * 32 + n32, n_sec - 1)] * FS + 8u * hf) * 4u;
+    f32x4 sp[SJ32][2 * KS32];         // the secondary rows of the snapshot P1 multiplies next (asm loads: see the header)
+    auto load_sec = [&](int s) __attribute__((always_inline)) {      // unconditional (rows are clamped): a fixed number of loads
+      const float *base = S_.sec_in + s * sec_stride;
+      static_for<SJ32>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        ws_gld16<0>(sp[j][0], base, srow[j]);
+        ws_gld16<16>(sp[j][1], base, srow[j]);
+        ws_gld16<64>(sp[j][2], base, srow[j]);
+        ws_gld16<80>(sp[j][3], base, srow[j]);
+        ws_gld16<128>(sp[j][4], base, srow[j]);
+        ws_gld16<144>(sp[j][5], base, srow[j]);
+        ws_gld16<192>(sp[j][6], base, srow[j]);
+        ws_gld16<208>(sp[j][7], base, srow[j]);
+      });
+    };
+#else
     bf16x8 wsh[KT_S][MB_S], wsl[KT_S][MB_S];      // 32 VGPRs
 #pragma unroll
     for (int t = 0; t < KT_S; ++t)
@@ -437,6 +602,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
         ws_gld16<192>(sp[j][3], base, srow[j]);
       });
     };
+#endif
     // P3 rows: degree-sorted inside the tile and dealt in 4-row groups: trip t (0, 1), unit u (0..3) -> group NX (2 u + t) + xw,
     // so both trips and all waves get the same mix of degrees, in descending order.  Static per tile: the (wave-uniform)
     // largest degree of every group in SGPRs, this lane's neighbour byte of every group in VGPRs.
@@ -474,6 +640,51 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
     if (S_.b_out) bo = *reinterpret_cast<const f32x4 *>(S_.b_out + 4 * c16);
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): drain the set-up loads on every path (see the Y team's note)
 
+#ifndef UDS_WS_MFMA16
+    // ---------------- P1: secondary MLP, registers -> MFMA (32x32x16) -> sec ----------------
+    auto phase1 = [&](int buf) __attribute__((always_inline)) {
+      float *secw = sec + buf * sec_buf;
+      static_for<SJ32>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        const int blk = xw + NX * j;
+        if (blk * 32 < n_sec) {
+          f32x16 acc;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {      // bias of this lane's features (r & 3) + 8 (r >> 2) + 4 hf
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(attn + 2 * FUSED_D + 8 * gq + 4 * hf);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[4 * gq + q] = b4[q];
+          }
+          static_for<KS32>([&](auto t_) {
+            constexpr int t = decltype(t_)::value;
+            const f32x4 u0 = sp[j][2 * t], u1 = sp[j][2 * t + 1];
+            bf16x8 dh, dl;
+            split8(make_float4(u0[0], u0[1], u0[2], u0[3]), make_float4(u1[0], u1[1], u1[2], u1[3]), dh, dl);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h[t], dl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1l[t], dh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h[t], dh, acc, 0, 0, 0);
+          });
+          const int lrow = blk * 32 + n32;
+          if (lrow < n_sec) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+              f32x4 o;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o[q] = fused_act<ACT>(acc[4 * gq + q], a.act);
+              *reinterpret_cast<f32x4 *>(secw + lrow * SEC_STRIDE + 8 * gq + 4 * hf) = o;
+            }
+          }
+        }
+      });
+    };
+    auto pin_rows = [&]() __attribute__((always_inline)) {
+      static_for<SJ32>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        ws_pin4(sp[j][0], sp[j][1], sp[j][2], sp[j][3]);
+        ws_pin4(sp[j][4], sp[j][5], sp[j][6], sp[j][7]);
+      });
+    };
+#else
     // ---------------- P1: secondary MLP, registers -> MFMA -> sec ----------------
     auto phase1 = [&](int buf) __attribute__((always_inline)) {
       float *secw = sec + buf * sec_buf;
@@ -514,6 +725,8 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
         ws_pin4(sp[j][0], sp[j][1], sp[j][2], sp[j][3]);
       });
     };
+
+#endif
 
     // first snapshot: rows -> registers -> P1 -> sec[0]; the second snapshot's rows into the registers
     if (n_snap > 0) {

@@ -93,6 +93,8 @@ struct uds_network {
 namespace {
 
 constexpr int64_t FUSED_LDS_BUDGET = 160 * 1024;   // one 8-wave workgroup per CU owns the whole 160 KiB LDS
+constexpr int WS_BIG32_OFF = 2 * (768 + 2048), WS_BIG32_LEN = 6 * 2 * 2 * 64;      // uint4: behind the four 16x16x32-order kernels of a d = 64 layer
+constexpr int WS_SMALL32_OFF = WS_BIG32_OFF + 2 * WS_BIG32_LEN, WS_SMALL32_LEN = 4 * 1 * 2 * 64;
 constexpr int64_t PACKED_WEIGHT_FLOATS = 2 * (2048 + 6144) * 4;   // both sides at d = 128 (128->64 and 192->128 kernels): uint4 = 4 floats
 
 inline int slot_index(int fp, int fs) {
@@ -996,6 +998,15 @@ int uds_spatial_pack_weights(const uds_spatial_params_t *p, int64_t fx, int64_t 
       (he = pack_weights(p->ex_k, (int)fx, (int)h, wq + o_small + o_big, st)) != hipSuccess ||
       (he = pack_weights(p->ge_k, (int)(fe + h), (int)d, wq + 2 * o_small + o_big, st)) != hipSuccess)
     return fail(UDS_EHIP, "uds_spatial_pack_weights: launch -> %s", hipGetErrorString(he));
+  if (!wide && fx == 64 && fe == 64) {      // the wave-specialised kernel's P2 multiplies with 32x32x16 MFMAs: the big kernels in that fragment order too
+    const int total = (int)((fx + h) / 16) * (int)(d / 32) * 64;
+    hipLaunchKernelGGL(uds::k_pack_weight_frags32, dim3((total + 255) / 256), dim3(256), 0, st, p->gx_k, (int)(fx + h), (int)d, wq + WS_BIG32_OFF);
+    hipLaunchKernelGGL(uds::k_pack_weight_frags32, dim3((total + 255) / 256), dim3(256), 0, st, p->ge_k, (int)(fe + h), (int)d, wq + WS_BIG32_OFF + WS_BIG32_LEN);
+    const int ts = (int)(fe / 16) * (int)(h / 32) * 64;
+    hipLaunchKernelGGL(uds::k_pack_weight_frags32, dim3((ts + 255) / 256), dim3(256), 0, st, p->xe_k, (int)fe, (int)h, wq + WS_SMALL32_OFF);
+    hipLaunchKernelGGL(uds::k_pack_weight_frags32, dim3((ts + 255) / 256), dim3(256), 0, st, p->ex_k, (int)fx, (int)h, wq + WS_SMALL32_OFF + WS_SMALL32_LEN);
+    if ((he = hipGetLastError()) != hipSuccess) return fail(UDS_EHIP, "uds_spatial_pack_weights: launch -> %s", hipGetErrorString(he));
+  }
   return UDS_OK;
 }
 
@@ -1046,8 +1057,8 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
     }
     uds::FusedArgs a;
     a.blocks = nullptr;
-    a.side[0] = uds::FusedSide{x, e, nullptr, nullptr, out_x, wq, wq + 2048, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
-    a.side[1] = uds::FusedSide{e, x, nullptr, nullptr, out_e, wq + 8192, wq + 10240, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};
+    a.side[0] = uds::FusedSide{x, e, nullptr, nullptr, out_x, wq, wq + 2048, nullptr, nullptr, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
+    a.side[1] = uds::FusedSide{e, x, nullptr, nullptr, out_e, wq + 8192, wq + 10240, nullptr, nullptr, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};
     a.S = (int)S;
     a.act = act;
     a.dbg = nullptr;
@@ -1113,8 +1124,9 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
     const uint4 *w_small_n = wq, *w_big_n = wq + 768, *w_small_e = wq + 768 + 2048, *w_big_e = wq + 2 * 768 + 2048;
     uds::FusedArgs a;
     a.blocks = nullptr;
-    a.side[0] = uds::FusedSide{x, e, xb, eb, out_x, w_small_n, w_big_n, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
-    a.side[1] = uds::FusedSide{e, x, eb, xb, out_e, w_small_e, w_big_e, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};
+    const bool has32 = fx == 64 && fe == 64;
+    a.side[0] = uds::FusedSide{x, e, xb, eb, out_x, w_small_n, w_big_n, has32 ? wq + WS_BIG32_OFF : nullptr, has32 ? wq + WS_SMALL32_OFF : nullptr, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
+    a.side[1] = uds::FusedSide{e, x, eb, xb, out_e, w_small_e, w_big_e, has32 ? wq + WS_BIG32_OFF + WS_BIG32_LEN : nullptr, has32 ? wq + WS_SMALL32_OFF + WS_SMALL32_LEN : nullptr, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};
     int64_t lds_need = 0;
     auto use_plan = [&](const uds_plan_slot &u, int side) {     // side < 0: both sides (merged tile list), else that side's tiles only
       a.hdr = side < 0 ? u.d_hdr : u.d_hdr_side[side];
