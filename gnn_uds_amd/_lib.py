@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # UDS_LIB_PATH: a differently built copy of the same library (kernel experiments: tools/variant_bench.py)
 LIB_PATH = os.environ.get('UDS_LIB_PATH') or os.path.join(_HERE, 'libuds_hip.so')
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
 PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
 
@@ -42,6 +42,7 @@ SYMBOLS = {
     'uds_recurrent_fused': (_c_int, [_c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_recurrent_fused_supported': (_c_int, [_c_i64, _c_int]),
     'uds_recurrent_forward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
+    'uds_attn_sum_pool': (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr]),
     'uds_recurrent_forward_train': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr]),
     'uds_recurrent_backward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr]),
     'uds_rowgemm_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
@@ -381,6 +382,19 @@ def recurrent_fused(x, packed, b_in, b_rec, kind, projected=False):
     if out.numel():
         _check(lib.uds_recurrent_fused(_dev(x, 'x'), 0 if projected else F, packed.data_ptr(), _dev(b_in, 'b_in', True), _dev(b_rec, 'b_rec', True),
                                        B, T, R, 0 if kind == 'GRU' else 1, _dev(out, 'out'), _stream()), 'uds_recurrent_fused')
+    return out
+
+
+def attn_sum_pool(x, attn_kernel):
+    """GlobalAttnSumPool: x (B, R, F), attn_kernel (F,) or (F, 1) -> (B, F) (uds_attn_sum_pool)."""
+    lib = load()
+    B, R, F = x.shape
+    k = attn_kernel.reshape(-1).contiguous()
+    if k.numel() != F:
+        raise UdsError('attn_sum_pool: x %r, attn_kernel %r' % (tuple(x.shape), tuple(attn_kernel.shape)))
+    out = torch.empty((B, F), device=x.device, dtype=torch.float32)
+    if B:
+        _check(lib.uds_attn_sum_pool(_dev(x, 'x'), _dev(k, 'attn_kernel'), B, R, F, _dev(out, 'out'), _stream()), 'uds_attn_sum_pool')
     return out
 
 

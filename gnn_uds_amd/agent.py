@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from . import autograd as _ag
 from .graph import DrainageGraph, csr_from_dense
 from .layers import Dense, GraphBaseBlock, SpatialBlock, _glorot_uniform, _param
 
@@ -27,7 +28,10 @@ class GlobalAttnSumPool(nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             raise _lib.UdsError('GlobalAttnSumPool input is on %s: gnn_uds_amd runs on the MI355X only' % x.device)
-        alpha = torch.softmax(torch.matmul(x, self.attn_kernel).squeeze(-1), dim=-1)      # (B, N)
+        F = x.shape[-1]
+        if x.dim() == 3 and F >= 4 and F <= 256 and (F & (F - 1)) == 0 and not _ag.grad_on(x, self.attn_kernel):
+            return _lib.attn_sum_pool(x.contiguous(), self.attn_kernel)                   # one HIP launch, one pass over the rows
+        alpha = torch.softmax(torch.matmul(x, self.attn_kernel).squeeze(-1), dim=-1)      # (B, N): differentiable form (RL training)
         return torch.matmul(alpha.unsqueeze(-2), x).squeeze(-2)                          # (B, F)
 
 

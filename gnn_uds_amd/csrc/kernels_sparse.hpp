@@ -572,4 +572,56 @@ inline hipError_t launch_diffusion(const DiffusionArgs &a, int S, hipStream_t st
   return hipGetLastError();
 }
 
+// spektral GlobalAttnSumPool in batch mode (agent.py:93-94: the head of the RL agents' ConvNet): per sample b,
+//     alpha = softmax_r(<x[b, r, :], k>),  out[b, :] = sum_r alpha_r x[b, r, :]
+// One 256-thread workgroup per sample, one pass over its rows with an online (running-max) softmax: thread (c, part) owns float4
+// chunk c of every row it visits (F <= 256), the 64 lanes of a wave visit 64 / (F/4) rows per step; the score of a row is a
+// shuffle reduction over its F/4 lanes.  Partial (max, sum, weighted row) triples are merged through LDS at the end.
+struct AttnPoolArgs {
+  const float *x, *k;
+  float *out;
+  int R, F4;          // rows per sample, float4 chunks per row (a power of two <= 64)
+};
+
+__global__ __launch_bounds__(256) void k_attn_sum_pool(AttnPoolArgs a) {
+  __shared__ float s_m[256], s_l[256];
+  __shared__ float4 s_acc[256];
+  const int tid = threadIdx.x, c = tid % a.F4, part = tid / a.F4, n_part = 256 / a.F4;
+  const float4 *xb = reinterpret_cast<const float4 *>(a.x) + (int64_t)blockIdx.x * a.R * a.F4;
+  const float4 kc = reinterpret_cast<const float4 *>(a.k)[c];
+  float m = -INFINITY, l = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r0 = 0; r0 < a.R; r0 += n_part) {          // every thread of the workgroup runs the same number of steps (shuffles below)
+    const int r = r0 + part;
+    const bool live = r < a.R;
+    const float4 v = live ? xb[(int64_t)r * a.F4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float sc = v.x * kc.x + v.y * kc.y + v.z * kc.z + v.w * kc.w;
+    for (int o = a.F4 >> 1; o > 0; o >>= 1) sc += __shfl_xor(sc, o);      // the F4 lanes of a row are consecutive and aligned
+    if (live) {
+      const float mn = fmaxf(m, sc), f_old = __expf(m - mn), w = __expf(sc - mn);
+      l = l * f_old + w;
+      acc.x = acc.x * f_old + w * v.x; acc.y = acc.y * f_old + w * v.y; acc.z = acc.z * f_old + w * v.z; acc.w = acc.w * f_old + w * v.w;
+      m = mn;
+    }
+  }
+  s_m[tid] = m; s_l[tid] = l; s_acc[tid] = acc;
+  __syncthreads();
+  if (part == 0) {                                      // chunk c: merge the n_part partial triples in a fixed order (reproducible)
+    float M = -INFINITY;
+    for (int p = 0; p < n_part; ++p) M = fmaxf(M, s_m[p * a.F4 + c]);
+    float L = 0.f;
+    float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < n_part; ++p) {
+      const int q = p * a.F4 + c;
+      if (s_l[q] > 0.f) {
+        const float f = __expf(s_m[q] - M);
+        L += s_l[q] * f;
+        A.x += s_acc[q].x * f; A.y += s_acc[q].y * f; A.z += s_acc[q].z * f; A.w += s_acc[q].w * f;
+      }
+    }
+    const float inv = 1.0f / L;
+    reinterpret_cast<float4 *>(a.out)[(int64_t)blockIdx.x * a.F4 + c] = make_float4(A.x * inv, A.y * inv, A.z * inv, A.w * inv);
+  }
+}
+
 }  // namespace uds

@@ -111,7 +111,11 @@ bool plan_network(const uds::HostCsr &adj, const uds::HostCsr &eadj, const uds::
   const int cand[][2] = {{128, 208}, {128, 192}, {128, 176}, {128, 160}, {128, 144}, {112, 160}, {112, 144}, {96, 144}, {96, 128},
                          {80, 128}, {64, 96}, {48, 64}, {32, 48}, {16, 32}};
   for (const auto &c : cand) {
-    const int p_lim = c[0], q_lim = c[1];
+    int p_lim = c[0], q_lim = c[1];
+#ifdef UDS_KNOBS
+    if (const char *ov = std::getenv("UDS_PLIM")) p_lim = std::min(p_lim, std::atoi(ov));      // experiment builds: smaller tiles
+    if (const char *ov = std::getenv("UDS_QLIM")) q_lim = std::min(q_lim, std::atoi(ov));
+#endif
     if (uds::fused_lds_bytes(p_lim, q_lim, 0, uds::FUSED_H, uds::FUSED_D, fp, fs) > FUSED_LDS_BUDGET) continue;
     const int t = std::min(p_lim, 4 * uds::FUSED_WAVES * uds::FUSED_U);        // own rows: P3 covers a tile in one trip
     out = uds::build_network_plan(adj, eadj, inc_n, inc_e, t, t, p_lim, q_lim);
@@ -578,6 +582,20 @@ int uds_cumsum_act(const float *x, const float *res, int64_t B, int64_t T, int64
   uds::CumsumArgs a{x, res, out, (int)B, (int)T, (int)R, (int)(F / 4), act};
   hipError_t e = uds::launch_cumsum(a, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(UDS_EHIP, "uds_cumsum_act: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
+int uds_attn_sum_pool(const float *x, const float *k, int64_t B, int64_t R, int64_t F, float *out, uds_stream_t stream) {
+  UDS_REQUIRE(x && k && out, "uds_attn_sum_pool: NULL argument");
+  UDS_REQUIRE(B >= 0 && R > 0 && F >= 4 && F <= 256 && (F & (F - 1)) == 0, "uds_attn_sum_pool: B=%lld R=%lld F=%lld (F a power of two, 4 .. 256)",
+              (long long)B, (long long)R, (long long)F);
+  UDS_REQUIRE(aligned16(x) && aligned16(k) && aligned16(out), "uds_attn_sum_pool: x/k/out must be 16-byte aligned");
+  UDS_REQUIRE(B < INT32_MAX && R < INT32_MAX, "uds_attn_sum_pool: too many rows");
+  if (B == 0) return UDS_OK;
+  uds::AttnPoolArgs a{x, k, out, (int)R, (int)(F / 4)};
+  hipLaunchKernelGGL(uds::k_attn_sum_pool, dim3((unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_attn_sum_pool: launch -> %s", hipGetErrorString(e));
   return UDS_OK;
 }
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 16
+#define UDS_ABI_VERSION 17
 
 enum {
   UDS_OK = 0,
@@ -219,6 +219,11 @@ int uds_dense_cumsum_heads(const float *x, int64_t B, int64_t T, int64_t R, cons
  * The resnet head of the emulator.                                          emulator.py:313-320 */
 int uds_cumsum_act(const float *x, const float *res, int64_t B, int64_t T, int64_t R, int64_t F, int act,
                    float *out, uds_stream_t stream);
+
+/* spektral GlobalAttnSumPool in batch mode, the head of the RL agents' graph encoder (agent.py:93-94, `ConvNet`):
+ * out[b, :] = sum_r softmax_r(<x[b, r, :], k>) x[b, r, :] for x (B, R, F), k (F), F a power of two up to 256.  One pass over the
+ * rows (online softmax), fixed merge order: bitwise reproducible. */
+int uds_attn_sum_pool(const float *x, const float *k, int64_t B, int64_t R, int64_t F, float *out, uds_stream_t stream);
 
 /* Link -> node flow balance of post_proc_tf: inc_n is the (N x E) incidence support, sign (nnz) its +1 / -1 values,
  * flow (S,E) the signed link flows; q_in, q_out (S,N) are scaled per node by scale_in / scale_out (N).

@@ -605,6 +605,18 @@ def test_graph_captured_rollout_equals_the_eager_loop(dev, networks):
         emul.drop_graph()
 
 
+@pytest.mark.parametrize('B,R,F', [(5, 59, 128), (3, 1000, 64), (2, 7, 8), (1, 257, 256)])
+def test_attn_sum_pool_kernel(dev, B, R, F):
+    """uds_attn_sum_pool (spektral GlobalAttnSumPool, agent.py:93-94) against the two-pass formula in fp64; repeatable."""
+    g = torch.Generator().manual_seed(B + R)
+    x, k = rnd(g, B, R, F) * 4 - 2, rnd(g, F, 1) - 0.5
+    alpha = torch.softmax((x @ k).squeeze(-1), dim=-1)
+    ref = (alpha.unsqueeze(-2) @ x).squeeze(-2)
+    out = _lib.attn_sum_pool(x.float().to(dev), k.float().to(dev))
+    close(out, ref, 5e-6)
+    assert torch.equal(out, _lib.attn_sum_pool(x.float().to(dev), k.float().to(dev)))
+
+
 def test_mbrl_agent_in_the_loop_rollout(dev, networks):
     """The model-based-RL virtual rollout (mbrl.py:304-347): policy -> settings -> predict_tf -> feedback, four control steps of
     two simulation steps, against its fp64 restatement (oracle.emulator_ref.mbrl_rollout).  The policy is a fixed smooth
