@@ -50,7 +50,7 @@ static_assert(WS_NY >= 2 && WS_NY <= 4, "2 .. 4 waves multiply the primary rows"
 
 // LDS bytes: tile block + 2 x (s_self, s_nbr) + attention vectors / bias + 2 x sec rows + 2 x hx rows
 inline int64_t fused_ws_lds_bytes(int p_cap, int q_cap, int meta_cap) {
-  return 4 * ((int64_t)meta_cap + 4 * p_cap + 2 * FUSED_D + FUSED_H + 2 * (int64_t)q_cap * SEC_STRIDE + 2 * (int64_t)p_cap * FUSED_D);
+  return 4 * ((int64_t)meta_cap + 4 * p_cap + 3 * FUSED_D + FUSED_H + 2 * (int64_t)q_cap * SEC_STRIDE + 2 * (int64_t)p_cap * FUSED_D);
 }
 
 // 16 bytes per lane from base (wave-uniform, SGPR pair) + voff (per-lane byte offset) + IMM, invisible to the compiler's
@@ -62,6 +62,30 @@ __device__ __forceinline__ void ws_gld16(f32x4 &dst, const float *base, unsigned
 // tie four row registers to a point of the program: nothing that reads them is scheduled above it, nothing that writes them below
 __device__ __forceinline__ void ws_pin4(f32x4 &a0, f32x4 &a1, f32x4 &a2, f32x4 &a3) {
   asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+}
+// 8-lane all-reduce (max / sum) of FOUR values at once with the DPP move folded into the operation, as row16_max4 / row16_sum4
+// (kernels_fused.hpp) but for the octet layout of P3 (8 lanes per output row): quad_perm x2, then row_half_mirror (lane i <-> 7 - i
+// inside every 8 lanes) joins the two quads.
+__device__ __forceinline__ void row8_max4(const float (&in)[4], float (&out)[4]) {
+  asm("s_nop 1\n\t" UDS_DPP4_FIRST("v_max_f32_dpp", "quad_perm:[1,0,3,2]") UDS_DPP4("v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+      UDS_DPP4("v_max_f32_dpp", "row_half_mirror")
+      : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
+      : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]));
+}
+__device__ __forceinline__ void row8_sum4(const float (&in)[4], float (&out)[4]) {
+  asm("s_nop 1\n\t" UDS_DPP4_FIRST("v_add_f32_dpp", "quad_perm:[1,0,3,2]") UDS_DPP4("v_add_f32_dpp", "quad_perm:[2,3,0,1]")
+      UDS_DPP4("v_add_f32_dpp", "row_half_mirror")
+      : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
+      : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]));
+}
+// 16-bit half HI of pk (zero-extended) + base, one SDWA instruction.  Written as C the compiler unpacks every half it will
+// need into a register of its own ahead of the snapshot loop: 32 registers the octet P3 does not have.
+template <int HI>
+__device__ __forceinline__ unsigned ws_add_half(unsigned pk, unsigned base) {
+  unsigned r;
+  if (HI) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(r) : "v"(pk), "v"(base));
+  else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(r) : "v"(pk), "v"(base));
+  return r;
 }
 // wait until all but the n youngest vector-memory operations of this wave are done (n <= 8, exact)
 __device__ __forceinline__ void ws_vmcnt(int n) {
@@ -117,8 +141,8 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
 
   float *s_self = reinterpret_cast<float *>(smem + a.meta_cap);         // [2][p_cap]
   float *s_nbr = s_self + 2 * a.p_cap;                                   // [2][p_cap]
-  float *attn = s_nbr + 2 * a.p_cap;             // a_self[64] | a_nbr[64] | b_small[32]
-  float *sec = attn + 2 * FUSED_D + FUSED_H;     // [2][q_cap * SEC_STRIDE]
+  float *attn = s_nbr + 2 * a.p_cap;             // a_self[64] | a_nbr[64] | b_small[32] | b_out[64]
+  float *sec = attn + 3 * FUSED_D + FUSED_H;     // [2][q_cap * SEC_STRIDE]
   float *hx = sec + 2 * a.q_cap * SEC_STRIDE;    // [2][p_cap * 64]
   const int sec_buf = a.q_cap * SEC_STRIDE, hx_buf = a.p_cap * FUSED_D;
 
@@ -132,6 +156,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
     attn[tid] = S_.a_self[tid] * 1.44269504088896340736f;
     attn[FUSED_D + tid] = S_.a_nbr[tid] * 1.44269504088896340736f;
     if (tid < FUSED_H) attn[2 * FUSED_D + tid] = S_.b_small ? S_.b_small[tid] : 0.f;
+    attn[2 * FUSED_D + FUSED_H + tid] = S_.b_out ? S_.b_out[tid] : 0.f;
   }
   __syncthreads();
   const int n_own = __builtin_amdgcn_readfirstlane(smem[0]), n_prim = __builtin_amdgcn_readfirstlane(smem[1]),
@@ -603,6 +628,57 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
       });
     };
 #endif
+#ifndef UDS_WS_OCT_WD
+#define UDS_WS_OCT_WD 4       // neighbour slots per step of the octet P3 (each step: UDS_WS_OCT_WD x 2 x octets ds_read_b128 in flight)
+#endif
+#ifndef UDS_WS_OCT_GRP
+#define UDS_WS_OCT_GRP 1
+#endif
+#ifndef UDS_WS_P3_GROUPS
+    // P3 in the OCTET layout: 8 lanes x 2 float4 per output row, 8 rows per wave-instruction (ro = lane >> 3, c8 = lane & 7 owns
+    // features 4 c8 .. + 3 and 32 + 4 c8 .. + 3: the two 16-byte pieces sit 128 B apart in a swizzled hx row, ONE address).
+    // Against 16 lanes x float4 (k_fused_tile, and this kernel under -DUDS_WS_P3_GROUPS) every instruction of the softmax
+    // prologue and of the output epilogue covers twice the rows, and a neighbour slot costs 7 vector + 2 LDS instructions per
+    // 8 rows instead of 10 + 2.  Lane c8 of a row scores neighbour slots c8 and (rows with more than eight neighbours: 7 %
+    // of the line graph at the headline, none of the shipped networks) c8 + 8.  The LDS byte offsets of slots 0..7 are
+    // static per tile: every lane keeps its own eight as 16-bit halves of four registers (p3_pk); slot K's weight reaches
+    // the row's lanes by two bank-masked DPP row broadcasts.  The second slot set goes through ds_bpermute instead (the
+    // LDS crossbar).  Rows are degree-sorted inside the tile and dealt in octets: unit u (0..3) of wave xw -> octet NX u + xw.
+    const int ro = lane >> 3, c8 = lane & 7, hf8 = ro & 1;      // hf8: which 128-B half of a row this lane takes first (see phase3o)
+    int p3_dmax[U];
+    unsigned p3_pk[U][4];      // (the row's own slot byte and its output row are re-read from the tile block per snapshot: registers are short)
+    int n_st = 0;                 // output-store instructions this wave issues per snapshot (two per octet that has a row)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = 8 * (NX * u + xw) + ro;
+      const int ic = min(i, n_own - 1);
+      int dmx;
+      if (flags & ELL_FLAG_LONG_ROWS) {
+        dmx = i < n_own ? adj_ptr[ic + 1] - adj_ptr[ic] : 0;
+      } else {
+        const unsigned long long m0 = __ballot(i < n_own && adj_b[ic * ELL_ADJ + c8] != 0xFF);
+        const unsigned long long m1 = __ballot(i < n_own && adj_b[ic * ELL_ADJ + 8 + c8] != 0xFF);
+        dmx = __builtin_popcountll((m0 >> (8 * ro)) & 0xffull) + __builtin_popcountll((m1 >> (8 * ro)) & 0xffull);
+      }
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) dmx = max(dmx, __shfl_xor(dmx, o));
+      p3_dmax[u] = __builtin_amdgcn_readfirstlane(dmx);
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) {
+        unsigned pk = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const unsigned jb = adj_b[ic * ELL_ADJ + 2 * k2 + h];
+          const unsigned j = (i < n_own && jb != 0xFFu) ? jb : 0u;
+          pk |= (j * (FUSED_D * 4) + (((j & 7) ^ c8) << 4)) << (16 * h);      // < 2^16: q_cap <= 256 rows of 256 B
+        }
+        p3_pk[u][k2] = pk;
+      }
+      if (8 * (NX * u + xw) < n_own) n_st += 2;
+    }
+    const float *bias_l = attn + 2 * FUSED_D + FUSED_H + 4 * c8;      // + 32 hf8 / + 32 - 32 hf8 for the lane's first / second piece      // the output bias, read back per snapshot (registers are short)
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): drain the set-up loads on every path (see the Y team's note)
+#else
     // P3 rows: degree-sorted inside the tile and dealt in 4-row groups: trip t (0, 1), unit u (0..3) -> group NX (2 u + t) + xw,
     // so both trips and all waves get the same mix of degrees, in descending order.  Static per tile: the (wave-uniform)
     // largest degree of every group in SGPRs, this lane's neighbour byte of every group in VGPRs.
@@ -639,6 +715,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
     f32x4 bo = f32x4{0.f, 0.f, 0.f, 0.f};
     if (S_.b_out) bo = *reinterpret_cast<const f32x4 *>(S_.b_out + 4 * c16);
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): drain the set-up loads on every path (see the Y team's note)
+#endif
 
 #ifndef UDS_WS_MFMA16
     // ---------------- P1: secondary MLP, registers -> MFMA (32x32x16) -> sec ----------------
@@ -739,6 +816,194 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
     WS_STAMP(0);
     lds_barrier();
 
+#ifndef UDS_WS_P3_GROUPS
+    // ---------------- P3 (octets): segmented softmax + neighbour sum -> HBM, the wave's four octets in one pass ----------------
+    auto phase3o = [&](int s, int buf) __attribute__((always_inline)) {
+      const float *hxr = hx + buf * hx_buf;
+      const float *ssr = s_self + buf * a.p_cap, *snr = s_nbr + buf * a.p_cap;
+      int d0 = p3_dmax[0], d1 = p3_dmax[1], d2 = p3_dmax[2], d3 = p3_dmax[3];
+      asm volatile("" : "+s"(d0), "+s"(d1), "+s"(d2), "+s"(d3));      // keep the slot tests on the scalar unit
+      const int e3 = d3, e2 = max(e3, d2), e1 = max(e2, d1), e0 = max(e1, d0);
+      if (e0 == 0) return;            // this wave has no row in the tile
+      float ss[U], lg0[U], lg1[U], w0[U], w1[U], den[U];
+      bool ok[U], has0[U], has1[U];
+      unsigned jb0[U], jb1[U];
+      int joff1[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ok[u] = 8 * (NX * u + xw) + ro < n_own;
+        // every LDS read of this prologue is unconditional (a row past n_own reads some other word of the tile block, a missing
+        // slot the score of row 255; the selects below discard both): under a condition the compiler branches around each read
+        // and waits for it alone
+        jb0[u] = adj_b[(8 * (NX * u + xw) + ro) * ELL_ADJ + c8];
+        ss[u] = ssr[8 * (NX * u + xw) + ro];
+      }
+      asm volatile("" : "+v"(jb0[0]), "+v"(jb0[1]), "+v"(jb0[2]), "+v"(jb0[3]));      // the four reads are issued, then waited for together
+#pragma unroll
+      for (int u = 0; u < U; ++u) has0[u] = ok[u] && jb0[u] != 0xFFu;
+      f32x4 acc0[U], acc1[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc0[u] = acc1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (e0 <= 16) {
+        const bool ext = e0 > 8;      // some row of this wave has more than eight neighbours: the second slot set takes part
+        float sn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) sn[u] = snr[jb0[u]];
+        asm volatile("" : "+v"(sn[0]), "+v"(sn[1]), "+v"(sn[2]), "+v"(sn[3]));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float sv = ss[u] + sn[u];
+          lg0[u] = has0[u] ? fmaxf(sv, 0.2f * sv) : -INFINITY;      // leaky_relu(0.2)
+        }
+        float mx[U];
+        row8_max4(lg0, mx);
+        if (ext) {
+          float m1[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) jb1[u] = adj_b[(8 * (NX * u + xw) + ro) * ELL_ADJ + 8 + c8];
+          asm volatile("" : "+v"(jb1[0]), "+v"(jb1[1]), "+v"(jb1[2]), "+v"(jb1[3]));
+#pragma unroll
+          for (int u = 0; u < U; ++u) sn[u] = snr[jb1[u]];
+          asm volatile("" : "+v"(sn[0]), "+v"(sn[1]), "+v"(sn[2]), "+v"(sn[3]));
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            has1[u] = ok[u] && jb1[u] != 0xFFu;
+            const int j1 = has1[u] ? (int)jb1[u] : 0;
+            joff1[u] = j1 * (FUSED_D * 4) + ((j1 & 7) << 4);
+            const float sv = ss[u] + sn[u];
+            lg1[u] = has1[u] ? fmaxf(sv, 0.2f * sv) : -INFINITY;
+          }
+          row8_max4(lg1, m1);
+#pragma unroll
+          for (int u = 0; u < U; ++u) mx[u] = fmaxf(mx[u], m1[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) w0[u] = has0[u] ? __builtin_amdgcn_exp2f(lg0[u] - mx[u]) : 0.f;
+        row8_sum4(w0, den);
+        if (ext) {
+          float d1s[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) w1[u] = has1[u] ? __builtin_amdgcn_exp2f(lg1[u] - mx[u]) : 0.f;
+          row8_sum4(w1, d1s);
+#pragma unroll
+          for (int u = 0; u < U; ++u) den[u] += d1s[u];
+        }
+        typedef const __attribute__((address_space(3))) f32x4 *lds_f4;
+        // the first piece a lane reads is the 128-B half `hf8` of the neighbour's row, the second the other one: the 16 lanes
+        // ds_read_b128 serves per LDS cycle hold two rows' low-numbered and two rows' high-numbered lanes, and rows of
+        // opposite parity among them -- both halves of the 256-B bank row are in use, as in the 16-lane layout
+        const unsigned hxa0 = lds_addr(hxr) + 128 * hf8, hxa1 = lds_addr(hxr) + 128 - 128 * hf8;
+        const int cx = c8 << 4;                        // this lane's first 16-byte piece as a byte offset inside a row
+        const int bp = (lane & 56) << 2;               // ds_bpermute address of lane 0 of this row's octet
+        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+        // slots K .. K + Wd - 1 (0 <= K < 8) of slot set SET for the first A octets of the wave
+        auto step = [&](auto SET_, auto K_, auto A_) __attribute__((always_inline)) {
+          constexpr int SET = decltype(SET_)::value, K = decltype(K_)::value, A = decltype(A_)::value,
+                        Wd = (8 - K < UDS_WS_OCT_WD ? 8 - K : UDS_WS_OCT_WD);
+          constexpr int G = UDS_WS_OCT_GRP;            // octets per batch of reads (registers: 8 x G x Wd for the pieces)
+          static_for<(A + G - 1) / G>([&](auto g_) {
+            constexpr int u0 = decltype(g_)::value * G, GA = (A - u0 < G ? A - u0 : G);
+            f32x4 h0[GA][Wd], h1[GA][Wd];
+            static_for<GA>([&](auto u_) {
+              constexpr int ul = decltype(u_)::value, u = u0 + ul;
+              static_for<Wd>([&](auto i_) {
+                constexpr int i = decltype(i_)::value, k = K + i;
+                unsigned ad = 0;
+                if (SET) ad = (unsigned)__builtin_amdgcn_ds_bpermute(bp + 4 * k, joff1[u]) ^ cx;
+                unsigned ad0, ad1;
+                if (SET) {
+                  ad0 = ad + hxa0;
+                  ad1 = ad + hxa1;
+                } else {                 // half k & 1 of the packed pair + the buffer's base in one instruction (ws_add_half)
+                  ad0 = ws_add_half<k & 1>(p3_pk[u][k >> 1], hxa0);
+                  ad1 = ws_add_half<k & 1>(p3_pk[u][k >> 1], hxa1);
+                }
+                h0[ul][i] = *(lds_f4)(uintptr_t)ad0;
+                h1[ul][i] = *(lds_f4)(uintptr_t)ad1;
+              });
+            });
+            static_for<GA>([&](auto u_) {
+              constexpr int ul = decltype(u_)::value, u = u0 + ul;
+              static_for<Wd>([&](auto i_) {
+                constexpr int i = decltype(i_)::value, k = K + i;
+                float wv;
+                if (SET) wv = __int_as_float(__builtin_amdgcn_ds_bpermute(bp + 4 * k, __float_as_int(w1[u])));
+                else {     // lane k of the octet: row broadcast of lane k into the low eight lanes of every 16, of lane 8 + k into the high eight
+                  const int wi = __float_as_int(w0[u]);
+                  int t = __builtin_amdgcn_update_dpp(wi, wi, 0x150 + k, 0xf, 0xf, true);      // every lane written: no `old` to set up
+                  t = __builtin_amdgcn_update_dpp(t, wi, 0x150 + 8 + k, 0xf, 0xc, false);
+                  wv = __int_as_float(t);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  acc0[u][q] = fmaf(wv, h0[ul][i][q], acc0[u][q]);
+                  acc1[u][q] = fmaf(wv, h1[ul][i][q], acc1[u][q]);
+                }
+              });
+            });
+          });
+        };
+        static_for<(8 + UDS_WS_OCT_WD - 1) / UDS_WS_OCT_WD>([&](auto t_) {                  // slot set 0: slots 0..7, UDS_WS_OCT_WD per step
+          constexpr int K = decltype(t_)::value * UDS_WS_OCT_WD;
+          using IK = std::integral_constant<int, K>;
+          using S0 = std::integral_constant<int, 0>;
+          if (K < e3) step(S0{}, IK{}, I4{});
+          else if (K < e2) step(S0{}, IK{}, I3{});
+          else if (K < e1) step(S0{}, IK{}, I2{});
+          else if (K < e0) step(S0{}, IK{}, I1{});
+        });
+        if (ext)
+          static_for<(8 + UDS_WS_OCT_WD - 1) / UDS_WS_OCT_WD>([&](auto t_) {                // slot set 1: slots 8..15
+            constexpr int K = decltype(t_)::value * UDS_WS_OCT_WD;
+            using IK = std::integral_constant<int, K>;
+            using S1 = std::integral_constant<int, 1>;
+            if (K + 8 < e3) step(S1{}, IK{}, I4{});
+            else if (K + 8 < e2) step(S1{}, IK{}, I3{});
+            else if (K + 8 < e1) step(S1{}, IK{}, I2{});
+            else if (K + 8 < e0) step(S1{}, IK{}, I1{});
+          });
+      } else {   // some row has more than 16 neighbours: every lane walks its row's whole list (tiles with ELL_FLAG_LONG_ROWS)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = 8 * (NX * u + xw) + ro;
+          const int b0 = i < n_own ? adj_ptr[i] : 0;
+          const int dg = i < n_own ? adj_ptr[i + 1] - b0 : 0;
+          float mx = -INFINITY;
+          for (int p = b0; p < b0 + dg; ++p) mx = fmaxf(mx, leaky02(ss[u] + snr[adj_loc[p]]));
+          den[u] = 0.f;
+          for (int p = b0; p < b0 + dg; ++p) {
+            const int jj = adj_loc[p];
+            const float wv = __builtin_amdgcn_exp2f(leaky02(ss[u] + snr[jj]) - mx);
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(hxr + jj * FUSED_D + 32 * hf8 + ((c8 ^ (jj & 7)) << 2));
+            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(hxr + jj * FUSED_D + 32 - 32 * hf8 + ((c8 ^ (jj & 7)) << 2));
+            den[u] += wv;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              acc0[u][q] = fmaf(wv, v0[q], acc0[u][q]);
+              acc1[u][q] = fmaf(wv, v1[q], acc1[u][q]);
+            }
+          }
+        }
+      }
+      const f32x4 bo0 = *reinterpret_cast<const f32x4 *>(bias_l + 32 * hf8), bo1 = *reinterpret_cast<const f32x4 *>(bias_l + 32 - 32 * hf8);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (ok[u]) {
+          const float inv = __builtin_amdgcn_rcpf(den[u]);
+          f32x4 o0, o1;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            o0[q] = fused_act<ACT>(fmaf(acc0[u][q], inv, bo0[q]), a.act);
+            o1[q] = fused_act<ACT>(fmaf(acc1[u][q], inv, bo1[q]), a.act);
+          }
+          float *orow = S_.out + ((int64_t)s * S_.n_prim_glob * FUSED_D + (prim_ids[8 * (NX * u + xw) + ro] * FUSED_D + 4 * c8));
+          *reinterpret_cast<f32x4 *>(orow + 32 * hf8) = o0;
+          *reinterpret_cast<f32x4 *>(orow + 32 - 32 * hf8) = o1;
+        }
+      }
+    };
+#else
     // ---------------- P3: segmented softmax + neighbour sum -> HBM, one trip = 4 row groups of this wave ----------------
     auto phase3 = [&](int TR, int s, int buf) __attribute__((always_inline)) {      // TR: trip 0 / 1 (a constant after inlining, or the
                                                                                         // counter of a real loop under UDS_WS_P3_LOOP: half the code)
@@ -889,6 +1154,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
       }
     };
 
+#endif
     for (int k = 0; k <= n_snap; ++k) {
       const int s = s_begin + k;
       if (k + 1 < n_snap) {
@@ -906,13 +1172,18 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
       WS_STAMP(3);
 #ifndef UDS_WS_ABL_NO_P3
       if (k >= 1) {
-#ifdef UDS_WS_P3_LOOP
+#ifndef UDS_WS_P3_GROUPS
+        phase3o(s - 1, (k - 1) & 1);
+        WS_STAMP(4);
+#elif defined(UDS_WS_P3_LOOP)
 #pragma nounroll
         for (int tr = 0; tr < 2; ++tr) phase3(tr, s - 1, (k - 1) & 1);
 #else
         phase3(0, s - 1, (k - 1) & 1);
         WS_STAMP(4);
+#ifndef UDS_WS_ABL_HALF_P3
         phase3(1, s - 1, (k - 1) & 1);
+#endif
         WS_STAMP(5);
 #endif
       }
