@@ -330,7 +330,7 @@ def bench_c4(args, U, dist, world, rank, dev):
                      'halo_ms_per_layer': (t_inorder - t_comp) / max(1, L - 1), 'exposed_ms_per_layer': (t_pipe - t_comp) / max(1, L - 1),
                      'note': 'exchange hidden by pipelining over 2 snapshot groups on a side stream (dist.ShardedSpatialBlock.forward)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
-                         'traffic': None, 'kernel': 'k_fused_tile (per rank, its part of the network)'}})
+                         'traffic': None, 'kernel': 'k_fused_ws (per rank, its part of the network)'}})
     return rec
 
 
@@ -583,7 +583,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': recorded_traffic(args),
                          'algorithmic_bytes_per_launch': S * bytes_gs, 'launch_ms': dev_ms / L,
-                         'kernel': ('k_fused_cs<128,128,128,8,relu>' if d == 128 else 'k_fused_tile<64,64,relu>') +
+                         'kernel': ('k_fused_cs<128,128,128,8,relu>' if d == 128 else 'k_fused_ws<relu>') +
                                    ' (one launch per layer over S snapshots)' if args.precision == 'bf16x3' else
                                    'uds_spatial_layer_forward, unfused (8 launches per layer over S snapshots)',
                          'algorithmic_bytes_per_graph_step': bytes_gs, 'device_ms_per_step': dev_ms,

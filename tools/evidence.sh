@@ -28,7 +28,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-form
 python tools/pmc_summary.py "k_fused_cs<128, 128, 128" $O/pmc4 $O/pmc5 > $O/${T}_d128_pmc_summary.txt
 rm -rf $O/pmc4 $O/pmc5
 cat $O/${T}_d128_pmc_summary.txt
-python bench.py --autoregressive --no-cpu-baseline --no-trained-bias --no-c4 --no-rollout > $O/${T}_autoregressive_bench.json 2>> $O/bench.err
+python bench.py --autoregressive --no-cpu-baseline --no-trained-bias --no-c4 > $O/${T}_autoregressive_bench.json 2>> $O/bench.err
 python bench.py --workload c5 --steps 5 --warmup 2 > $O/${T}_c5_bench.json 2>> $O/bench.err
 python bench.py --workload c4 --steps 5 --warmup 2 > $O/${T}_c4_bench.json 2>> $O/bench.err
 python bench.py --workload small > $O/${T}_small_bench.json 2>> $O/bench.err
