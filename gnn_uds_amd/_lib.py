@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # UDS_LIB_PATH: a differently built copy of the same library (kernel experiments: tools/variant_bench.py)
 LIB_PATH = os.environ.get('UDS_LIB_PATH') or os.path.join(_HERE, 'libuds_hip.so')
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
 PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
 
@@ -43,6 +43,7 @@ SYMBOLS = {
     'uds_recurrent_fused_supported': (_c_int, [_c_i64, _c_int]),
     'uds_recurrent_forward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_attn_sum_pool': (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr]),
+    'uds_dropout': (_c_int, [_c_ptr, _c_i64, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _c_ptr, _c_ptr]),
     'uds_recurrent_forward_train': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr]),
     'uds_recurrent_backward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr]),
     'uds_rowgemm_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
@@ -395,6 +396,18 @@ def attn_sum_pool(x, attn_kernel):
     out = torch.empty((B, F), device=x.device, dtype=torch.float32)
     if B:
         _check(lib.uds_attn_sum_pool(_dev(x, 'x'), _dev(k, 'attn_kernel'), B, R, F, _dev(out, 'out'), _stream()), 'uds_attn_sum_pool')
+    return out
+
+
+def dropout(x, rate, seed, offset):
+    """keras Dropout in training mode on a contiguous fp32 device tensor (uds_dropout): kept elements scaled by 1 / (1 - rate);
+    the mask depends on (seed, offset + flat index) only."""
+    lib = load()
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    if out.numel():
+        _check(lib.uds_dropout(_dev(x, 'x'), x.numel(), float(rate), int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset) & 0xFFFFFFFFFFFFFFFF,
+                               _dev(out, 'out'), _stream()), 'uds_dropout')
     return out
 
 

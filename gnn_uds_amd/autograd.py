@@ -305,6 +305,21 @@ class CumsumActFn(torch.autograd.Function):
         return dx, dres, None
 
 
+class DropoutFn(torch.autograd.Function):
+    """keras Dropout in training mode (uds_dropout): the backward pass is the same kernel on the gradient with the same
+    (seed, offset) -- the mask is recomputed, not stored."""
+
+    @staticmethod
+    def forward(ctx, x, rate, seed, offset):
+        ctx.cfg = (rate, seed, offset)
+        return _lib.dropout(x, rate, seed, offset)
+
+    @staticmethod
+    def backward(ctx, gy):
+        rate, seed, offset = ctx.cfg
+        return _lib.dropout(gy.contiguous(), rate, seed, offset), None, None, None
+
+
 class FlowBalanceFn(torch.autograd.Function):
     """q_in, q_out (S,N) from signed link flows (S,E) (`emulator.py:717-724`); edges (E,2) int64 = [from, to] per link."""
 

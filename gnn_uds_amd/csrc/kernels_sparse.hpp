@@ -624,4 +624,57 @@ __global__ __launch_bounds__(256) void k_attn_sum_pool(AttnPoolArgs a) {
   }
 }
 
+// ---- training-time dropout (emulator.py:199-213,234-235,287-288,314-318; keras Dropout = inverted dropout) ----------------
+// out[i] = x[i] / (1 - rate) where bit i is kept, else 0.  The mask is a pure function of (seed, offset + i): Philox4x32-10
+// (Salmon et al., SC'11) with key = seed, counter = (offset + i) / 4, word (offset + i) % 4 -- nothing is stored, the backward
+// pass calls the same kernel on the gradient with the same (seed, offset).  A word u keeps its element when u >= rate * 2^32.
+struct DropoutArgs {
+  const float *x;
+  float *out;
+  int64_t n;
+  unsigned long long seed, offset;
+  unsigned thresh;
+  float scale;
+};
+
+__device__ __forceinline__ void philox4x32_10(unsigned long long ctr_lo, unsigned long long ctr_hi, unsigned long long key, unsigned (&r)[4]) {
+  unsigned c0 = (unsigned)ctr_lo, c1 = (unsigned)(ctr_lo >> 32), c2 = (unsigned)ctr_hi, c3 = (unsigned)(ctr_hi >> 32);
+  unsigned k0 = (unsigned)key, k1 = (unsigned)(key >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+
+// one thread = one counter = four consecutive elements (offset % 4 == 0 and 16-byte aligned x / out: the float4 path; else scalar)
+__global__ __launch_bounds__(256) void k_dropout(DropoutArgs a) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // index of the group of four ELEMENT POSITIONS offset + 4q ..
+  const unsigned long long g0 = a.offset >> 2;
+  const int lead = (int)(a.offset & 3);                                    // elements of the first counter that precede x[0]
+  // element i uses counter (offset + i) >> 2, word (offset + i) & 3: thread q covers positions p = 4 (g0 + q) + w, i = p - offset
+  unsigned r[4];
+  philox4x32_10(g0 + (unsigned long long)q, 0ull, a.seed, r);
+  const int64_t i0 = 4 * q - lead;
+  if (lead == 0 && i0 + 3 < a.n && ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.out)) & 15) == 0) {
+    const float4 v = *reinterpret_cast<const float4 *>(a.x + i0);
+    float4 o;
+    o.x = r[0] >= a.thresh ? v.x * a.scale : 0.f;
+    o.y = r[1] >= a.thresh ? v.y * a.scale : 0.f;
+    o.z = r[2] >= a.thresh ? v.z * a.scale : 0.f;
+    o.w = r[3] >= a.thresh ? v.w * a.scale : 0.f;
+    *reinterpret_cast<float4 *>(a.out + i0) = o;
+    return;
+  }
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int64_t i = i0 + w;
+    if (i >= 0 && i < a.n) a.out[i] = r[w] >= a.thresh ? a.x[i] * a.scale : 0.f;
+  }
+}
+
 }  // namespace uds

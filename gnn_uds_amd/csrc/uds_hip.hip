@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -596,6 +597,20 @@ int uds_attn_sum_pool(const float *x, const float *k, int64_t B, int64_t R, int6
   hipLaunchKernelGGL(uds::k_attn_sum_pool, dim3((unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(UDS_EHIP, "uds_attn_sum_pool: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
+int uds_dropout(const float *x, int64_t n, float rate, uint64_t seed, uint64_t offset, float *out, uds_stream_t stream) {
+  UDS_REQUIRE(n >= 0 && (n == 0 || (x && out)), "uds_dropout: NULL argument");
+  UDS_REQUIRE(rate >= 0.f && rate < 1.f, "uds_dropout: rate=%g outside [0, 1)", (double)rate);
+  if (n == 0) return UDS_OK;
+  const int64_t groups = (n + (int64_t)(offset & 3) + 3) / 4;
+  UDS_REQUIRE((groups + 255) / 256 < INT32_MAX, "uds_dropout: n=%lld too large for one launch", (long long)n);
+  uds::DropoutArgs a{x, out, n, (unsigned long long)seed, (unsigned long long)offset,
+                     (unsigned)std::min<double>(4294967295.0, std::ceil((double)rate * 4294967296.0)), 1.0f / (1.0f - rate)};
+  hipLaunchKernelGGL(uds::k_dropout, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_dropout: launch -> %s", hipGetErrorString(e));
   return UDS_OK;
 }
 

@@ -16,7 +16,7 @@ Conv1D, the resnet prefix sum) and the link->node flow balance of post_proc_tf a
 The remaining post-processing is elementwise gating / clipping on tensors already in HBM and is written with torch
 tensor ops (device plumbing).  Training (`fit_eval`, GradNorm), `graph_base` 1 / 2, GCN and DiffusionConv are built.
 `use_adj` (per-time-step adjacency rewritten by the control action) is built for GAT as a mask over the CSR entries.
-GRU / LSTM temporal nets run (inference and, at 64 units, training).  Not built, each raises: training-time dropout, `use_adj` with GCN / Diffusion or under autograd,
+GRU / LSTM temporal nets run (inference and, at 64 units, training).  Training-time dropout: `layers.Dropout` on `uds_dropout`.  Not built, each raises: `use_adj` with GCN / Diffusion or under autograd,
 GeneralConv (a sparse-mode-only Spektral layer the reference's dense call cannot run either).  conv = False -- the reference's non-graph
 baseline, its shipped `*_nncat_*` models -- runs on the same Dense / temporal / cumsum kernels (`_forward_mlp`).
 """
@@ -30,7 +30,7 @@ from . import _lib
 from .graph import DrainageGraph, csr_from_dense
 from . import autograd as _ag
 from .graph import csr_from_dense, edge_based_adj_csr, node_based_adj_csr
-from .layers import Dense, GraphBaseBlock, SpatialBlock, _glorot_uniform, _packed_kernel, _param
+from .layers import Dense, Dropout, DropoutStream, GraphBaseBlock, SpatialBlock, _glorot_uniform, _packed_kernel, _param
 
 
 class Conv1D(nn.Module):
@@ -272,8 +272,15 @@ class Emulator(nn.Module):
             raise ValueError('graph_base must be 0, 1 (node-based) or 2 (edge-based), got %r' % (self.graph_base,))
         if recurrent not in ('Conv1D', 'GRU', 'LSTM', None, 'None', False):
             raise NotImplementedError('recurrent=%r: Conv1D, GRU, LSTM or none (emulator.py:154-163)' % (recurrent,))
-        if self.dropout:
-            raise NotImplementedError('dropout > 0 (training-time) is not built')
+        # keras Dropout layers (:199-213,234-235,287-288,314-318): active only in `forward(..., training=True)` = `fit_eval(fit=True)`
+        # (`self.model(inp, training=fit)`, :411,434); one counter-based stream for all of them (layers.Dropout)
+        self.dropout_stream = DropoutStream(generator=generator) if self.dropout else None
+        if self.dropout and self.conv and self.conv_kind == 'GAT':
+            import warnings
+            warnings.warn('dropout > 0: the Dropout layers of the model are applied in training; the attention-coefficient dropout of '
+                          "Spektral's GATConv (rate 0.5), which the reference's `training=True` also switches on, is not")
+        self._drop02 = Dropout(0.2, self.dropout_stream) if self.dropout else None
+        self._drop = Dropout(self.dropout, self.dropout_stream) if self.dropout else None
 
         graph = g('graph')
         self._base_filter = None
@@ -439,20 +446,26 @@ class Emulator(nn.Module):
         self.flood_out = Dense(N, 'sigmoid', in_features=fi, generator=gen, precision=pr) if self.if_flood else None      # :327-330
         self.e_out_layer = Dense(self.e_out * E, 'tanh', in_features=d, generator=gen, precision=pr)          # :335-337
 
-    def _forward_mlp(self, X, B, E, AE=None):
+    def _forward_mlp(self, X, B, E, AE=None, training=False):
         nb, T = X.shape[0], self.seq_out
+        drop = bool(self.dropout) and training
+        d02 = (lambda t: self._drop02(t, True)) if drop else (lambda t: t)
+        dr = (lambda t: self._drop(t, True)) if drop else (lambda t: t)
         flat = lambda t: t.reshape(t.shape[0], t.shape[1], 1, -1).contiguous()        # (B, T, N, c) -> one row of N * c per step
-        xl = self.embed_x(flat(X), 'linear')
-        x_lin_last, x = xl[:, -1:].contiguous(), self.embed_x(flat(X), self.activation)
-        el = self.embed_e(flat(E), 'linear')
-        e_lin_last, e = el[:, -1:].contiguous(), self.embed_e(flat(E), self.activation)
-        b = self.embed_b(flat(B))
-        ae = self.embed_ae(flat(AE)) if self.act else None
+        xl = d02(self.embed_x(flat(X), 'linear'))                                     # masks drawn in the reference's order x, b, e, ae
+        b = d02(self.embed_b(flat(B)))
+        el = d02(self.embed_e(flat(E), 'linear'))
+        ae = d02(self.embed_ae(flat(AE))) if self.act else None
+        x_lin_last, e_lin_last = xl[:, -1:].contiguous(), el[:, -1:].contiguous()
+        if drop:      # the activation follows the dropout (:199-201)
+            x, e = _ag.apply_activation(xl, self.activation), _ag.apply_activation(el, self.activation)
+        else:
+            x, e = self.embed_x(flat(X), self.activation), self.embed_e(flat(E), self.activation)
 
         def spatial(layers, x, e):
             for ly in layers:
                 z = ly(torch.cat([x, e], dim=-1))
-                x, e = z[..., :z.shape[-1] // 2].contiguous(), z[..., z.shape[-1] // 2:].contiguous()
+                x, e = dr(z[..., :z.shape[-1] // 2].contiguous()), dr(z[..., z.shape[-1] // 2:].contiguous())
             return x, e
 
         def chain(mods, t):
@@ -469,7 +482,7 @@ class Emulator(nn.Module):
         x, e = chain(self.tem2_x, x), chain(self.tem2_e, e)
 
         def res_head(layer, t, lin_last):
-            y = layer(t)
+            y = dr(layer(t))                                                          # :314,318
             if not self.resnet:
                 return y
             if _ag.grad_on(y, lin_last):
@@ -484,11 +497,15 @@ class Emulator(nn.Module):
         return out, self.e_out_layer(e).reshape(nb, T, self.n_edge, self.e_out)
 
     # ------------------------------------------------------------------ network forward (build_network)
-    def forward(self, X, B, E, AE=None, ADJ=None):
+    def forward(self, X, B, E, AE=None, ADJ=None, training=False):
         """ADJ: the per-time-step node adjacency of `use_adj` (emulator.py:178-180,268-271; block 2 only): the edge mask
-        (B, T_out, nnz) of `get_adj_action`, or the reference's dense (B, T_out, n, n) integer array (small networks)."""
+        (B, T_out, nnz) of `get_adj_action`, or the reference's dense (B, T_out, n, n) integer array (small networks).
+        training: keras' `training=` flag -- switches the Dropout layers on when the model was built with `dropout` > 0."""
         if not self.conv:
-            return self._forward_mlp(X, B, E, AE)
+            return self._forward_mlp(X, B, E, AE, training)
+        drop = bool(self.dropout) and training
+        d02 = (lambda t: self._drop02(t, True)) if drop else (lambda t: t)
+        dr = (lambda t: self._drop(t, True)) if drop else None
         nb = X.shape[0]
         c = lambda t: t.contiguous()
         adj_mask = None
@@ -498,20 +515,28 @@ class Emulator(nn.Module):
             adj_mask = self._adj_mask_from(ADJ, X.device).reshape(nb * self.seq_out, -1)
         # the embedding is linear, its last step is kept as the residual, then the activation is applied (:198-201):
         # two launches of the same GEMM (same per-row arithmetic), one with and one without the activation
-        x_lin_last = self.embed_x(c(X[:, -1:]), 'linear')
-        x = self.embed_x(c(X), self.activation)
-        e_lin_last = self.embed_e(c(E[:, -1:]), 'linear')
-        e = self.embed_e(c(E), self.activation)
-        b = self.embed_b(c(B))
-        ae = self.embed_ae(c(AE)) if self.act else None
+        if drop:      # Dense(linear) -> Dropout(0.2) -> residual slice -> activation (:198-201,206-209); masks drawn in the reference's order x, b, e, ae
+            xl = d02(self.embed_x(c(X), 'linear'))
+            b = d02(self.embed_b(c(B)))
+            el = d02(self.embed_e(c(E), 'linear'))
+            ae = d02(self.embed_ae(c(AE))) if self.act else None
+            x_lin_last, e_lin_last = c(xl[:, -1:]), c(el[:, -1:])
+            x, e = _ag.apply_activation(xl, self.activation), _ag.apply_activation(el, self.activation)
+        else:
+            x_lin_last = self.embed_x(c(X[:, -1:]), 'linear')
+            x = self.embed_x(c(X), self.activation)
+            e_lin_last = self.embed_e(c(E[:, -1:]), 'linear')
+            e = self.embed_e(c(E), self.activation)
+            b = self.embed_b(c(B))
+            ae = self.embed_ae(c(AE)) if self.act else None
 
         def spatial(block, x, e, xb=None, eb=None, mask=None):
             T = x.shape[1]
             r = lambda t, n: None if t is None else t.reshape(nb * T, n, -1)
-            if mask is None:
-                xs, es = block(r(x, self.n_node), r(e, self.n_edge), r(xb, self.n_node), r(eb, self.n_edge))
-            else:
-                xs, es = block(r(x, self.n_node), r(e, self.n_edge), r(xb, self.n_node), r(eb, self.n_edge), adj_mask=mask)
+            kw = {} if mask is None else {'adj_mask': mask}
+            if dr is not None:
+                kw['dropout'] = dr
+            xs, es = block(r(x, self.n_node), r(e, self.n_edge), r(xb, self.n_node), r(eb, self.n_edge), **kw)
             return xs.reshape(nb, T, self.n_node, -1), es.reshape(nb, T, self.n_edge, -1)
 
         def temporal(mods_x, mods_e, x, e):
@@ -542,6 +567,9 @@ class Emulator(nn.Module):
         x, e = spatial(self.block2, c(x), c(e), b, ae if self.act else None, adj_mask)
         x, e = temporal(self.tem2_x, self.tem2_e, x, e)
         def res_head(layer, t, lin_last):                             # :313-320
+            if drop:
+                y = dr(layer(t))
+                return _ag.CumsumActFn.apply(y, lin_last, self.activation) if self.resnet else y
             if not self.resnet:
                 return layer(t)
             if (layer.precision == 'bf16x3' and layer.units == 64 and t.shape[-1] == 64 and t.shape[0] * t.shape[2] >= 4096
@@ -559,7 +587,7 @@ class Emulator(nn.Module):
             pk = lambda m: _packed_kernel(m, m.kernel)
             ok = (self.resnet and layer.precision == 'bf16x3' and layer.units == 64 and t.shape[-1] == 64 and head.units <= 4
                   and len(hidden) <= 5 and all(m.units == 32 for m in hidden) and (not hidden or hidden[0].kernel.shape[0] == 64)
-                  and not _ag.grad_on(t, lin_last, *self.parameters()))
+                  and not drop and not _ag.grad_on(t, lin_last, *self.parameters()))
             if not ok:
                 return None
             return _lib.dense_cumsum_heads(
@@ -830,7 +858,7 @@ class Emulator(nn.Module):
             ys, eys = [], []
             for i in range(self.roll):
                 sl = slice(i * self.seq_out, (i + 1) * self.seq_out)
-                y, ey, x, ex = self._roll_step(x, ex, a[:, sl] if a is not None else None, b[:, sl])
+                y, ey, x, ex = self._roll_step(x, ex, a[:, sl] if a is not None else None, b[:, sl], fit)
                 ys.append(y)
                 eys.append(ey)
             preds, edge_preds = torch.cat(ys, dim=1), torch.cat(eys, dim=1)
@@ -839,15 +867,15 @@ class Emulator(nn.Module):
                 ae = self.get_edge_action(a, True)
             if adj is None and self.act and self.use_adj:
                 adj = self.get_adj_action(a, True)
-            preds, edge_preds = self.post_proc_tf(self.forward(x, b, ex, ae, adj), a, b)
+            preds, edge_preds = self.post_proc_tf(self.forward(x, b, ex, ae, adj, training=fit), a, b)
         return preds.clamp(0, 1), edge_preds                          # :437
 
-    def _roll_step(self, x, ex, a_i, b_i):
+    def _roll_step(self, x, ex, a_i, b_i, fit=False):
         """One chunk of the autoregressive rollout (emulator.py:403-423): forward on the last seq_in steps, post-processing,
         then the window shifts by seq_out steps fed with the prediction (flood bit thresholded at 0.5)."""
         ae_i = self.get_edge_action(a_i, True) if self.act else None
         adj_i = self.get_adj_action(a_i, True) if self.act and self.use_adj else None       # :407
-        y, ey = self.forward(x[:, -self.seq_in:], b_i, ex[:, -self.seq_in:], ae_i, adj_i)
+        y, ey = self.forward(x[:, -self.seq_in:], b_i, ex[:, -self.seq_in:], ae_i, adj_i, training=fit)
         y, ey = self.post_proc_tf((y, ey), a_i, b_i)
         if self.if_flood:                                   # flood bit fed back as a hard 0/1 (:417)
             x_new = torch.cat([y[..., :-1], (y[..., -1:] > 0.5).float(), b_i], dim=-1)

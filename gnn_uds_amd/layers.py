@@ -681,7 +681,7 @@ class GraphBaseBlock(nn.Module):
             if conv == 'GAT':
                 ly.precision = precision
 
-    def forward(self, x, e, xb=None, eb=None, adj_mask=None):
+    def forward(self, x, e, xb=None, eb=None, adj_mask=None, dropout=None):
         if xb is not None:
             x = torch.cat([x, xb], dim=-1)
         if eb is not None:
@@ -693,7 +693,48 @@ class GraphBaseBlock(nn.Module):
         z = torch.cat([x, e], dim=-2)
         for ly in self.layers:
             z = ly([z, self.filt], edge_mask=adj_mask) if adj_mask is not None else ly([z, self.filt])
+            if dropout is not None:      # Dropout on the node rows and on the link rows (emulator.py:234-235): one elementwise mask
+                z = dropout(z)
         return z[..., :self.n_node, :].contiguous(), z[..., self.n_node:, :].contiguous()
+
+
+class Dropout(nn.Module):
+    """`keras.layers.Dropout(rate)` as the emulator uses it (`emulator.py:199-213,234-235,287-288,314-318`): identity unless
+    called with training=True (`self.model(inp, training=fit)`, :411,434), then inverted dropout on the HIP kernel (uds_dropout,
+    counter-based Philox4x32-10: the mask is a function of (seed, offset + element index), recomputed in the backward pass).
+    `seed` comes from the generator given at construction (or torch's default one); every call consumes x.numel() positions of
+    the stream, so successive calls and successive layers sharing one DropoutStream draw disjoint masks."""
+
+    def __init__(self, rate, stream=None, generator=None):
+        super().__init__()
+        if not 0.0 <= rate < 1.0:
+            raise ValueError('dropout rate %r outside [0, 1)' % (rate,))
+        self.rate = float(rate)
+        self.stream = stream if stream is not None else DropoutStream(generator=generator)
+
+    def forward(self, x, training=False):
+        if not training or self.rate == 0.0:
+            return x
+        x = x.contiguous()
+        offset = self.stream.take(x.numel())
+        return _ag.DropoutFn.apply(x, self.rate, self.stream.seed, offset)
+
+
+class DropoutStream:
+    """(seed, running offset) of one counter-based random stream shared by the Dropout layers of a model."""
+
+    def __init__(self, seed=None, generator=None):
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator).item())
+        self.seed, self.offset = int(seed), 0
+
+    def take(self, n):
+        o = self.offset
+        self.offset += (int(n) + 3) // 4 * 4      # whole counters: every call starts on the float4 path of the kernel
+        return o
+
+    def reseed(self, seed):
+        self.seed, self.offset = int(seed), 0
 
 
 class SpatialBlock(nn.Module):
@@ -733,11 +774,14 @@ class SpatialBlock(nn.Module):
         replay.graph = graph
         return replay
 
-    def forward(self, x, e, xb=None, eb=None, adj_mask=None):
+    def forward(self, x, e, xb=None, eb=None, adj_mask=None, dropout=None):
         """xb / eb: extra input columns of the FIRST layer (`concat([x, b])` before block 2, emulator.py:260-262);
-        adj_mask: the per-snapshot node adjacency of `use_adj`, seen by every layer of the block (emulator.py:268-282)."""
+        adj_mask: the per-snapshot node adjacency of `use_adj`, seen by every layer of the block (emulator.py:268-282);
+        dropout: callable applied to x and e after every layer (`Dropout(self.dropout)`, emulator.py:234-235,287-288), training only."""
         net = self.layers[0].network() if self.layers[0].conv == 'GAT' else None
         for i, layer in enumerate(self.layers):
             layer._net = net
             x, e = layer(x, e, xb if i == 0 else None, eb if i == 0 else None, adj_mask=adj_mask)
+            if dropout is not None:
+                x, e = dropout(x), dropout(e)
         return x, e

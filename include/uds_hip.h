@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 17
+#define UDS_ABI_VERSION 18
 
 enum {
   UDS_OK = 0,
@@ -224,6 +224,13 @@ int uds_cumsum_act(const float *x, const float *res, int64_t B, int64_t T, int64
  * out[b, :] = sum_r softmax_r(<x[b, r, :], k>) x[b, r, :] for x (B, R, F), k (F), F a power of two up to 256.  One pass over the
  * rows (online softmax), fixed merge order: bitwise reproducible. */
 int uds_attn_sum_pool(const float *x, const float *k, int64_t B, int64_t R, int64_t F, float *out, uds_stream_t stream);
+
+/* keras Dropout in training mode (the emulator's Dropout(0.2) / Dropout(self.dropout) layers,   emulator.py:199-213,234-235,
+ * 287-288,314-318; `self.model(inp, training=fit)`, :411,434): out[i] = x[i] / (1 - rate) if element i is kept, else 0, for n floats;
+ * out may be x.  0 <= rate < 1.  The mask is a pure function of (seed, offset + i) -- Philox4x32-10, key = seed, counter =
+ * (offset + i) / 4, word (offset + i) % 4, kept when word >= rate * 2^32 -- so the backward pass is the same call on the gradient
+ * with the same (seed, offset) and nothing is stored; the caller advances offset by n per use. */
+int uds_dropout(const float *x, int64_t n, float rate, uint64_t seed, uint64_t offset, float *out, uds_stream_t stream);
 
 /* Link -> node flow balance of post_proc_tf: inc_n is the (N x E) incidence support, sign (nnz) its +1 / -1 values,
  * flow (S,E) the signed link flows; q_in, q_out (S,N) are scaled per node by scale_in / scale_out (N).

@@ -72,6 +72,7 @@ def config(args):
     c.conv = 'GCN' if 'GCN' in conv else 'Diffusion' if 'Diff' in conv else 'GAT'     # emulator.py:131-142
     c.resnet = bool(g('resnet', False))
     c.roll = int(g('roll', 0))
+    c.dropout = float(g('dropout', 0.0) or 0.0)           # rate of the Dropout layers behind the spatial layers / the resnet Dense (:65)
     c.graph_base = int(g('graph_base', 0))                # 0: node graph + line graph; 1 / 2: one graph over nodes AND links (:220-223)
     if c.conv == 'GAT':                                   # emulator.py:143-145
         c.filter = (c.adj > 0).astype(np.float64)
@@ -288,23 +289,34 @@ def _spatial_layer(x, e, p, c, dtype, adj=None):
                                   torch.from_numpy(c.edge_filter).to(dtype), torch.from_numpy(c.node_edge).to(dtype), c.activation, c.conv)
 
 
+# Training-time dropout (emulator.py:199-213,234-235,287-288,314-318 with `training=fit`, :411,434): None = inference (identity);
+# a test sets it to a callable (tensor, rate) -> tensor that applies the mask stream it wants to compare with (oracle/dropout_ref.py).
+DROPOUT = None
+
+
+def _drop(t, rate):
+    return t if DROPOUT is None or not rate else DROPOUT(t, rate)
+
+
 def _forward_mlp(c, params, X, B, E, AE, act, D):
     """`build_network(conv=False)` (emulator.py:166-341, `net = Dense`): the reference's non-graph baseline (`*_nncat_*` models)."""
     nb = X.shape[0]
+    dr = c.dropout
+    d02 = 0.2 if dr else 0.0
     flat = lambda t: t.reshape(t.shape[0], t.shape[1], -1)        # :197,202,205,211: (B, T, N, c) -> (B, T, N * c)
-    x = D(flat(X), params['embed_x'])
+    x = _drop(D(flat(X), params['embed_x']), d02)
     res = x[:, -1:]
     x = act(x)
-    b = D(flat(B), params['embed_b'], c.activation)
-    e = D(flat(E), params['embed_e'])
+    b = _drop(D(flat(B), params['embed_b'], c.activation), d02)
+    e = _drop(D(flat(E), params['embed_e']), d02)
     res_e = e[:, -1:]
     e = act(e)
-    ae = D(flat(AE), params['embed_ae'], c.activation) if c.act else None
+    ae = _drop(D(flat(AE), params['embed_ae'], c.activation), d02) if c.act else None
 
     def spatial(x, e, layers):                                    # :236-237
         for p in layers:
             z = D(torch.cat([x, e], dim=-1), p, c.activation)
-            x, e = z[..., :z.shape[-1] // 2], z[..., z.shape[-1] // 2:]
+            x, e = _drop(z[..., :z.shape[-1] // 2], dr), _drop(z[..., z.shape[-1] // 2:], dr)
         return x, e
 
     def temporal(y, layers):                                      # rows are the batch elements: (B, T, F) as it stands
@@ -322,7 +334,8 @@ def _forward_mlp(c, params, X, B, E, AE, act, D):
         e = torch.cat([e, ae], dim=-1)
     x, e = spatial(x, e, params['block2'])
     x, e = temporal(x, params['tem2_x']), temporal(e, params['tem2_e'])
-    x_out, e_out = D(x, params['res_x']), D(e, params['res_e'])
+    x_out = _drop(D(x, params['res_x']), dr)
+    e_out = _drop(D(e, params['res_e']), dr)
     if c.resnet:
         x, e = act(torch.cumsum(x_out, dim=1) + res), act(torch.cumsum(e_out, dim=1) + res_e)
     else:
@@ -345,14 +358,16 @@ def forward(args, params, X, B, E, AE=None, ADJ=None):
     D = lambda t, p, a='linear': OD.dense(t, p['kernel'], p['bias'], a)
     if c.mlp:
         return _forward_mlp(c, params, X, B, E, AE, act, D)
-    x = D(X, params['embed_x'])                                   # :198
+    dr = c.dropout
+    d02 = 0.2 if dr else 0.0                                      # `Dropout(0.2)(x) if self.dropout else x`
+    x = _drop(D(X, params['embed_x']), d02)                       # :198-199
     res = x[:, -1:]                                               # :200
     x = act(x)
-    b = D(B, params['embed_b'], c.activation)                     # :203
-    e = D(E, params['embed_e'])                                   # :206
+    b = _drop(D(B, params['embed_b'], c.activation), d02)         # :203-204
+    e = _drop(D(E, params['embed_e']), d02)                       # :206-207
     res_e = e[:, -1:]
     e = act(e)
-    ae = D(AE, params['embed_ae'], c.activation) if c.act else None      # :212
+    ae = _drop(D(AE, params['embed_ae'], c.activation), d02) if c.act else None      # :212-213
     nb = X.shape[0]
 
     def spatial(x, e, layers, adj=None):                          # :217-235 / :265-288; adj: (B,T,n,n) of use_adj (:268-271)
@@ -363,14 +378,16 @@ def forward(args, params, X, B, E, AE=None, ADJ=None):
             if c.graph_base:
                 q = p['gat']
                 if c.conv == 'Diffusion':
-                    z = OD.diffusion_conv_dense(torch.cat([xs, es], dim=-2), torch.from_numpy(c.filter).to(dt), q['theta'], c.activation)
+                    z = _drop(OD.diffusion_conv_dense(torch.cat([xs, es], dim=-2), torch.from_numpy(c.filter).to(dt), q['theta'], c.activation), dr)
                     xs, es = z[:, :c.n_node], z[:, c.n_node:]
                     continue
                 z = OD.gat_conv_dense(torch.cat([xs, es], dim=-2), torch.from_numpy(c.filter).to(dt) if A is None else A.to(dt), q['kernel'], q['attn_kernel_self'],
                                       q['attn_kernel_neighs'], q['bias'], c.activation)
+                z = _drop(z, dr)                                  # :234-235 (one mask over the stacked rows = one per half)
                 xs, es = z[:, :c.n_node], z[:, c.n_node:]
             else:
                 xs, es = _spatial_layer(xs, es, p, c, dt, A)
+                xs, es = _drop(xs, dr), _drop(es, dr)             # :234-235,287-288
         return xs.reshape(nb, T, c.n_node, -1), es.reshape(nb, T, c.n_edge, -1)
 
     def temporal(x, layers, n):                                   # :244-257 / :299-310
@@ -392,9 +409,9 @@ def forward(args, params, X, B, E, AE=None, ADJ=None):
     x, e = spatial(x, e, params['block2'], ADJ)                       # :264-288 (A = A_in with use_adj)
     x = temporal(x, params['tem2_x'], c.n_node)
     e = temporal(e, params['tem2_e'], c.n_edge)
-    x_out = D(x, params['res_x'])                                 # :313
+    x_out = _drop(D(x, params['res_x']), dr)                      # :313-314
     x = act(torch.cumsum(x_out, dim=1) + res) if c.resnet else act(x_out)   # :315-316
-    e_o = D(e, params['res_e'])
+    e_o = _drop(D(e, params['res_e']), dr)                        # :317-318
     e = act(torch.cumsum(e_o, dim=1) + res_e) if c.resnet else act(e_o)     # :319-320
     out = D(x, params['out'], 'hard_sigmoid')                     # :324
     if c.if_flood:
