@@ -112,7 +112,8 @@ def trained_bias_leg(U, g, args, dev, x, e, reps=5):
     """The same block with the reference's trained form of NodeEdge: dense (R, M) weight and bias, the bias non-zero off the
     incidence support (reference emulator.py:36-45 -- what every checkpoint the reference trains looks like).  Per layer:
     secondary MLPs on the row-GEMM kernel, `rest @ x_e` on the split-bf16 MFMA GEMM (k_remainder_gemm), the rest in the fused
-    kernel's 96-wide variant with the remainder as 32 extra input columns."""
+    kernel's 96-wide variant with the remainder as 32 extra input columns (d = 64) or in the column-split kernel, which adds the
+    remainder to its NodeEdge aggregate (d = 128, uds_spatial_layer_forward_rem)."""
     d, L, S = args.embed, args.layers, args.snapshots
     blk = U.SpatialBlock(g, d, L, 'relu', sparse_params=False, generator=torch.Generator().manual_seed(1), precision=args.precision).to(dev)
     with torch.no_grad():
@@ -595,7 +596,7 @@ def main():
             out['rollout'] = rollout_forward(U, g, args, dev)
             if args.autoregressive:
                 out['rollout']['autoregressive'] = rollout_autoregressive(U, dev)
-        if world == 1 and args.embed == 64 and args.precision == 'bf16x3' and not args.no_trained_bias \
+        if world == 1 and args.embed in (64, 128) and args.precision == 'bf16x3' and not args.no_trained_bias \
                 and g.n_node * g.n_edge <= (1 << 28):
             out['trained_bias'] = trained_bias_leg(U, g, args, dev, x, e)
         if world == 1 and not args.no_cpu_baseline:

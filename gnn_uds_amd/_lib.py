@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # UDS_LIB_PATH: a differently built copy of the same library (kernel experiments: tools/variant_bench.py)
 LIB_PATH = os.environ.get('UDS_LIB_PATH') or os.path.join(_HERE, 'libuds_hip.so')
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
 PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
 
@@ -88,6 +88,8 @@ SYMBOLS = {
     'uds_spatial_pack_weights': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr]),
     'uds_spatial_layer_forward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
                                            _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
+    'uds_spatial_layer_forward_rem': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_int,
+                                      _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'uds_spatial_layer_forward_split': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64,
                                                  _c_i64, _c_i64, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
 }
@@ -872,11 +874,13 @@ def spatial_pack_weights(p, fx, fe, h, d):
     return out
 
 
-def spatial_layer_forward(net, p, x, e, h, d, act='relu', flags=0, xb=None, eb=None):
+def spatial_layer_forward(net, p, x, e, h, d, act='relu', flags=0, xb=None, eb=None, rem_x=None, rem_e=None):
     """One spatial-block loop body (`emulator.py:225-230`).  p: dict of the 14 tensors of
     uds_spatial_params_t.  x:(S,N,fx), e:(S,E,fe) -> (S,N,d), (S,E,d).  flags: FLAG_* of the C ABI.
     xb (S,N,32) / eb (S,E,32): extra columns appended to a 64-wide x / e without materialising the concatenation
-    (uds_spatial_layer_forward_split; fused kernel only)."""
+    (uds_spatial_layer_forward_split; fused kernel only).
+    rem_x (S,N,h) / rem_e (S,E,h): the dense remainder of a trained NodeEdge, added to the aggregates inside the d = 128 fused
+    kernel (uds_spatial_layer_forward_rem; fused kernel only)."""
     lib = load()
     S, N, fx = x.shape
     _, E, fe = e.shape
@@ -891,6 +895,15 @@ def spatial_layer_forward(net, p, x, e, h, d, act='relu', flags=0, xb=None, eb=N
     ws = torch.empty(lib.uds_spatial_workspace_floats(net.ptr, S, h, d), device=x.device, dtype=torch.float32)
     out_x = torch.empty((S, N, d), device=x.device, dtype=torch.float32)
     out_e = torch.empty((S, E, d), device=x.device, dtype=torch.float32)
+    if rem_x is not None or rem_e is not None:
+        if xb is not None or eb is not None or rem_x is None or rem_e is None:
+            raise UdsError('rem_x and rem_e come together, without xb / eb')
+        if tuple(rem_x.shape) != (S, N, h) or tuple(rem_e.shape) != (S, E, h):
+            raise UdsError('rem_x %r / rem_e %r must be %r / %r' % (tuple(rem_x.shape), tuple(rem_e.shape), (S, N, h), (S, E, h)))
+        _check(lib.uds_spatial_layer_forward_rem(net.ptr, ctypes.byref(sp), _dev(x, 'x'), fx, _dev(e, 'e'), fe, _dev(rem_x, 'rem_x'),
+                                                 _dev(rem_e, 'rem_e'), S, h, d, ACT[act], int(flags), _dev(ws, 'workspace'),
+                                                 _dev(out_x, 'out_x'), _dev(out_e, 'out_e'), _stream()), 'uds_spatial_layer_forward_rem')
+        return out_x, out_e
     if xb is not None or eb is not None:
         for t, ref, name in ((xb, x, 'xb'), (eb, e, 'eb')):
             if t is not None and tuple(t.shape[:2]) != tuple(ref.shape[:2]):

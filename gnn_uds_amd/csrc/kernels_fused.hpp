@@ -54,6 +54,9 @@ struct FusedSide {
   const uint4 *w_big32, *w_small32;      // both kernels as 32x32x16 A-operand fragments (k_pack_weight_frags32): k_fused_ws only, else NULL
   const float *b_small, *a_self, *a_nbr, *b_out, *ne_val;
   int n_prim_glob, n_sec_glob;
+  // k_fused_cs only, else NULL: (S, n_prim_glob, h) added to the NodeEdge aggregate of the primary rows -- the dense part of a
+  // trained NodeEdge, (bias off the incidence support) @ Dense(secondary rows), computed by uds_remainder_forward (emulator.py:36-45)
+  const float *rem;
 };
 
 struct FusedArgs {

@@ -38,6 +38,15 @@ inline int64_t fused128_lds_bytes(int p_cap, int q_cap, int meta_cap, int fp = F
   return fused_cs_lds_bytes(F128_D, p_cap, q_cap, meta_cap, fp, fs);
 }
 
+// 16 bytes per lane from base (wave-uniform) + voff (per-lane byte offset) + IMM, invisible to the compiler's vmcnt bookkeeping:
+// the value is there after the next wait_all_but() of the snapshot loop (the loads are older than the P3 stores it leaves
+// in flight), then f128_pin2 ties the registers to that point
+template <int IMM>
+__device__ __forceinline__ void f128_gld16(f32x4 &dst, const float *base, unsigned voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+}
+__device__ __forceinline__ void f128_pin2(f32x4 &a0, f32x4 &a1) { asm volatile("" : "+v"(a0), "+v"(a1)); }
+
 // FP / FS: widths of the primary / secondary input rows, 128 or 64 (the first layer of block 2 without actions has 128-wide
 // node rows [temporal output | boundary embedding] and 64-wide link rows, emulator.py:260-262)
 // D = embed size (128 with 8 waves; 64 with 16 waves: four waves per SIMD hide the LDS / MFMA latencies the 8-wave
@@ -143,10 +152,24 @@ __global__ __launch_bounds__(NW * 64) void k_fused_cs(FusedArgs a) {
     p3_dmax[u] = __builtin_amdgcn_readfirstlane(dmx);
   }
 
+  // The dense remainder of a trained NodeEdge (FusedSide::rem): P1.5's unit `wave` (one per wave: KT_A * nb_prim <= NW, checked by
+  // the host) adds its 8 floats per lane to the aggregate.  Loaded one snapshot ahead, right behind the primary rows' DMA.
+  const bool has_rem = S_.rem != nullptr && wave < KT_A * nb_prim;      // wave-uniform
+  f32x4 rm0 = f32x4{0.f, 0.f, 0.f, 0.f}, rm1 = rm0;
+  unsigned rem_off = 0;
+  if (has_rem) rem_off = (unsigned)((prim_ids[min((wave / KT_A) * 16 + r16, n_prim - 1)] * H + 32 * (wave % KT_A) + 4 * qd) * 4);
+  auto rem_issue = [&](int s) __attribute__((always_inline)) {
+    if (has_rem) {
+      const float *base = S_.rem + (int64_t)s * S_.n_prim_glob * H;
+      f128_gld16<0>(rm0, base, rem_off);
+      f128_gld16<64>(rm1, base, rem_off);
+    }
+  };
   const int s_begin = chunk_id * a.chunk, s_end = min(a.S, (chunk_id + 1) * a.chunk);
   if (s_begin < s_end) {
     dma_sec_all(s_begin);
     dma_prim_all(s_begin);
+    rem_issue(s_begin);
   }
   // everything below overlaps with the first snapshot's DMA
   for (int i = tid; i < n_inc; i += NT) reinterpret_cast<float *>(inc_w)[i] = S_.ne_val[inc_w[i]];
@@ -181,6 +204,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused_cs(FusedArgs a) {
 
   for (int s = s_begin; s < s_end; ++s) {
     wait_all_but(n_st);       // this wave's DMA pieces of snapshot s have landed (the P3 stores are younger)
+    f128_pin2(rm0, rm1);      // ... and its remainder piece
     UDS_STAMP128(1);
     // ---------------- P0: raw fp32 rows -> bf16 hi / lo fragments, in place, by the wave that fetched them ----------------
     auto split_block = [&](auto KT_, float *stage, int blk) {
@@ -247,6 +271,10 @@ __global__ __launch_bounds__(NW * 64) void k_fused_cs(FusedArgs a) {
         g0.x = fmaf(wv, u0.x, g0.x); g0.y = fmaf(wv, u0.y, g0.y); g0.z = fmaf(wv, u0.z, g0.z); g0.w = fmaf(wv, u0.w, g0.w);
         g1.x = fmaf(wv, u1.x, g1.x); g1.y = fmaf(wv, u1.y, g1.y); g1.z = fmaf(wv, u1.z, g1.z); g1.w = fmaf(wv, u1.w, g1.w);
       }
+      if (has_rem) {          // unit == wave
+        g0.x += rm0[0]; g0.y += rm0[1]; g0.z += rm0[2]; g0.w += rm0[3];
+        g1.x += rm1[0]; g1.y += rm1[1]; g1.z += rm1[2]; g1.w += rm1[3];
+      }
       bf16x8 hi, lo;
       split8(g0, g1, hi, lo);
       float4 *dst = reinterpret_cast<float4 *>(aggf + unit * 512) + lane;
@@ -311,7 +339,10 @@ __global__ __launch_bounds__(NW * 64) void k_fused_cs(FusedArgs a) {
     UDS_STAMP128(8);
     lds_barrier();
     UDS_STAMP128(9);
-    if (s + 1 < s_end) dma_prim_all(s + 1);       // the primary fragments are consumed
+    if (s + 1 < s_end) {      // the primary fragments are consumed
+      dma_prim_all(s + 1);
+      rem_issue(s + 1);
+    }
     // ---------------- P3: segmented softmax + neighbour sum -> HBM (16 lanes x CH float4 per output row) ----------------
     n_st = 0;
     {

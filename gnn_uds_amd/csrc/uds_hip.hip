@@ -1049,10 +1049,31 @@ int uds_spatial_layer_forward(const uds_network_t *net, const uds_spatial_params
   return uds_spatial_layer_forward_split(net, p, x, fx, nullptr, 0, e, fe, nullptr, 0, S, h, d, act, flags, ws, out_x, out_e, stream);
 }
 
+static int spatial_forward_impl(const uds_network_t *net, const uds_spatial_params_t *p, const float *x, int64_t fxa,
+                                const float *xb, int64_t fxb, const float *e, int64_t fea, const float *eb, int64_t feb,
+                                const float *rem_x, const float *rem_e, int64_t S, int64_t h, int64_t d, int act, int flags,
+                                float *ws, float *out_x, float *out_e, uds_stream_t stream);
+
 int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_params_t *p, const float *x, int64_t fxa,
                                     const float *xb, int64_t fxb, const float *e, int64_t fea, const float *eb, int64_t feb,
                                     int64_t S, int64_t h, int64_t d, int act, int flags, float *ws, float *out_x, float *out_e,
                                     uds_stream_t stream) {
+  return spatial_forward_impl(net, p, x, fxa, xb, fxb, e, fea, eb, feb, nullptr, nullptr, S, h, d, act, flags, ws, out_x, out_e, stream);
+}
+
+int uds_spatial_layer_forward_rem(const uds_network_t *net, const uds_spatial_params_t *p, const float *x, int64_t fx,
+                                  const float *e, int64_t fe, const float *rem_x, const float *rem_e, int64_t S, int64_t h,
+                                  int64_t d, int act, int flags, float *ws, float *out_x, float *out_e, uds_stream_t stream) {
+  UDS_REQUIRE(rem_x && rem_e, "uds_spatial_layer_forward_rem: NULL remainder");
+  UDS_REQUIRE(aligned16(rem_x) && aligned16(rem_e), "uds_spatial_layer_forward_rem: rem_x / rem_e must be 16-byte aligned");
+  return spatial_forward_impl(net, p, x, fx, nullptr, 0, e, fe, nullptr, 0, rem_x, rem_e, S, h, d, act, flags | UDS_FLAG_REQUIRE_FUSED, ws,
+                              out_x, out_e, stream);
+}
+
+static int spatial_forward_impl(const uds_network_t *net, const uds_spatial_params_t *p, const float *x, int64_t fxa,
+                                const float *xb, int64_t fxb, const float *e, int64_t fea, const float *eb, int64_t feb,
+                                const float *rem_x, const float *rem_e, int64_t S, int64_t h, int64_t d, int act, int flags,
+                                float *ws, float *out_x, float *out_e, uds_stream_t stream) {
   UDS_REQUIRE(net && p && x && e && ws && out_x && out_e, "uds_spatial_layer_forward: NULL argument");
   UDS_REQUIRE((xb != nullptr) == (fxb > 0) && (eb != nullptr) == (feb > 0), "uds_spatial_layer_forward_split: xb/fxb or eb/feb disagree");
   UDS_REQUIRE((!xb || (fxa == 64 && fxb == 32)) && (!eb || (fea == 64 && feb == 32)),
@@ -1090,8 +1111,8 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
     }
     uds::FusedArgs a;
     a.blocks = nullptr;
-    a.side[0] = uds::FusedSide{x, e, nullptr, nullptr, out_x, wq, wq + 2048, nullptr, nullptr, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
-    a.side[1] = uds::FusedSide{e, x, nullptr, nullptr, out_e, wq + 8192, wq + 10240, nullptr, nullptr, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};
+    a.side[0] = uds::FusedSide{x, e, nullptr, nullptr, out_x, wq, wq + 2048, nullptr, nullptr, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E, rem_x};
+    a.side[1] = uds::FusedSide{e, x, nullptr, nullptr, out_e, wq + 8192, wq + 10240, nullptr, nullptr, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N, rem_e};
     a.S = (int)S;
     a.act = act;
     a.dbg = nullptr;
@@ -1106,6 +1127,7 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
       a.q_cap = u.plan.q_cap;
       a.meta_cap = u.plan.meta_cap;
       a.side_mask = side < 0 ? 3 : (1 << side);
+      if ((rem_x || rem_e) && a.p_cap > 64) return hipErrorInvalidValue;      // one P1.5 unit per wave (kernels_fused128.hpp)
       int64_t chunk = S, best = INT64_MAX;
       for (int64_t c = 1; c <= S; ++c) {
         const int64_t rounds = (((S + c - 1) / c) * a.n_tiles + 255) / 256;
@@ -1131,6 +1153,8 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
     if (he != hipSuccess) return fail(UDS_EHIP, "uds_spatial_layer_forward: fused d=128 launch -> %s", hipGetErrorString(he));
     return UDS_OK;
   }
+  UDS_REQUIRE(!rem_x && !rem_e, "uds_spatial_layer_forward_rem: only the d = 128 fused kernel takes the remainder (fx=%lld fe=%lld h=%lld d=%lld, plan %d)",
+              (long long)fxa, (long long)fea, (long long)h, (long long)d, (int)(net->slot[4].ok));
   // (rows of one snapshot are addressed with a 32-bit byte offset from a per-snapshot base: N, E < 2^31 / 384)
   const bool shape_ok = h == uds::FUSED_H && d == uds::FUSED_D && (fx == 64 || fx == 96) && (fe == 64 || fe == 96) &&
                         std::max(N, E) * 384 < ((int64_t)1 << 31);

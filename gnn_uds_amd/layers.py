@@ -505,6 +505,14 @@ class SpatialLayer(nn.Module):
             self._packed = (key, _lib.spatial_pack_weights(p, fx, fe, self.h, self.d), aug)
         return self._packed[1], self._packed[2]
 
+    def _d128_remainder_ok(self, xs, es, xbs, ebs):
+        if not (self.precision == 'bf16x3' and self.h == 64 and self.d == 128 and xs.shape[-1] == 128 and es.shape[-1] in (64, 128)
+                and xbs is None and ebs is None):
+            return False
+        net = self.network()
+        net.prepare(128, es.shape[-1])
+        return bool(net.plan_info()['fused'] & (8 if es.shape[-1] == 128 else 16))
+
     def network(self):
         if self._net is None:
             self._net = _lib.NetworkHandle(self.graph)
@@ -611,6 +619,15 @@ class SpatialLayer(nn.Module):
                 net.prepare(96, 96)
                 ox, oe = _lib.spatial_layer_forward(net, dict(p, packed=packed, **aug), xs, es, self.h, self.d, self.activation,
                                                     _lib.PRECISION_FLAGS[self.precision], xb=rem_n, eb=rem_e)
+                self.last_path = 'fused+remainder'
+            elif self._d128_remainder_ok(xs, es, xbs, ebs):
+                # the reference's stock model after training (embed_size 128, dense bias): the remainder is added to the support
+                # aggregate inside the column-split kernel (uds_spatial_layer_forward_rem)
+                rem_n = self.node_edge_n.remainder(x_e) if rest_n is not None else torch.zeros_like(e_x)
+                rem_e = self.node_edge_e.remainder(e_x) if rest_e is not None else torch.zeros_like(x_e)
+                packed = self._packed_weights(p, 128, es.shape[-1])[0]
+                ox, oe = _lib.spatial_layer_forward(net, dict(p, packed=packed), xs, es, self.h, self.d, self.activation,
+                                                    _lib.PRECISION_FLAGS[self.precision], rem_x=rem_n, rem_e=rem_e)
                 self.last_path = 'fused+remainder'
             else:
                 ox = self.gat_x([xs, net.adj], xb=self.node_edge_n(x_e))

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 18
+#define UDS_ABI_VERSION 19
 
 enum {
   UDS_OK = 0,
@@ -389,6 +389,17 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
                                     int64_t fxa, const float *xb, int64_t fxb, const float *ea, int64_t fea,
                                     const float *eb, int64_t feb, int64_t S, int64_t h, int64_t d, int act, int flags,
                                     float *workspace, float *out_x, float *out_e, uds_stream_t stream);
+
+/* The same layer for a TRAINED NodeEdge at the reference's default width (h = 64, d = 128, fx = 128, fe = 128 or 64).  The
+ * reference's layer is matmul(w * inci + b, x) with a dense trainable b (emulator.py:36-45): after training b is non-zero
+ * off the incidence support, and that part, rem_x = (b_n off the support) @ Dense_xe(e) (S,N,h) and rem_e = (b_e off the
+ * support) @ Dense_ex(x) (S,E,h), is a dense GEMM (uds_remainder_forward).  Here it is added to the support aggregate inside
+ * the fused kernel (one 64-float row per primary row and snapshot, prefetched one snapshot ahead).  Fused kernel only:
+ * UDS_EINVAL when the shape or the network's plan does not take it. */
+int uds_spatial_layer_forward_rem(const uds_network_t *net, const uds_spatial_params_t *params, const float *x, int64_t fx,
+                                  const float *e, int64_t fe, const float *rem_x, const float *rem_e, int64_t S, int64_t h,
+                                  int64_t d, int act, int flags, float *workspace, float *out_x, float *out_e,
+                                  uds_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -196,13 +196,15 @@ def test_network_forward_mlp_baseline(dev, networks, over):
                                                           seq_in=6, seq_out=2))
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
-def test_network_forward_trained_node_edge_bias(dev, networks, precision):
+@pytest.mark.parametrize('precision,embed', [('fp32', 64), ('bf16x3', 64), ('bf16x3', 128)])
+def test_network_forward_trained_node_edge_bias(dev, networks, precision, embed):
     """The whole network with reference-TRAINED NodeEdge layers (dense bias non-zero off the incidence support, emulator.py:36-45)
     in every spatial layer: 64-wide layers on the fused kernel with the remainder GEMM, the 96-wide first layer of block 2
     (`concat([x, b])`, :260-262) on the unfused chain with the same GEMM -- against the dense oracle, which simply multiplies
     the full (N, E) matrices."""
-    args, params, emul, _ = _setup(networks, 'shunqing', dev, precision=precision, n_sp_layer=2, n_tp_layer=1, seq_in=4, seq_out=3)
+    # embed 128 / hidden 64 = the reference's default sizes (utils/config.yaml:39): the stock model after training
+    args, params, emul, _ = _setup(networks, 'shunqing', dev, precision=precision, n_sp_layer=2, n_tp_layer=1, seq_in=4, seq_out=3,
+                                   embed_size=embed, hidden_dim=64)
     g = torch.Generator().manual_seed(17)
     for blk in ('block1', 'block2'):
         for q in params[blk]:
@@ -217,7 +219,10 @@ def test_network_forward_trained_node_edge_bias(dev, networks, precision):
     close(y, ry, TOL_FWD[precision]); close(ey, rey, TOL_FWD[precision])
     paths = [ly.last_path for ly in emul.block1.layers] + [ly.last_path for ly in emul.block2.layers]
     if precision == 'bf16x3':
-        assert paths == ['fused+remainder', 'fused+remainder', 'unfused', 'fused+remainder'], paths
+        # d = 64: the 96-wide first layer of block 2 already uses the split-input slot the remainder rides in -> unfused; d = 128: that
+        # layer is 128 wide like the others, and the column-split kernel takes the remainder beside its rows
+        first_b2 = 'unfused' if embed == 64 else 'fused+remainder'
+        assert paths == ['fused+remainder', 'fused+remainder', first_b2, 'fused+remainder'], paths
     # and the bias matters: the same inputs through the support-only model differ visibly
     for blk in ('block1', 'block2'):
         for q in params[blk]:
@@ -660,7 +665,7 @@ def test_save_load_and_not_built(dev, networks, tmp_path):
     other.load(str(tmp_path))
     y1, e1 = other.predict_tf(f(X), f(Bd), f(a), f(Ex))
     assert torch.equal(y0, y1) and torch.equal(e0, e1)
-    for bad in (dict(conv='General'), dict(recurrent='Transformer'), dict(dropout=0.2), dict(conv='GCN', use_adj=True)):
+    for bad in (dict(conv='General'), dict(recurrent='Transformer'), dict(conv='GCN', use_adj=True)):
         from types import SimpleNamespace
         a2 = SimpleNamespace(**{**vars(args), **bad})
         with pytest.raises(NotImplementedError):
