@@ -162,4 +162,177 @@ __global__ __launch_bounds__(256, 2) void k_remainder_gemm(const __bf16 *__restr
 #undef UDS_GEMM_STORE
 #undef UDS_GEMM_STORE1
 
+// ---- second form of the same GEMM (round 3): LDS-DMA staging, 256-row block tiles, 8 waves ------------------------------------
+// What bounded k_remainder_gemm (128 x 128, register staging): every k-step moved 4 planes x 16 KB from L2 through 64 VGPRs and
+// 16 ds_write_b128 per thread into LDS -- 0.0104 B of L2 traffic per MFMA flop (10 TB/s at its 0.96 PF, against the 17-19 TB/s
+// the L2s deliver into LDS, MI355X_MICROARCH.md 'Indexed rows'), an LDS store for every LDS load byte, two barriers per step.
+// Here: block tile 256 (X rows) x BN (W rows, 256 or 128) per 512-thread workgroup; k-steps of 32 fetched by
+// global_load_lds_dwordx4 straight into a double-buffered LDS image (no staging registers, no LDS stores); one barrier per
+// step; wave tile (256 / WRN) x 64.  L2 bytes per flop: (2/3) (1/256 + 1/BN) = 0.0052 (BN 256) / 0.0078 (BN 128).
+// LDS image of one buffer: [Xh | Xl | Wh | Wl] planes of 16-row blocks of 1 KiB (a row = 32 bf16 = 4 chunks of 16 B); chunk c of
+// row r sits at position c ^ F[(r & 15) >> 2], F = {0, 3, 2, 1}: the 16 lanes ds_read_b128 serves per LDS cycle -- rows 0-3 and
+// 12-15 of k-chunk q, rows 4-11 of chunk q ^ 1 -- then cover the sixteen 16-B slots of the 256-B bank row once.  A DMA piece is
+// a block: lane l fetches the chunk that belongs at position l & 3 of row l >> 2 (the swizzle is applied on the GLOBAL side:
+// LDS-DMA writes lane l's 16 bytes at piece + 16 l).
+template <int WRN>
+struct Gemm2Cfg {
+  static constexpr int BM = 256, NWC = 8 / WRN, BN = 64 * NWC;              // waves: WRN along X rows x NWC along W rows
+  static constexpr int TI = BM / WRN / 16;                                   // 16-row X tiles per wave (8, 4 or 2); W tiles per wave: 4
+  static constexpr int XI = TI < 4 ? TI : 4;                                 // X tiles whose fragments are held at a time
+  static constexpr int X_PLANE = BM * 64, W_PLANE = BN * 64;                 // bytes of one plane of one buffer
+  static constexpr int BUF = 2 * X_PLANE + 2 * W_PLANE;                      // 64 KiB (BN 256) / 48 KiB (BN 128)
+  static constexpr int LDS_BYTES = 2 * BUF;
+};
+
+__device__ __forceinline__ void gemm2_dma(const __bf16 *base, unsigned voff, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(base), "s"(lds_byte)
+               : "memory");
+}
+
+template <int WRN>
+__global__ __launch_bounds__(512) void k_remainder_gemm2(const __bf16 *__restrict__ Xh, const __bf16 *__restrict__ Xl,
+                                                         const __bf16 *__restrict__ Wh, const __bf16 *__restrict__ Wl, int64_t Nc, int64_t R,
+                                                         int64_t Kp, int h, int n_ctile, float *__restrict__ out, int tile_base, int ksplit,
+                                                         float *__restrict__ partial) {
+  // The tiles that fill whole rounds of 256 workgroups are computed whole (results straight to `out`); the remaining ones are cut
+  // along K into ksplit pieces each so that they fill one more (partial) round: their accumulators go to `partial` in register
+  // order and k_remainder_gemm2_reduce adds the pieces in a fixed order (uds_remainder_forward).
+  using C = Gemm2Cfg<WRN>;
+  constexpr int64_t r_base = 0;
+  const int64_t r_lim = R;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds2[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / C::NWC, wc = wave % C::NWC;
+  // workgroups [0, tile_base): whole tiles, straight to `out`; [tile_base, gridDim.x): the cut tiles, ksplit pieces each, in the
+  // SAME launch so that they start as the whole tiles finish (two launches serialise on the first one's ragged end).
+  // XCD-aware order inside each part as in k_remainder_gemm (tile_base is a multiple of 256).
+  const bool cut = (int)blockIdx.x >= tile_base;
+  const int nblk = cut ? (int)gridDim.x - tile_base : tile_base, b = cut ? (int)blockIdx.x - tile_base : (int)blockIdx.x;
+  const int q8 = nblk / 8, r8 = nblk % 8, xcd = b % 8;
+  const int wi = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+  const int w = cut ? tile_base + wi / ksplit : wi, piece = cut ? wi % ksplit : 0;
+  if (!cut) ksplit = 1;
+  const int64_t c0 = (int64_t)(w % n_ctile) * C::BM, r0 = r_base + (int64_t)(w / n_ctile) * C::BN;
+  // DMA duty of this wave: X blocks 2 wave, 2 wave + 1 and W blocks NWB wave + {0, ..} (while there are any) of both planes
+  constexpr int NXB = 2, WBLK = C::BN / 16, NWB = (WBLK + 7) / 8;
+  const int d_row = lane >> 2, d_pos = lane & 3;
+  const int d_chunk = d_pos ^ ((4 - (lane >> 4)) & 3);                     // F[(row & 15) >> 2] with row = lane >> 2
+  unsigned xvoff[NXB], wvoff[NWB];
+#pragma unroll
+  for (int i = 0; i < NXB; ++i)      // rows past the matrix are clamped (their results are not stored); host: Nc * Kp * 2 < 2^32
+    xvoff[i] = (unsigned)(min(c0 + 16 * (NXB * wave + i) + d_row, Nc - 1) * Kp * 2 + d_chunk * 16);
+#pragma unroll
+  for (int i = 0; i < NWB; ++i)
+    wvoff[i] = (unsigned)(min(r0 + 16 * (NWB * wave + i) + d_row, r_lim - 1) * Kp * 2 + d_chunk * 16);
+  const unsigned lds0 = lds_addr(lds2);
+  auto issue = [&](int64_t kt) __attribute__((always_inline)) {
+    const unsigned buf = lds0 + (unsigned)(kt & 1) * C::BUF;
+    const int64_t ko = kt * 32;                                             // bf16 elements
+#pragma unroll
+    for (int i = 0; i < NXB; ++i) {
+      gemm2_dma(Xh + ko, xvoff[i], buf + (NXB * wave + i) * 1024);
+      gemm2_dma(Xl + ko, xvoff[i], buf + C::X_PLANE + (NXB * wave + i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < NWB; ++i)
+      if (NWB * wave + i < WBLK) {
+        gemm2_dma(Wh + ko, wvoff[i], buf + 2 * C::X_PLANE + (NWB * wave + i) * 1024);
+        gemm2_dma(Wl + ko, wvoff[i], buf + 2 * C::X_PLANE + C::W_PLANE + (NWB * wave + i) * 1024);
+      }
+  };
+  f32x4 acc[C::TI][4];
+#pragma unroll
+  for (int i = 0; i < C::TI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, q = lane >> 4;
+  const int f_off = fr * 64 + ((q ^ ((4 - (fr >> 2)) & 3)) << 4);          // this lane's 16 bytes inside a 1-KiB block
+  const unsigned char *xbase = lds2 + (C::TI * wr) * 1024 + f_off;
+  const unsigned char *wbase = lds2 + 2 * C::X_PLANE + (4 * wc) * 1024 + f_off;
+  const int64_t n_k_all = Kp / 32, k_beg = n_k_all * piece / ksplit, n_k = n_k_all * (piece + 1) / ksplit;
+  // (buffer = parity of the absolute k-step: consistent between issue() and the reads below)
+  issue(k_beg);
+  for (int64_t kt = k_beg; kt < n_k; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of step kt have landed
+    __syncthreads();                                         // ... everybody's have, and everybody is done reading the other buffer
+    if (kt + 1 < n_k) issue(kt + 1);
+    const int bo = (int)(kt & 1) * C::BUF;
+    bf16x8 wh[4], wl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      wh[j] = *reinterpret_cast<const bf16x8 *>(wbase + bo + j * 1024);
+      wl[j] = *reinterpret_cast<const bf16x8 *>(wbase + bo + C::W_PLANE + j * 1024);
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < C::TI; i0 += C::XI) {
+      bf16x8 xh[C::XI], xl[C::XI];
+#pragma unroll
+      for (int i = 0; i < C::XI; ++i) {
+        xh[i] = *reinterpret_cast<const bf16x8 *>(xbase + bo + (i0 + i) * 1024);
+        xl[i] = *reinterpret_cast<const bf16x8 *>(xbase + bo + C::X_PLANE + (i0 + i) * 1024);
+      }
+#pragma unroll
+      for (int i = 0; i < C::XI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i0 + i][j] = mfma3(xh[i], xl[i], wh[j], wl[j], acc[i0 + i][j]);
+    }
+  }
+  if (cut) {          // piece `piece` of cut tile wi / ksplit: [(piece, tile)][i][j][thread] float4
+    const int n_t = nblk / ksplit;
+    f32x4 *dst = reinterpret_cast<f32x4 *>(partial) + ((int64_t)piece * n_t + wi / ksplit) * (C::TI * 4 * 512) + tid;
+#pragma unroll
+    for (int i = 0; i < C::TI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dst[(i * 4 + j) * 512] = acc[i][j];
+    return;
+  }
+  // D[row = 4 (lane >> 4) + e][col = lane & 15] of tile (i, j): result column c = c0 + 16 (TI wr + i) + 4 (lane >> 4) + e
+  // (= snapshot c / h, feature c % h), result row r = r0 + 64 wc + 16 j + (lane & 15): four consecutive features per lane
+#pragma unroll
+  for (int i = 0; i < C::TI; ++i) {
+    const int64_t c = c0 + (C::TI * wr + i) * 16 + (lane >> 4) * 4;
+    if (c >= Nc) continue;
+    const int64_t s = c / h, f = c - s * h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t r = r0 + wc * 64 + j * 16 + (lane & 15);
+      if (r < r_lim) *reinterpret_cast<f32x4 *>(out + (s * R + r) * h + f) = acc[i][j];
+    }
+  }
+}
+
+// Sum of the ksplit accumulator pieces of the cut tiles (tile t of the n_t of that launch = tile tile_base + t of the matrix), in
+// piece order, stored as k_remainder_gemm2's own epilogue would (same thread -> element mapping).
+template <int WRN>
+__global__ __launch_bounds__(512) void k_remainder_gemm2_reduce(const float *__restrict__ partial, int ksplit, int tile_base, int64_t Nc, int64_t R,
+                                                                int h, int n_ctile, float *__restrict__ out) {
+  using C = Gemm2Cfg<WRN>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / C::NWC, wc = wave % C::NWC;
+  const int t = blockIdx.x, n_t = gridDim.x, w = tile_base + t;
+  const int64_t c0 = (int64_t)(w % n_ctile) * C::BM, r0 = (int64_t)(w / n_ctile) * C::BN;
+  const f32x4 *src = reinterpret_cast<const f32x4 *>(partial) + (int64_t)t * (C::TI * 4 * 512) + tid;
+#pragma unroll
+  for (int i = 0; i < C::TI; ++i) {
+    const int64_t c = c0 + (C::TI * wr + i) * 16 + (lane >> 4) * 4;
+    if (c >= Nc) continue;
+    const int64_t s = c / h, f = c - s * h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t r = r0 + wc * 64 + j * 16 + (lane & 15);
+      if (r >= R) continue;
+      f32x4 v = src[(i * 4 + j) * 512];
+      for (int p = 1; p < ksplit; ++p) {
+        const f32x4 u = src[(int64_t)p * n_t * (C::TI * 4 * 512) + (i * 4 + j) * 512];
+        v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+      }
+      *reinterpret_cast<f32x4 *>(out + (s * R + r) * h + f) = v;
+    }
+  }
+}
+
 }  // namespace uds

@@ -410,6 +410,7 @@ int uds_rowgemm_pack(const float *W, int64_t k_total, int64_t f_out, void *packe
 }
 
 static int64_t pad_k(int64_t k) { return (k + 63) / 64 * 64; }      // the remainder GEMM's k-step
+constexpr int REMAINDER_MAX_PIECES = 512;      // (tile, K piece) pairs of the cut tiles of k_remainder_gemm2: at most two rounds of workgroups
 
 int64_t uds_remainder_packed_bytes(int64_t R, int64_t M) {
   if (R <= 0 || M <= 0) return 0;
@@ -431,7 +432,8 @@ int uds_remainder_pack(const float *rest, int64_t R, int64_t M, void *packed, ud
 
 int64_t uds_remainder_workspace_bytes(int64_t M, int64_t S, int64_t h) {
   if (M <= 0 || S <= 0 || h <= 0) return 0;
-  return 2 * S * h * pad_k(M) * 2;
+  // the split activation planes + the accumulator pieces of the K-cut tiles (at most REMAINDER_MAX_PIECES of 256 x 256 floats)
+  return 2 * S * h * pad_k(M) * 2 + (int64_t)REMAINDER_MAX_PIECES * 256 * 256 * 4;
 }
 
 int uds_remainder_forward(const void *packed, int64_t R, int64_t M, const float *x, int64_t S, int64_t h, void *workspace, float *out,
@@ -448,10 +450,54 @@ int uds_remainder_forward(const void *packed, int64_t R, int64_t M, const float 
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(uds::k_split_transpose_bf16, dim3((unsigned)(Kp / 64 + (Kp % 64 != 0)), (unsigned)S), dim3(256), 0, st, x, M, (int)h, Kp,
                      xh, xl);
-  const int64_t n_ctile = (Nc + 127) / 128, n_rtile = (R + 127) / 128;
-  hipLaunchKernelGGL(uds::k_remainder_gemm, dim3((unsigned)(n_ctile * n_rtile)), dim3(256), 0, st, xh, xl, wh, wl, Nc, R, Kp, (int)h,
-                     (int)n_ctile, out);
-  hipError_t e = hipGetLastError();
+  hipError_t e = hipSuccess;
+  // k_remainder_gemm2<2> (256 x 256 tiles, LDS-DMA staged, one 8-wave workgroup per CU): the tiles that fill whole rounds of 256
+  // workgroups go out as they are; the rest are cut along K into ks pieces each so that they fill (most of) one more round, their
+  // accumulators land in the workspace behind the activation planes and a third launch adds the pieces in a fixed order
+  bool v2 = Nc * Kp * 2 < ((int64_t)1 << 32) && R * Kp * 2 < ((int64_t)1 << 32) && Nc >= 256 && R >= 128;
+#ifdef UDS_GEMM_V1
+  v2 = false;
+#endif
+  if (v2) {
+    using C = uds::Gemm2Cfg<2>;
+    static unsigned long long done = 0;
+    if ((e = uds::set_max_lds_once(reinterpret_cast<const void *>(&uds::k_remainder_gemm2<2>), C::LDS_BYTES, done)) != hipSuccess)
+      return fail(UDS_EHIP, "uds_remainder_forward: LDS attribute -> %s", hipGetErrorString(e));
+    const int64_t n_ctile = (Nc + 255) / 256, tiles = n_ctile * ((R + 255) / 256);
+    int64_t t_main = tiles / 256 * 256, t_rest = tiles - t_main;
+    int64_t ks = 1;
+    if (t_rest) {      // pieces per cut tile: the fewest rounds-of-256 per piece length, ties to the fewer pieces (each piece = 256 KB out and back)
+      double best = 1e300;
+      for (int64_t k = 1; k <= std::min<int64_t>({(int64_t)REMAINDER_MAX_PIECES / t_rest, 8, Kp / 32 / 8}); ++k) {
+        const double cost = (double)((t_rest * k + 255) / 256) / (double)k + 0.01 * (double)k;
+        if (cost < best - 1e-9) {
+          best = cost;
+          ks = k;
+        }
+      }
+    }
+#ifdef UDS_KNOBS
+    if (const char *ov = std::getenv("UDS_GEMM_KS")) ks = std::max<int64_t>(1, std::min<int64_t>(std::atoll(ov), REMAINDER_MAX_PIECES / std::max<int64_t>(1, t_rest)));
+#endif
+    if (ks == 1) {
+      t_main = tiles;
+      t_rest = 0;
+    }
+    float *partial = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + 2 * Nc * Kp * 2);
+    hipLaunchKernelGGL(uds::k_remainder_gemm2<2>, dim3((unsigned)(t_main + t_rest * ks)), dim3(512), C::LDS_BYTES, st, xh, xl, wh, wl, Nc, R, Kp, (int)h,
+                       (int)n_ctile, out, (int)t_main, (int)ks, partial);
+    if (t_rest)
+      hipLaunchKernelGGL(uds::k_remainder_gemm2_reduce<2>, dim3((unsigned)t_rest), dim3(512), 0, st, partial, (int)ks, (int)t_main, Nc, R, (int)h,
+                         (int)n_ctile, out);
+    if ((e = hipGetLastError()) != hipSuccess) return fail(UDS_EHIP, "uds_remainder_forward: launch -> %s", hipGetErrorString(e));
+    return UDS_OK;
+  }
+  {
+    const int64_t n_ctile = (Nc + 127) / 128, n_rtile = (R + 127) / 128;
+    hipLaunchKernelGGL(uds::k_remainder_gemm, dim3((unsigned)(n_ctile * n_rtile)), dim3(256), 0, st, xh, xl, wh, wl, Nc, R, Kp, (int)h,
+                       (int)n_ctile, out);
+  }
+  e = hipGetLastError();
   if (e != hipSuccess) return fail(UDS_EHIP, "uds_remainder_forward: launch -> %s", hipGetErrorString(e));
   return UDS_OK;
 }
