@@ -229,20 +229,21 @@ __global__ __launch_bounds__(512) void k_remainder_gemm2(const __bf16 *__restric
   for (int i = 0; i < NWB; ++i)
     wvoff[i] = (unsigned)(min(r0 + 16 * (NWB * wave + i) + d_row, r_lim - 1) * Kp * 2 + d_chunk * 16);
   const unsigned lds0 = lds_addr(lds2);
-  auto issue = [&](int64_t kt) __attribute__((always_inline)) {
+  // part p of this wave's DMA duty for k-step kt: p < NXB -> X block p (both planes), else W block p - NXB
+  auto issue_part = [&](int64_t kt, int p) __attribute__((always_inline)) {
     const unsigned buf = lds0 + (unsigned)(kt & 1) * C::BUF;
     const int64_t ko = kt * 32;                                             // bf16 elements
-#pragma unroll
-    for (int i = 0; i < NXB; ++i) {
-      gemm2_dma(Xh + ko, xvoff[i], buf + (NXB * wave + i) * 1024);
-      gemm2_dma(Xl + ko, xvoff[i], buf + C::X_PLANE + (NXB * wave + i) * 1024);
+    if (p < NXB) {
+      gemm2_dma(Xh + ko, xvoff[p], buf + (NXB * wave + p) * 1024);
+      gemm2_dma(Xl + ko, xvoff[p], buf + C::X_PLANE + (NXB * wave + p) * 1024);
+    } else if (p - NXB < NWB && NWB * wave + (p - NXB) < WBLK) {
+      gemm2_dma(Wh + ko, wvoff[p - NXB], buf + 2 * C::X_PLANE + (NWB * wave + p - NXB) * 1024);
+      gemm2_dma(Wl + ko, wvoff[p - NXB], buf + 2 * C::X_PLANE + C::W_PLANE + (NWB * wave + p - NXB) * 1024);
     }
+  };
+  auto issue = [&](int64_t kt) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < NWB; ++i)
-      if (NWB * wave + i < WBLK) {
-        gemm2_dma(Wh + ko, wvoff[i], buf + 2 * C::X_PLANE + (NWB * wave + i) * 1024);
-        gemm2_dma(Wl + ko, wvoff[i], buf + 2 * C::X_PLANE + C::W_PLANE + (NWB * wave + i) * 1024);
-      }
+    for (int p = 0; p < NXB + NWB; ++p) issue_part(kt, p);
   };
   f32x4 acc[C::TI][4];
 #pragma unroll
@@ -259,7 +260,10 @@ __global__ __launch_bounds__(512) void k_remainder_gemm2(const __bf16 *__restric
   for (int64_t kt = k_beg; kt < n_k; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of step kt have landed
     __syncthreads();                                         // ... everybody's have, and everybody is done reading the other buffer
-    if (kt + 1 < n_k) issue(kt + 1);
+    // The next step's pieces are issued BEHIND the first tile rows' MFMAs, one part per tile row: a DMA instruction holds the
+    // wave at issue for 100+ cycles under load, and issued right here (as at first) eight of them kept the matrix pipe idle at
+    // the start of every step; behind the MFMAs the pipe works through them meanwhile.
+    const bool more = kt + 1 < n_k;
     const int bo = (int)(kt & 1) * C::BUF;
     bf16x8 wh[4], wl[4];
 #pragma unroll
@@ -276,9 +280,20 @@ __global__ __launch_bounds__(512) void k_remainder_gemm2(const __bf16 *__restric
         xl[i] = *reinterpret_cast<const bf16x8 *>(xbase + bo + C::X_PLANE + (i0 + i) * 1024);
       }
 #pragma unroll
-      for (int i = 0; i < C::XI; ++i)
+      for (int i = 0; i < C::XI; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i0 + i][j] = mfma3(xh[i], xl[i], wh[j], wl[j], acc[i0 + i][j]);
+        if (i0 == 0 && i < NXB + NWB) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) issue_part(kt + 1, i);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (C::XI < NXB + NWB) {      // (wave tiles of fewer than four tile rows: the parts not issued above)
+#pragma unroll
+      for (int p = C::XI; p < NXB + NWB; ++p)
+        if (more) issue_part(kt + 1, p);
     }
   }
   if (cut) {          // piece `piece` of cut tile wi / ksplit: [(piece, tile)][i][j][thread] float4
