@@ -111,9 +111,9 @@ def rollout_autoregressive(U, dev, steps=100):
 def trained_bias_leg(U, g, args, dev, x, e, reps=5):
     """The same block with the reference's trained form of NodeEdge: dense (R, M) weight and bias, the bias non-zero off the
     incidence support (reference emulator.py:36-45 -- what every checkpoint the reference trains looks like).  Per layer:
-    secondary MLPs on the row-GEMM kernel, `rest @ x_e` on the split-bf16 MFMA GEMM (k_remainder_gemm), the rest in the fused
-    kernel's 96-wide variant with the remainder as 32 extra input columns (d = 64) or in the column-split kernel, which adds the
-    remainder to its NodeEdge aggregate (d = 128, uds_spatial_layer_forward_rem)."""
+    secondary MLPs on the row-GEMM kernel, `rest @ x_e` on the split-bf16 MFMA GEMM (k_remainder_gemm2), the rest in the fused
+    kernel, which adds the remainder to its NodeEdge aggregate (uds_spatial_layer_forward_rem: k_fused_ws at d = 64, the
+    column-split kernel at d = 128)."""
     d, L, S = args.embed, args.layers, args.snapshots
     blk = U.SpatialBlock(g, d, L, 'relu', sparse_params=False, generator=torch.Generator().manual_seed(1), precision=args.precision).to(dev)
     with torch.no_grad():
@@ -152,7 +152,7 @@ def trained_bias_leg(U, g, args, dev, x, e, reps=5):
     lib_ms = (time.perf_counter() - t0) / reps * 1e3
     del la, lb
     return {'value': L * S / (ms * 1e-3), 'unit': 'graph-steps/s', 'ms_per_step': ms, 'path': [ly.last_path for ly in blk.layers],
-            'remainder_gemm': {'kernel': 'k_remainder_gemm (128x128 tiles, split-bf16, 3 MFMA products)', 'ms': gemm_ms,
+            'remainder_gemm': {'kernel': 'k_remainder_gemm2 (256x256 tiles, LDS-DMA staged, split-bf16, 3 MFMA products; incl. activation split + K-cut reduce)', 'ms': gemm_ms,
                                'shape': '(%d x %d) @ (%d x %d)' % (g.n_node, g.n_edge, g.n_edge, S * (d // 2)),
                                'tflops_fp32_equivalent': flops / gemm_ms / 1e9, 'tflops_bf16_issued': 3 * flops / gemm_ms / 1e9,
                                'bound': 'mfma', 'peak_tflops_bf16': 2500.0, 'frac': 3 * flops / gemm_ms / 1e9 / 2500.0,

@@ -225,6 +225,12 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
     const int lr = min(lrow, n_prim - 1);
     const unsigned prow = (unsigned)prim_ids[lr] * FP + 8u * hf;      // element offset of this lane's 8-float piece of k-step 0
     f32x4 pp[2 * KX32];           // the primary row of the snapshot P2 multiplies next: piece i = floats 16 (i >> 1) + 8 hf + 4 (i & 1)
+    // the dense remainder of a trained NodeEdge (FusedSide::rem, (S, n_prim_glob, 32)): this lane's 16 aggregate features of its
+    // row, fetched with the row itself one interval ahead and used as the initial value of the aggregate
+    const bool has_rem = S_.rem != nullptr;
+    const unsigned rrow = (unsigned)prim_ids[lr] * FUSED_H + 8u * hf;
+    f32x4 rm[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const int64_t rem_stride = (int64_t)S_.n_prim_glob * FUSED_H;
     const unsigned ag_locs = inc_loc[lr];
     const f32x4 ag_vals = inc_val4[lr];
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): drain the set-up loads on every path (see the X team's note)
@@ -234,6 +240,13 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
         constexpr int i = decltype(i_)::value;
         pp[i] = *reinterpret_cast<const f32x4 *>(base + prow + 16 * (i >> 1) + 4 * (i & 1));
       });
+      if (has_rem) {
+        const float *rb = S_.rem + s_begin * rem_stride + rrow;
+        rm[0] = *reinterpret_cast<const f32x4 *>(rb);
+        rm[1] = *reinterpret_cast<const f32x4 *>(rb + 4);
+        rm[2] = *reinterpret_cast<const f32x4 *>(rb + 16);
+        rm[3] = *reinterpret_cast<const f32x4 *>(rb + 20);
+      }
     }
     WS_STAMP(0);
     lds_barrier();      // the X team has computed the secondary MLP of the first snapshot
@@ -276,7 +289,15 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
 #pragma unroll
           for (int m = 0; m < MB32; ++m) acc[m] = mfma3_32(wh[t][m], wl[t][m], dh[t], dl[t], acc[m]);
         // NodeEdge aggregate of this row in fragment shape: features 8 hf .. + 7 (k-step 4) and 16 + 8 hf .. + 7 (k-step 5)
-        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0, g3 = g0;
+        float4 g0 = make_float4(rm[0][0], rm[0][1], rm[0][2], rm[0][3]), g1 = make_float4(rm[1][0], rm[1][1], rm[1][2], rm[1][3]),
+               g2 = make_float4(rm[2][0], rm[2][1], rm[2][2], rm[2][3]), g3 = make_float4(rm[3][0], rm[3][1], rm[3][2], rm[3][3]);
+        if (more && has_rem) {      // consumed: the next snapshot's remainder piece
+          const float *rb = S_.rem + (s_begin + k + 1) * rem_stride + rrow;
+          rm[0] = *reinterpret_cast<const f32x4 *>(rb);
+          rm[1] = *reinterpret_cast<const f32x4 *>(rb + 4);
+          rm[2] = *reinterpret_cast<const f32x4 *>(rb + 16);
+          rm[3] = *reinterpret_cast<const f32x4 *>(rb + 20);
+        }
         auto fma4 = [&](float4 &g, float wv, const float4 &u) { g.x = fmaf(wv, u.x, g.x); g.y = fmaf(wv, u.y, g.y); g.z = fmaf(wv, u.z, g.z); g.w = fmaf(wv, u.w, g.w); };
         auto add_row = [&](unsigned la, float wa) {
           const float *ra = secr + la * SEC_STRIDE + 8 * hf;

@@ -1199,7 +1199,8 @@ static int spatial_forward_impl(const uds_network_t *net, const uds_spatial_para
     if (he != hipSuccess) return fail(UDS_EHIP, "uds_spatial_layer_forward: fused d=128 launch -> %s", hipGetErrorString(he));
     return UDS_OK;
   }
-  UDS_REQUIRE(!rem_x && !rem_e, "uds_spatial_layer_forward_rem: only the d = 128 fused kernel takes the remainder (fx=%lld fe=%lld h=%lld d=%lld, plan %d)",
+  UDS_REQUIRE((!rem_x && !rem_e) || (h == uds::FUSED_H && d == uds::FUSED_D && fxa == 64 && fea == 64),
+              "uds_spatial_layer_forward_rem: the remainder goes into the d = 128 fused kernel or the 64-wide d = 64 one (fx=%lld fe=%lld h=%lld d=%lld, plan %d)",
               (long long)fxa, (long long)fea, (long long)h, (long long)d, (int)(net->slot[4].ok));
   // (rows of one snapshot are addressed with a 32-bit byte offset from a per-snapshot base: N, E < 2^31 / 384)
   const bool shape_ok = h == uds::FUSED_H && d == uds::FUSED_D && (fx == 64 || fx == 96) && (fe == 64 || fe == 96) &&
@@ -1228,8 +1229,8 @@ static int spatial_forward_impl(const uds_network_t *net, const uds_spatial_para
     uds::FusedArgs a;
     a.blocks = nullptr;
     const bool has32 = fx == 64 && fe == 64;
-    a.side[0] = uds::FusedSide{x, e, xb, eb, out_x, w_small_n, w_big_n, has32 ? wq + WS_BIG32_OFF : nullptr, has32 ? wq + WS_SMALL32_OFF : nullptr, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E};
-    a.side[1] = uds::FusedSide{e, x, eb, xb, out_e, w_small_e, w_big_e, has32 ? wq + WS_BIG32_OFF + WS_BIG32_LEN : nullptr, has32 ? wq + WS_SMALL32_OFF + WS_SMALL32_LEN : nullptr, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N};
+    a.side[0] = uds::FusedSide{x, e, xb, eb, out_x, w_small_n, w_big_n, has32 ? wq + WS_BIG32_OFF : nullptr, has32 ? wq + WS_SMALL32_OFF : nullptr, p->xe_b, p->gx_as, p->gx_an, p->gx_b, p->ne_n_val, (int)N, (int)E, rem_x};
+    a.side[1] = uds::FusedSide{e, x, eb, xb, out_e, w_small_e, w_big_e, has32 ? wq + WS_BIG32_OFF + WS_BIG32_LEN : nullptr, has32 ? wq + WS_SMALL32_OFF + WS_SMALL32_LEN : nullptr, p->ex_b, p->ge_as, p->ge_an, p->ge_b, p->ne_e_val, (int)E, (int)N, rem_e};
     int64_t lds_need = 0;
     auto use_plan = [&](const uds_plan_slot &u, int side) {     // side < 0: both sides (merged tile list), else that side's tiles only
       a.hdr = side < 0 ? u.d_hdr : u.d_hdr_side[side];
@@ -1277,6 +1278,8 @@ static int spatial_forward_impl(const uds_network_t *net, const uds_spatial_para
 #ifdef UDS_NO_WS
       ws = false;
 #endif
+      UDS_REQUIRE(ws || (!rem_x && !rem_e), "uds_spatial_layer_forward_rem: the wave-specialised d = 64 kernel cannot take this network's plan (p_cap %d, q_cap %d, %lld B of LDS)",
+                  a.p_cap, a.q_cap, (long long)ws_lds);
       if (ws) he = launch_fused_ws(a, grid, ws_lds, st);
       else he = (fx == 64) ? launch_fused<64, 64>(a, grid, lds_need, st) : launch_fused<96, 96>(a, grid, lds_need, st);
     } else {   // node tiles: FP = fx, FS = fe; link tiles: FP = fe, FS = fx -> one launch per side

@@ -615,10 +615,21 @@ class SpatialLayer(nn.Module):
                     and xbs is None and ebs is None:
                 rem_n = self.node_edge_n.remainder(x_e) if rest_n is not None else torch.zeros_like(e_x)
                 rem_e = self.node_edge_e.remainder(e_x) if rest_e is not None else torch.zeros_like(x_e)
-                packed, aug = self._packed_weights(p, 96, 96, remainder=True)
-                net.prepare(96, 96)
-                ox, oe = _lib.spatial_layer_forward(net, dict(p, packed=packed, **aug), xs, es, self.h, self.d, self.activation,
-                                                    _lib.PRECISION_FLAGS[self.precision], xb=rem_n, eb=rem_e)
+                ox = None
+                if getattr(self, '_ws_rem_ok', True):
+                    # the wave-specialised kernel adds the remainder to its NodeEdge aggregate (uds_spatial_layer_forward_rem); it
+                    # refuses plans whose tiles it cannot hold -- then the 96-wide split-input kernel below carries the remainder
+                    try:
+                        net.prepare(64, 64)
+                        ox, oe = _lib.spatial_layer_forward(net, dict(p, packed=self._packed_weights(p, 64, 64)[0]), xs, es, self.h, self.d,
+                                                            self.activation, _lib.PRECISION_FLAGS[self.precision], rem_x=rem_n, rem_e=rem_e)
+                    except _lib.UdsError:
+                        self._ws_rem_ok = False
+                if ox is None:
+                    packed, aug = self._packed_weights(p, 96, 96, remainder=True)
+                    net.prepare(96, 96)
+                    ox, oe = _lib.spatial_layer_forward(net, dict(p, packed=packed, **aug), xs, es, self.h, self.d, self.activation,
+                                                        _lib.PRECISION_FLAGS[self.precision], xb=rem_n, eb=rem_e)
                 self.last_path = 'fused+remainder'
             elif self._d128_remainder_ok(xs, es, xbs, ebs):
                 # the reference's stock model after training (embed_size 128, dense bias): the remainder is added to the support

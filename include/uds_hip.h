@@ -391,12 +391,12 @@ int uds_spatial_layer_forward_split(const uds_network_t *net, const uds_spatial_
                                     const float *eb, int64_t feb, int64_t S, int64_t h, int64_t d, int act, int flags,
                                     float *workspace, float *out_x, float *out_e, uds_stream_t stream);
 
-/* The same layer for a TRAINED NodeEdge at the reference's default width (h = 64, d = 128, fx = 128, fe = 128 or 64).  The
- * reference's layer is matmul(w * inci + b, x) with a dense trainable b (emulator.py:36-45): after training b is non-zero
- * off the incidence support, and that part, rem_x = (b_n off the support) @ Dense_xe(e) (S,N,h) and rem_e = (b_e off the
- * support) @ Dense_ex(x) (S,E,h), is a dense GEMM (uds_remainder_forward).  Here it is added to the support aggregate inside
- * the fused kernel (one 64-float row per primary row and snapshot, prefetched one snapshot ahead).  Fused kernel only:
- * UDS_EINVAL when the shape or the network's plan does not take it. */
+/* The same layer for a TRAINED NodeEdge: h = 64, d = 128, fx = 128, fe = 128 or 64 (the reference's default width) or h = 32,
+ * d = 64, fx = fe = 64.  The reference's layer is matmul(w * inci + b, x) with a dense trainable b (emulator.py:36-45): after
+ * training b is non-zero off the incidence support, and that part, rem_x = (b_n off the support) @ Dense_xe(e) (S,N,h) and
+ * rem_e = (b_e off the support) @ Dense_ex(x) (S,E,h), is a dense GEMM (uds_remainder_forward).  Here it is added to the
+ * support aggregate inside the fused kernel (one h-float row per primary row and snapshot, prefetched one snapshot ahead).
+ * Fused kernel only: UDS_EINVAL when the shape or the network's tile plan does not take it. */
 int uds_spatial_layer_forward_rem(const uds_network_t *net, const uds_spatial_params_t *params, const float *x, int64_t fx,
                                   const float *e, int64_t fe, const float *rem_x, const float *rem_e, int64_t S, int64_t h,
                                   int64_t d, int act, int flags, float *workspace, float *out_x, float *out_e,

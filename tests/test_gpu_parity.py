@@ -200,6 +200,15 @@ def test_spatial_layer_vs_dense_masked_oracle(dev, networks, name, d, S, precisi
     close(ox, rx, tol); close(oe, re, tol)
     # (d = 128, the reference's default width: the remainder is added to the aggregate inside the column-split kernel, uds_spatial_layer_forward_rem)
     assert layer.last_path == ('fused+remainder' if d in (64, 128) and precision == 'bf16x3' else 'unfused')
+    if d == 64 and precision == 'bf16x3':
+        # d = 64 has two carriers for the remainder: the wave-specialised kernel adds it to its aggregate (the call above); the
+        # 96-wide split-input kernel takes it as 32 extra input columns (the fallback for tile plans the first one refuses)
+        assert getattr(layer, '_ws_rem_ok', True)
+        layer._ws_rem_ok = False
+        ox2, oe2 = layer(x.float().to(dev), e.float().to(dev))
+        close(ox2, rx, tol); close(oe2, re, tol)
+        assert layer.last_path == 'fused+remainder'
+        layer._ws_rem_ok = True
     p['ne_e_b'] = torch.zeros_like(p['ne_e_b'])        # trained on the node side only
     rx, re = OD.spatial_layer_dense(x, e, p, torch.from_numpy(gph.adj.to_dense()), torch.from_numpy(gph.edge_adj.to_dense()), ne)
     load_spatial_layer(layer, p, dev)
