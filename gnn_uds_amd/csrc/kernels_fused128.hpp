@@ -199,6 +199,23 @@ __global__ __launch_bounds__(NW * 64) void k_fused_cs(FusedArgs a) {
       wbl[t][m] = __builtin_bit_cast(bf16x8, S_.w_big[((t * MB_B + MPW * cs + m) * 2 + 1) * 64 + lane]);
     }
   __syncthreads();
+  // P1.5 operands of this wave's first unit (see there): NodeEdge values are in LDS since the barrier above
+  unsigned ag_locs = 0;
+  f32x4 ag_vals = f32x4{0.f, 0.f, 0.f, 0.f};
+  int ag_beg = 0, ag_end = 0;
+  bool ag_wide = false;
+  if (wave < KT_A * nb_prim) {
+    const int lr = min((wave / KT_A) * 16 + r16, n_prim - 1);
+    ag_beg = inc_ptr[lr];
+    ag_end = inc_ptr[lr + 1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (ag_beg + k < ag_end) {
+        ag_locs |= (unsigned)inc_loc[ag_beg + k] << (8 * k);      // local secondary rows: q_cap <= 255
+        ag_vals[k] = inc_val[ag_beg + k];
+      }
+    ag_wide = __any(ag_end - ag_beg > 2);
+  }
   int n_st = 0;
   UDS_STAMP128(0);
 
@@ -258,18 +275,33 @@ __global__ __launch_bounds__(NW * 64) void k_fused_cs(FusedArgs a) {
     lds_barrier();
     UDS_STAMP128(5);
     if (s + 1 < s_end) dma_sec_all(s + 1);        // the secondary fragments are consumed: fetch the next snapshot's rows
+    // (issued from inside P2, behind its first block's MFMAs, the issue time of these DMA instructions -- ~700 cycles per wave and
+    // snapshot -- just moves there: the launch takes the same time)
     // ---------------- P1.5: NodeEdge aggregation of the primary rows -> fragments (block wave/2, k-step wave&1) ----------------
     for (int unit = wave; unit < KT_A * nb_prim; unit += NW) {
       const int blk = unit / KT_A, half = unit % KT_A;
       const int lr = min(blk * 16 + r16, n_prim - 1);
       float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
-      for (int p = inc_ptr[lr]; p < inc_ptr[lr + 1]; ++p) {
-        const float wv = inc_val[p];
-        const float *row = sec + inc_loc[p] * SECS + 32 * half + 4 * qd;
+      auto add_row = [&](int loc, float wv) __attribute__((always_inline)) {
+        const float *row = sec + loc * SECS + 32 * half + 4 * qd;
         const float4 u0 = *reinterpret_cast<const float4 *>(row);
         const float4 u1 = *reinterpret_cast<const float4 *>(row + 16);
         g0.x = fmaf(wv, u0.x, g0.x); g0.y = fmaf(wv, u0.y, g0.y); g0.z = fmaf(wv, u0.z, g0.z); g0.w = fmaf(wv, u0.w, g0.w);
         g1.x = fmaf(wv, u1.x, g1.x); g1.y = fmaf(wv, u1.y, g1.y); g1.z = fmaf(wv, u1.z, g1.z); g1.w = fmaf(wv, u1.w, g1.w);
+      };
+      if (unit == wave) {
+        // the wave's first unit (its only one when KT_A * nb_prim <= NW): the first four (row, weight) pairs of the lane's row are
+        // static per tile and sit in registers -- four independent pairs of LDS reads per snapshot instead of a loop of dependent
+        // (weight, index, row) reads per entry, which was 13 % of the kernel for ~1 % of its arithmetic
+        add_row((int)(ag_locs & 0xffu), ag_vals[0]);
+        add_row((int)((ag_locs >> 8) & 0xffu), ag_vals[1]);
+        if (ag_wide) {      // wave-uniform: some row of the unit has more than two entries
+          add_row((int)((ag_locs >> 16) & 0xffu), ag_vals[2]);
+          add_row((int)(ag_locs >> 24), ag_vals[3]);
+        }
+        for (int p = ag_beg + 4; p < ag_end; ++p) add_row(inc_loc[p], inc_val[p]);
+      } else {
+        for (int p = inc_ptr[lr]; p < inc_ptr[lr + 1]; ++p) add_row(inc_loc[p], inc_val[p]);
       }
       if (has_rem) {          // unit == wave
         g0.x += rm0[0]; g0.y += rm0[1]; g0.z += rm0[2]; g0.w += rm0[3];
