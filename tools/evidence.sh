@@ -23,8 +23,8 @@ cat $O/${T}_pmc_summary.txt
 # d = 128 (the reference's default width): bench + FETCH / WRITE passes
 python bench.py --embed 128 --layers 2 --no-cpu-baseline > $O/${T}_d128_bench.json 2>> $O/bench.err
 echo "d128 bench done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/pmc4 -- python3 bench.py --embed 128 --layers 2 --steps 5 --warmup 1 --no-cpu-baseline > $O/pmc4.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc5 -- python3 bench.py --embed 128 --layers 2 --steps 5 --warmup 1 --no-cpu-baseline > $O/pmc5.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/pmc4 -- python3 bench.py --embed 128 --layers 2 --steps 5 --warmup 1 --no-cpu-baseline --no-trained-bias > $O/pmc4.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc5 -- python3 bench.py --embed 128 --layers 2 --steps 5 --warmup 1 --no-cpu-baseline --no-trained-bias > $O/pmc5.log 2>&1
 python tools/pmc_summary.py "k_fused_cs<128, 128, 128" $O/pmc4 $O/pmc5 > $O/${T}_d128_pmc_summary.txt
 rm -rf $O/pmc4 $O/pmc5
 cat $O/${T}_d128_pmc_summary.txt
