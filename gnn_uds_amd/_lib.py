@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # UDS_LIB_PATH: a differently built copy of the same library (kernel experiments: tools/variant_bench.py)
 LIB_PATH = os.environ.get('UDS_LIB_PATH') or os.path.join(_HERE, 'libuds_hip.so')
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
 PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
 
@@ -54,7 +54,7 @@ SYMBOLS = {
     'uds_halo_unpack': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr]),
     'uds_remainder_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
     'uds_remainder_pack': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
-    'uds_remainder_workspace_bytes': (_c_i64, [_c_i64, _c_i64, _c_i64]),
+    'uds_remainder_workspace_bytes': (_c_i64, [_c_i64, _c_i64, _c_i64, _c_i64]),
     'uds_remainder_forward': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr]),
     'uds_rowgemm_forward': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_rowgemm_forward_pair': (_c_int, [_c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64,
@@ -555,7 +555,7 @@ def remainder_forward(packed, shape, x):
     if S == 0:
         _dev(x, 'x')
         return out
-    ws = torch.empty(lib.uds_remainder_workspace_bytes(M, S, h) // 4, device=x.device, dtype=torch.float32)
+    ws = torch.empty(lib.uds_remainder_workspace_bytes(R, M, S, h) // 4, device=x.device, dtype=torch.float32)
     _check(lib.uds_remainder_forward(packed.data_ptr(), R, M, _dev(x, 'x'), S, h, ws.data_ptr(), _dev(out, 'out'), _stream()),
            'uds_remainder_forward')
     return out

@@ -430,10 +430,51 @@ int uds_remainder_pack(const float *rest, int64_t R, int64_t M, void *packed, ud
   return UDS_OK;
 }
 
-int64_t uds_remainder_workspace_bytes(int64_t M, int64_t S, int64_t h) {
-  if (M <= 0 || S <= 0 || h <= 0) return 0;
-  // the split activation planes + the accumulator pieces of the K-cut tiles (at most REMAINDER_MAX_PIECES of 256 x 256 floats)
-  return 2 * S * h * pad_k(M) * 2 + (int64_t)REMAINDER_MAX_PIECES * 256 * 256 * 4;
+namespace {
+// How uds_remainder_forward tiles (R x Kp) x (Nc x Kp): k_remainder_gemm2<2> (256 x 256 tiles, one 8-wave workgroup per CU) when
+// the shape has at least one tile's worth of columns; the tiles that fill whole rounds of 256 workgroups go out as they are, the
+// rest are cut along K into ks pieces each so that they fill (most of) one more round.
+struct RemainderPlan {
+  bool v2;
+  int64_t n_ctile, t_main, t_rest, ks;
+};
+RemainderPlan remainder_plan(int64_t R, int64_t Nc, int64_t Kp) {
+  RemainderPlan q{false, 0, 0, 0, 1};
+  q.v2 = Nc * Kp * 2 < ((int64_t)1 << 32) && R * Kp * 2 < ((int64_t)1 << 32) && Nc >= 256 && R >= 128;
+#ifdef UDS_GEMM_V1
+  q.v2 = false;
+#endif
+  if (!q.v2) return q;
+  q.n_ctile = (Nc + 255) / 256;
+  const int64_t tiles = q.n_ctile * ((R + 255) / 256);
+  q.t_main = tiles / 256 * 256;
+  q.t_rest = tiles - q.t_main;
+  if (q.t_rest) {      // pieces per cut tile: the fewest rounds-of-256 per piece length, ties to the fewer pieces (each piece = 256 KB out and back)
+    double best = 1e300;
+    for (int64_t k = 1; k <= std::min<int64_t>({(int64_t)REMAINDER_MAX_PIECES / q.t_rest, 8, Kp / 32 / 8}); ++k) {
+      const double cost = (double)((q.t_rest * k + 255) / 256) / (double)k + 0.01 * (double)k;
+      if (cost < best - 1e-9) {
+        best = cost;
+        q.ks = k;
+      }
+    }
+  }
+#ifdef UDS_KNOBS
+  if (const char *ov = std::getenv("UDS_GEMM_KS")) q.ks = std::max<int64_t>(1, std::min<int64_t>(std::atoll(ov), REMAINDER_MAX_PIECES / std::max<int64_t>(1, q.t_rest)));
+#endif
+  if (q.ks == 1) {
+    q.t_main = tiles;
+    q.t_rest = 0;
+  }
+  return q;
+}
+}  // namespace
+
+int64_t uds_remainder_workspace_bytes(int64_t R, int64_t M, int64_t S, int64_t h) {
+  if (R <= 0 || M <= 0 || S <= 0 || h <= 0) return 0;
+  // the split activation planes + the accumulator pieces of the K-cut tiles (256 x 256 floats each)
+  const RemainderPlan q = remainder_plan(R, S * h, pad_k(M));
+  return 2 * S * h * pad_k(M) * 2 + (q.v2 ? q.t_rest * q.ks * 256 * 256 * 4 : 0);
 }
 
 int uds_remainder_forward(const void *packed, int64_t R, int64_t M, const float *x, int64_t S, int64_t h, void *workspace, float *out,
@@ -454,35 +495,13 @@ int uds_remainder_forward(const void *packed, int64_t R, int64_t M, const float 
   // k_remainder_gemm2<2> (256 x 256 tiles, LDS-DMA staged, one 8-wave workgroup per CU): the tiles that fill whole rounds of 256
   // workgroups go out as they are; the rest are cut along K into ks pieces each so that they fill (most of) one more round, their
   // accumulators land in the workspace behind the activation planes and a third launch adds the pieces in a fixed order
-  bool v2 = Nc * Kp * 2 < ((int64_t)1 << 32) && R * Kp * 2 < ((int64_t)1 << 32) && Nc >= 256 && R >= 128;
-#ifdef UDS_GEMM_V1
-  v2 = false;
-#endif
-  if (v2) {
+  const RemainderPlan plan = remainder_plan(R, Nc, Kp);
+  if (plan.v2) {
     using C = uds::Gemm2Cfg<2>;
     static unsigned long long done = 0;
     if ((e = uds::set_max_lds_once(reinterpret_cast<const void *>(&uds::k_remainder_gemm2<2>), C::LDS_BYTES, done)) != hipSuccess)
       return fail(UDS_EHIP, "uds_remainder_forward: LDS attribute -> %s", hipGetErrorString(e));
-    const int64_t n_ctile = (Nc + 255) / 256, tiles = n_ctile * ((R + 255) / 256);
-    int64_t t_main = tiles / 256 * 256, t_rest = tiles - t_main;
-    int64_t ks = 1;
-    if (t_rest) {      // pieces per cut tile: the fewest rounds-of-256 per piece length, ties to the fewer pieces (each piece = 256 KB out and back)
-      double best = 1e300;
-      for (int64_t k = 1; k <= std::min<int64_t>({(int64_t)REMAINDER_MAX_PIECES / t_rest, 8, Kp / 32 / 8}); ++k) {
-        const double cost = (double)((t_rest * k + 255) / 256) / (double)k + 0.01 * (double)k;
-        if (cost < best - 1e-9) {
-          best = cost;
-          ks = k;
-        }
-      }
-    }
-#ifdef UDS_KNOBS
-    if (const char *ov = std::getenv("UDS_GEMM_KS")) ks = std::max<int64_t>(1, std::min<int64_t>(std::atoll(ov), REMAINDER_MAX_PIECES / std::max<int64_t>(1, t_rest)));
-#endif
-    if (ks == 1) {
-      t_main = tiles;
-      t_rest = 0;
-    }
+    const int64_t n_ctile = plan.n_ctile, t_main = plan.t_main, t_rest = plan.t_rest, ks = plan.ks;
     float *partial = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + 2 * Nc * Kp * 2);
     hipLaunchKernelGGL(uds::k_remainder_gemm2<2>, dim3((unsigned)(t_main + t_rest * ks)), dim3(512), C::LDS_BYTES, st, xh, xl, wh, wl, Nc, R, Kp, (int)h,
                        (int)n_ctile, out, (int)t_main, (int)ks, partial);

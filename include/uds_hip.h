@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 19
+#define UDS_ABI_VERSION 20
 
 enum {
   UDS_OK = 0,
@@ -183,11 +183,11 @@ int uds_halo_unpack(const float *buf, int64_t S, int64_t F, const int32_t *idx_x
  * split-bf16 (three products, fp32 accumulation):
  *   out[s, r, :] = sum_m rest[r, m] * x[s, m, :]        x (S, M, h), out (S, R, h), h % 4 == 0, h <= 64.
  * `packed` = uds_remainder_pack(rest), uds_remainder_packed_bytes(R, M) bytes, once per parameter update; `workspace` =
- * uds_remainder_workspace_bytes(M, S, h) bytes of scratch per call (the transposed bf16 image of x, and 128 MiB for the
- * accumulator pieces of the tiles k_remainder_gemm2 cuts along K). */
+ * uds_remainder_workspace_bytes(R, M, S, h) bytes of scratch per call (the transposed bf16 image of x, and the accumulator
+ * pieces of the tiles k_remainder_gemm2 cuts along K: at most 128 MiB). */
 int64_t uds_remainder_packed_bytes(int64_t R, int64_t M);
 int uds_remainder_pack(const float *rest, int64_t R, int64_t M, void *packed, uds_stream_t stream);
-int64_t uds_remainder_workspace_bytes(int64_t M, int64_t S, int64_t h);
+int64_t uds_remainder_workspace_bytes(int64_t R, int64_t M, int64_t S, int64_t h);
 int uds_remainder_forward(const void *packed, int64_t R, int64_t M, const float *x, int64_t S, int64_t h, void *workspace,
                           float *out, uds_stream_t stream);
 

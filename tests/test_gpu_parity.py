@@ -250,7 +250,9 @@ def test_spatial_layer_with_per_snapshot_adjacency(dev, networks, precision):
 @pytest.mark.parametrize('R,M,S,h', [(1, 1, 1, 4), (130, 77, 3, 32), (257, 300, 5, 32), (64, 1000, 2, 64), (300, 129, 7, 12),
                                      # the LDS-DMA staged form (k_remainder_gemm2; S * h >= 256 and R >= 128): 256 x 128 tiles with ragged
                                      # edges on both sides, two k-steps / one k-step / many, and a shape whose round count picks 256 x 256 tiles
-                                     (130, 64, 8, 32), (1000, 777, 9, 32), (443, 444, 5, 64), (129, 31, 37, 12), (8192, 300, 64, 32)])
+                                     (130, 64, 8, 32), (1000, 777, 9, 32), (443, 444, 5, 64), (129, 31, 37, 12), (8192, 300, 64, 32),
+                                     # 272 tiles: one whole round of 256 + 16 tiles cut along K into four pieces each, in one launch + the reduce
+                                     (8704, 1000, 64, 32)])
 def test_remainder_gemm_ragged_shapes(dev, R, M, S, h):
     """uds_remainder_forward (the dense off-support part of a trained NodeEdge, emulator.py:44) against the fp64 product:
     shapes that are not multiples of the 128 x 128 (or 256 x 128 / 256 x 256) tile, of the k-step of 32, or of one snapshot per tile
