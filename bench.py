@@ -358,15 +358,37 @@ def bench_small(args, U, dev):
             for a_, b_ in ev:
                 a_.record(); layer(x, e); b_.record()
             torch.cuda.synchronize()
-            ms = float(np.median([a_.elapsed_time(b_) for a_, b_ in ev]))
-            info = layer.network().plan_info()
+            ms_eager = float(np.median([a_.elapsed_time(b_) for a_, b_ in ev]))
+            # the same call as a captured HIP graph (what a rollout on a small network replays, Emulator.rollout_graphed /
+            # SpatialBlock.graphed): the eager figure of a 30-node network is the host's launch path, not the kernel
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side), torch.no_grad():
+                layer(x, e)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph), torch.no_grad():
+                layer(x, e)
+            graph.replay()
+            torch.cuda.synchronize()
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_.record()
+            for _ in range(20):
+                graph.replay()
+            b_.record()
+            torch.cuda.synchronize()
+            ms = a_.elapsed_time(b_) / 20
+            k = layer.pack_factor() if S >= 16 * layer.pack_factor() else 1
+            info = (layer._replica(k) if k > 1 else layer.network()).plan_info()
             bytes_gs = algorithmic_bytes_per_graph_step(g, d, d)
             achieved = S * bytes_gs / (ms * 1e-3) / 1e9
             tiles = info['node_tiles'] + info['link_tiles']
             legs.append({'network': name, 'nodes': g.n_node, 'links': g.n_edge, 'd': d, 'snapshots': S, 'ms_per_launch': ms,
+                         'ms_per_launch_eager': ms_eager, 'launch': 'replay of a captured HIP graph (eager: one C-ABI call from Python)',
                          'graph_steps_per_s': S / (ms * 1e-3), 'achieved_GBps': achieved, 'frac': achieved / HBM_PEAK_GBPS,
-                         'path': layer.last_path, 'tiles': tiles, 'p_cap': info['p_cap'], 'q_cap': info['q_cap'],
-                         'rows_per_tile': (g.n_node + g.n_edge) / max(1, tiles)})
+                         'frac_eager': S * bytes_gs / (ms_eager * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         'path': layer.last_path, 'snapshots_side_by_side': k, 'tiles': tiles, 'p_cap': info['p_cap'], 'q_cap': info['q_cap'],
+                         'rows_per_tile': k * (g.n_node + g.n_edge) / max(1, tiles)})
     print(json.dumps({'metric': 'graph-steps/sec, one spatial layer on the reference\'s shipped networks (30-443 nodes), S=%d snapshots' % S,
                       'unit': 'graph-steps/s', 'n_gpus': 1, 'dtype': 'f32 storage/accumulate, GEMM operands as bf16 hi+lo split',
                       'data': 'link lists of the five shipped networks, synthetic features', 'legs': legs}))
