@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # UDS_LIB_PATH: a differently built copy of the same library (kernel experiments: tools/variant_bench.py)
 LIB_PATH = os.environ.get('UDS_LIB_PATH') or os.path.join(_HERE, 'libuds_hip.so')
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
 PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
 
@@ -49,6 +49,7 @@ SYMBOLS = {
     'uds_rowgemm_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
     'uds_rowgemm_pack': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
     'uds_gat_aggregate_masked': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
+    'uds_gat_aggregate_coef': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_diffusion_forward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_halo_pack': (_c_int, [_c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_ptr]),
     'uds_halo_unpack': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr]),
@@ -70,6 +71,8 @@ SYMBOLS = {
     'uds_gat_aggregate': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_gat_backward': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr,
                                   _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
+    'uds_gat_backward_coef': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr,
+                                       _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'uds_csr_sddmm': (_c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
     'uds_wgrad_workspace_floats': (_c_i64, [_c_i64, _c_i64, _c_i64, _c_int]),
     'uds_wgrad': (_c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
@@ -765,11 +768,23 @@ def gat_forward(handle, xa, kernel, a_self, a_nbr, bias=None, act='relu', xb=Non
     return out
 
 
-def gat_aggregate(handle, hx, s_self, s_nbr, bias=None, act='relu', edge_mask=None):
+def gat_aggregate(handle, hx, s_self, s_nbr, bias=None, act='relu', edge_mask=None, coef=None):
     """Attention softmax + neighbour sum of a GATConv from precomputed hx (S,n,d), s_self / s_nbr (S,n).
-    edge_mask (S, nnz): per-snapshot 0/1 over the pattern's entries (`use_adj`; the diagonal always takes part)."""
+    edge_mask (S, nnz): per-snapshot 0/1 over the pattern's entries (`use_adj`; the diagonal always takes part).
+    coef (S, nnz): multiplier of the normalised coefficients (Spektral's attention dropout in training, uds_gat_aggregate_coef)."""
     lib = load()
     S, n, d = hx.shape
+    if coef is not None:
+        if edge_mask is not None:
+            raise UdsError('gat_aggregate: edge_mask and coef together are not built')
+        if tuple(coef.shape) != (S, handle.nnz) or n != handle.n_rows or tuple(s_self.shape) != (S, n) or tuple(s_nbr.shape) != (S, n):
+            raise UdsError('gat_aggregate: coef %r / hx %r for %d snapshots of a %d-row, %d-entry pattern' %
+                           (tuple(coef.shape), tuple(hx.shape), S, handle.n_rows, handle.nnz))
+        out = torch.empty_like(hx)
+        if out.numel():
+            _check(lib.uds_gat_aggregate_coef(handle.ptr, _dev(hx, 'hx'), _dev(s_self, 's_self'), _dev(s_nbr, 's_nbr'), _dev(bias, 'bias', True),
+                                              _dev(coef, 'coef'), S, d, ACT[act], _dev(out, 'out'), _stream()), 'uds_gat_aggregate_coef')
+        return out
     if edge_mask is not None:
         if tuple(edge_mask.shape) != (S, handle.nnz):
             raise UdsError('gat_aggregate: edge_mask %r for %d snapshots of a %d-entry pattern' % (tuple(edge_mask.shape), S, handle.nnz))
@@ -793,9 +808,9 @@ def gat_aggregate(handle, hx, s_self, s_nbr, bias=None, act='relu', edge_mask=No
     return out
 
 
-def gat_backward(handle, handle_t, perm_t, grad, hx, s_self, s_nbr, a_self, a_nbr):
+def gat_backward(handle, handle_t, perm_t, grad, hx, s_self, s_nbr, a_self, a_nbr, coef=None):
     """Reverse mode of the attention / aggregation part of gat_forward (uds_gat_backward): grad = dL/d(pre-activation)
-    (S,n,d) -> d_hx (S,n,d), ds_self (S,n), ds_nbr (S,n)."""
+    (S,n,d) -> d_hx (S,n,d), ds_self (S,n), ds_nbr (S,n).  coef: the attention-dropout multiplier of the forward pass, if any."""
     lib = load()
     S, n, d = grad.shape
     d_hx = torch.empty_like(grad)
@@ -805,10 +820,10 @@ def gat_backward(handle, handle_t, perm_t, grad, hx, s_self, s_nbr, a_self, a_nb
         _dev(grad, 'grad')
         return d_hx, ds_self, ds_nbr
     ws = torch.empty((2, S, max(handle.nnz, 1)), device=grad.device, dtype=torch.float32)
-    _check(lib.uds_gat_backward(handle.ptr, handle_t.ptr, _dev_i32(perm_t, 'perm_t'), _dev(grad, 'grad'), _dev(hx, 'hx'),
-                                _dev(s_self, 's_self'), _dev(s_nbr, 's_nbr'), _dev(a_self, 'a_self'), _dev(a_nbr, 'a_nbr'),
-                                S, d, _dev(ws[0], 'alpha_ws'), _dev(ws[1], 'de_ws'), _dev(d_hx, 'd_hx'),
-                                _dev(ds_self, 'ds_self'), _dev(ds_nbr, 'ds_nbr'), _stream()), 'uds_gat_backward')
+    _check(lib.uds_gat_backward_coef(handle.ptr, handle_t.ptr, _dev_i32(perm_t, 'perm_t'), _dev(grad, 'grad'), _dev(hx, 'hx'),
+                                     _dev(s_self, 's_self'), _dev(s_nbr, 's_nbr'), _dev(a_self, 'a_self'), _dev(a_nbr, 'a_nbr'),
+                                     _dev(coef, 'coef', True), S, d, _dev(ws[0], 'alpha_ws'), _dev(ws[1], 'de_ws'), _dev(d_hx, 'd_hx'),
+                                     _dev(ds_self, 'ds_self'), _dev(ds_nbr, 'ds_nbr'), _stream()), 'uds_gat_backward_coef')
     return d_hx, ds_self, ds_nbr
 
 

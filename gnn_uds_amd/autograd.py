@@ -235,7 +235,8 @@ class SpmmFn(torch.autograd.Function):
 
 class GatFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xa, xb, kernel, a_self, a_nbr, bias, act, handle, precision):
+    def forward(ctx, xa, xb, kernel, a_self, a_nbr, bias, act, handle, precision, coef=None):
+        """coef (S, nnz) or None: multiplier of the normalised attention coefficients (Spektral's attention dropout)."""
         xa = xa.contiguous()
         xb = None if xb is None else xb.contiguous()
         fin, d = xa.shape[-1] + (0 if xb is None else xb.shape[-1]), kernel.shape[-1]
@@ -251,11 +252,13 @@ class GatFn(torch.autograd.Function):
             wa = torch.stack([w2 @ a_self.reshape(-1), w2 @ a_nbr.reshape(-1)], dim=1).contiguous()
             s2 = _lib.rowgemm_cat(xa, xb, _lib.rowgemm_pack(wa), None, 2, 'linear')
             s_self, s_nbr = s2[..., 0].contiguous(), s2[..., 1].contiguous()
-            out = _lib.gat_aggregate(handle, hx, s_self, s_nbr, bias, act)
+            out = _lib.gat_aggregate(handle, hx, s_self, s_nbr, bias, act, coef=coef)
         else:
             out, (hx, s_self, s_nbr) = _lib.gat_forward(handle, xa, kernel, a_self, a_nbr, bias, act, xb, return_workspace=True)
+            if coef is not None:
+                out = _lib.gat_aggregate(handle, hx, s_self, s_nbr, bias, act, coef=coef)
         ctx.save_for_backward(xa, xb, kernel, a_self, a_nbr, out, hx, s_self, s_nbr)
-        ctx.act, ctx.handle, ctx.precision, ctx.has_bias = act, handle, precision, bias is not None
+        ctx.act, ctx.handle, ctx.precision, ctx.has_bias, ctx.coef = act, handle, precision, bias is not None, coef
         return out
 
     @staticmethod
@@ -265,7 +268,7 @@ class GatFn(torch.autograd.Function):
         g = act_grad(out, gout.contiguous(), ctx.act).contiguous()
         ht, perm = ctx.handle.transposed(g.device)
         d_hx, ds_self, ds_nbr = _lib.gat_backward(ctx.handle, ht, perm, g, hx, s_self, s_nbr, a_self.reshape(-1).contiguous(),
-                                                  a_nbr.reshape(-1).contiguous())
+                                                  a_nbr.reshape(-1).contiguous(), coef=ctx.coef)
         fa = xa.shape[-1]
         w2 = kernel.reshape(-1, d)
         dxa = dxb = dk = das = dan = db = None
@@ -285,7 +288,7 @@ class GatFn(torch.autograd.Function):
             das, dan = da[0].reshape(a_self.shape), da[1].reshape(a_nbr.shape)
         if ctx.has_bias and ctx.needs_input_grad[5]:
             db = g.reshape(-1, d).sum(0)
-        return dxa, dxb, dk, das, dan, db, None, None, None
+        return dxa, dxb, dk, das, dan, db, None, None, None, None
 
 
 class CumsumActFn(torch.autograd.Function):

@@ -25,6 +25,9 @@ struct GatBwdRowsArgs {
   float *alpha, *de, *ds_self;
   int n, d4, S, G;        // G lanes per row (power of two, <= 64, <= d4 rounded down)
   int64_t nnz;
+  // attention dropout (k_gat_aggregate_coef): pre_i = sum_j alpha_ij m_ij hx_j with m (S, nnz) = 0 or 1 / (1 - rate), else NULL.
+  // Then q_ij = m_ij <g_i, hx_j> in the formulas above, and the alpha handed to the column pass is alpha_ij m_ij.
+  const float *coef;
 };
 
 __global__ __launch_bounds__(256) void k_gat_bwd_rows(GatBwdRowsArgs a) {
@@ -40,6 +43,7 @@ __global__ __launch_bounds__(256) void k_gat_bwd_rows(GatBwdRowsArgs a) {
   const float4 *g4 = reinterpret_cast<const float4 *>(a.g) + ((int64_t)s * a.n + i) * a.d4;
   const float4 *hx4 = reinterpret_cast<const float4 *>(a.hx) + (int64_t)s * a.n * a.d4;
   float *al = a.alpha + (int64_t)s * a.nnz, *de = a.de + (int64_t)s * a.nnz;
+  const float *cf = a.coef ? a.coef + (int64_t)s * a.nnz : nullptr;
   float m = -INFINITY;
   for (int p = beg; p < end; ++p) m = fmaxf(m, leaky02(ss + sn[a.col[p]]));
   float den = 0.f, cn = 0.f;
@@ -59,6 +63,7 @@ __global__ __launch_bounds__(256) void k_gat_bwd_rows(GatBwdRowsArgs a) {
         q = fmaf(gv.x, hv.x, fmaf(gv.y, hv.y, fmaf(gv.z, hv.z, fmaf(gv.w, hv.w, q))));
       }
       for (int o = a.G >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o);
+      if (cf) q *= cf[p];
       den += w;
       cn = fmaf(w, q, cn);
       if (p - beg == lg) {
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256) void k_gat_bwd_rows(GatBwdRowsArgs a) {
     const float dl = w * (qk - cbar);
     const float dv = mine ? (pos ? dl : 0.2f * dl) : 0.f;
     if (mine && row_ok) {
-      al[beg + lg] = w;
+      al[beg + lg] = cf ? w * cf[beg + lg] : w;
       de[beg + lg] = dv;
     }
     // ds_self = sum of the row's de in entry order (the order the one-lane walk below adds them in)
@@ -92,6 +97,7 @@ __global__ __launch_bounds__(256) void k_gat_bwd_rows(GatBwdRowsArgs a) {
       q = fmaf(gv.x, hv.x, fmaf(gv.y, hv.y, fmaf(gv.z, hv.z, fmaf(gv.w, hv.w, q))));
     }
     for (int o = a.G >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (cf) q *= cf[p];
     den += w;
     cn = fmaf(w, q, cn);
     if (lg == 0 && row_ok) {
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256) void k_gat_bwd_rows(GatBwdRowsArgs a) {
     const float w = al[p] * inv;
     const float dl = w * (de[p] - cbar);
     const float dv = ss + sn[a.col[p]] > 0.0f ? dl : 0.2f * dl;
-    al[p] = w;
+    al[p] = cf ? w * cf[p] : w;
     de[p] = dv;
     dss += dv;
   }
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(256) void k_gat_bwd_rows_g(GatBwdRowsArgs a) {
 inline hipError_t launch_gat_bwd_rows(const GatBwdRowsArgs &a, hipStream_t st) {
   int G, NC;
   group_shape(a.d4, G, NC);
-  if (G && a.n > 0)
+  if (G && a.n > 0 && !a.coef)      // (attention dropout: the plain kernel below)
     return launch_grouped(a, a.n, a.S, a.d4, st, [&](auto g_, auto nc_, dim3 grid) {
       hipLaunchKernelGGL((k_gat_bwd_rows_g<decltype(g_)::value, decltype(nc_)::value>), grid, dim3(256), 0, st, a);
     });

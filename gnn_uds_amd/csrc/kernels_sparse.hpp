@@ -342,6 +342,54 @@ __global__ __launch_bounds__(256) void k_gat_aggregate_masked(GatArgs a, const f
   reinterpret_cast<float4 *>(a.out)[((int64_t)s * a.n + i) * a.d4 + c] = o;
 }
 
+// k_gat_aggregate with a per-entry multiplier on the NORMALISED attention coefficients: Spektral's attention dropout
+// (`attn_coef_drop = self.dropout(attn_coef)` after the softmax, GATConv._call_dense; rate 0.5, active whenever the model runs
+// with training=True, i.e. the emulator's dropout > 0 under fit, emulator.py:411,434).  coef (S, nnz): 0 or 1 / (1 - rate) per
+// pattern entry and snapshot.  Training path only: one thread per (row, 16-byte chunk), no grouping.
+__global__ __launch_bounds__(256) void k_gat_aggregate_coef(GatArgs a, const float *__restrict__ coef, int64_t nnz) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per_snap = (int64_t)a.n * a.d4;
+  if (t >= per_snap) return;
+  const int s = blockIdx.y;
+  const int c = (int)(t % a.d4);
+  const int i = a.order[t / a.d4];
+  const int beg = a.rowptr[i], end = a.rowptr[i + 1];
+  const float *sn = a.s_nbr + (int64_t)s * a.n;
+  const float *cf = coef + (int64_t)s * nnz;
+  const float ss = a.s_self[(int64_t)s * a.n + i];
+  float m = -INFINITY;
+  for (int p = beg; p < end; ++p) m = fmaxf(m, leaky02(ss + sn[a.col[p]]));
+  const float4 *hx4 = reinterpret_cast<const float4 *>(a.hx) + (int64_t)s * a.n * a.d4 + c;
+  float den = 0.0f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = beg; p < end; ++p) {
+    const int j = a.col[p];
+    const float w = expf(leaky02(ss + sn[j]) - m);
+    den += w;                                   // the softmax is over ALL entries; the dropped ones only leave the sum
+    const float wc = w * cf[p];
+    const float4 hv = hx4[(int64_t)j * a.d4];
+    acc.x = fmaf(wc, hv.x, acc.x);
+    acc.y = fmaf(wc, hv.y, acc.y);
+    acc.z = fmaf(wc, hv.z, acc.z);
+    acc.w = fmaf(wc, hv.w, acc.w);
+  }
+  const float inv = den > 0.0f ? 1.0f / den : 0.0f;
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.bias) b = reinterpret_cast<const float4 *>(a.bias)[c];
+  float4 o;
+  o.x = apply_act(fmaf(acc.x, inv, b.x), a.act);
+  o.y = apply_act(fmaf(acc.y, inv, b.y), a.act);
+  o.z = apply_act(fmaf(acc.z, inv, b.z), a.act);
+  o.w = apply_act(fmaf(acc.w, inv, b.w), a.act);
+  reinterpret_cast<float4 *>(a.out)[((int64_t)s * a.n + i) * a.d4 + c] = o;
+}
+
+inline hipError_t launch_gat_aggregate_coef(const GatArgs &a, const float *coef, int64_t nnz, hipStream_t st) {
+  const int64_t per_snap = (int64_t)a.n * a.d4;
+  hipLaunchKernelGGL(k_gat_aggregate_coef, dim3((unsigned)((per_snap + 255) / 256), (unsigned)a.S), dim3(256), 0, st, a, coef, nnz);
+  return hipGetLastError();
+}
+
 inline hipError_t launch_gat_aggregate_masked(const GatArgs &a, const float *mask, int64_t nnz, hipStream_t st) {
   const int64_t per_snap = (int64_t)a.n * a.d4;
   hipLaunchKernelGGL(k_gat_aggregate_masked, dim3((unsigned)((per_snap + 255) / 256), (unsigned)a.S), dim3(256), 0, st, a, mask, nnz);

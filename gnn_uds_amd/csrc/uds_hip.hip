@@ -799,6 +799,21 @@ int uds_gat_aggregate(const uds_csr_t *g, const float *hx, const float *s_self, 
   return UDS_OK;
 }
 
+int uds_gat_aggregate_coef(const uds_csr_t *g, const float *hx, const float *s_self, const float *s_nbr, const float *bias,
+                           const float *coef, int64_t S, int64_t d, int act, float *out, uds_stream_t stream) {
+  UDS_REQUIRE(g && hx && s_self && s_nbr && coef && out, "uds_gat_aggregate_coef: NULL argument");
+  UDS_REQUIRE(g->n_rows == g->n_cols, "uds_gat_aggregate_coef: pattern must be square");
+  UDS_REQUIRE(d > 0 && d % 4 == 0 && d <= 256, "uds_gat_aggregate_coef: d=%lld must be a multiple of 4, at most 256", (long long)d);
+  UDS_REQUIRE(S >= 0 && S <= 65535, "uds_gat_aggregate_coef: S=%lld outside [0,65535]", (long long)S);
+  UDS_REQUIRE(act >= UDS_ACT_LINEAR && act <= UDS_ACT_HARD_SIGMOID, "uds_gat_aggregate_coef: unknown activation %d", act);
+  UDS_REQUIRE(aligned16(hx) && aligned16(out) && aligned16(bias), "uds_gat_aggregate_coef: hx/out/bias must be 16-byte aligned");
+  if (S == 0 || g->n_rows == 0) return UDS_OK;
+  uds::GatArgs a{g->d_rowptr, g->d_col, g->d_order, hx, s_self, s_nbr, bias, out, (int)g->n_rows, (int)(d / 4), act, (int)S};
+  hipError_t e = uds::launch_gat_aggregate_coef(a, coef, g->nnz, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(UDS_EHIP, "uds_gat_aggregate_coef: launch -> %s", hipGetErrorString(e));
+  return UDS_OK;
+}
+
 int uds_gat_aggregate_masked(const uds_csr_t *g, const float *hx, const float *s_self, const float *s_nbr, const float *bias,
                              const float *edge_mask, int64_t S, int64_t d, int act, float *out, uds_stream_t stream) {
   UDS_REQUIRE(g && hx && s_self && s_nbr && edge_mask && out, "uds_gat_aggregate_masked: NULL argument");
@@ -817,6 +832,12 @@ int uds_gat_aggregate_masked(const uds_csr_t *g, const float *hx, const float *s
 int uds_gat_backward(const uds_csr_t *g, const uds_csr_t *gt, const int32_t *perm_t, const float *grad, const float *hx,
                      const float *s_self, const float *s_nbr, const float *a_self, const float *a_nbr, int64_t S, int64_t d,
                      float *alpha_ws, float *de_ws, float *d_hx, float *ds_self, float *ds_nbr, uds_stream_t stream) {
+  return uds_gat_backward_coef(g, gt, perm_t, grad, hx, s_self, s_nbr, a_self, a_nbr, nullptr, S, d, alpha_ws, de_ws, d_hx, ds_self, ds_nbr, stream);
+}
+
+int uds_gat_backward_coef(const uds_csr_t *g, const uds_csr_t *gt, const int32_t *perm_t, const float *grad, const float *hx,
+                          const float *s_self, const float *s_nbr, const float *a_self, const float *a_nbr, const float *coef, int64_t S,
+                          int64_t d, float *alpha_ws, float *de_ws, float *d_hx, float *ds_self, float *ds_nbr, uds_stream_t stream) {
   UDS_REQUIRE(g && gt && perm_t && grad && hx && s_self && s_nbr && a_self && a_nbr && alpha_ws && de_ws && d_hx && ds_self && ds_nbr,
               "uds_gat_backward: NULL argument");
   UDS_REQUIRE(g->n_rows == g->n_cols && gt->n_rows == g->n_rows && gt->n_cols == g->n_cols && gt->nnz == g->nnz,
@@ -828,7 +849,7 @@ int uds_gat_backward(const uds_csr_t *g, const uds_csr_t *gt, const int32_t *per
   if (S == 0 || g->n_rows == 0) return UDS_OK;
   const int d4 = (int)(d / 4);
   uds::GatBwdRowsArgs ra{g->d_rowptr, g->d_col, grad, hx, s_self, s_nbr, alpha_ws, de_ws, ds_self,
-                         (int)g->n_rows, d4, (int)S, uds::lanes_per_item(d4), g->nnz};
+                         (int)g->n_rows, d4, (int)S, uds::lanes_per_item(d4), g->nnz, coef};
   hipError_t e = uds::launch_gat_bwd_rows(ra, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(UDS_EHIP, "uds_gat_backward: row pass launch -> %s", hipGetErrorString(e));
   uds::GatBwdColsArgs ca{gt->d_rowptr, gt->d_col, perm_t, grad, alpha_ws, de_ws, ds_self, a_self, a_nbr, d_hx, ds_nbr,

@@ -272,13 +272,10 @@ class Emulator(nn.Module):
             raise ValueError('graph_base must be 0, 1 (node-based) or 2 (edge-based), got %r' % (self.graph_base,))
         if recurrent not in ('Conv1D', 'GRU', 'LSTM', None, 'None', False):
             raise NotImplementedError('recurrent=%r: Conv1D, GRU, LSTM or none (emulator.py:154-163)' % (recurrent,))
-        # keras Dropout layers (:199-213,234-235,287-288,314-318): active only in `forward(..., training=True)` = `fit_eval(fit=True)`
-        # (`self.model(inp, training=fit)`, :411,434); one counter-based stream for all of them (layers.Dropout)
+        # keras Dropout layers (:199-213,234-235,287-288,314-318) and Spektral's attention dropout inside every GATConv (rate 0.5): active
+        # only in `forward(..., training=True)` = `fit_eval(fit=True)` (`self.model(inp, training=fit)`, :411,434); one counter-based
+        # stream for all of them (layers.Dropout, GATConv(attn_dropout=))
         self.dropout_stream = DropoutStream(generator=generator) if self.dropout else None
-        if self.dropout and self.conv and self.conv_kind == 'GAT':
-            import warnings
-            warnings.warn('dropout > 0: the Dropout layers of the model are applied in training; the attention-coefficient dropout of '
-                          "Spektral's GATConv (rate 0.5), which the reference's `training=True` also switches on, is not")
         self._drop02 = Dropout(0.2, self.dropout_stream) if self.dropout else None
         self._drop = Dropout(self.dropout, self.dropout_stream) if self.dropout else None
 
@@ -536,6 +533,8 @@ class Emulator(nn.Module):
             kw = {} if mask is None else {'adj_mask': mask}
             if dr is not None:
                 kw['dropout'] = dr
+                if self.conv_kind == 'GAT':      # training=True reaches the GATConv layers too: Spektral's attention dropout (rate 0.5)
+                    kw['attn_dropout'] = self.dropout_stream
             xs, es = block(r(x, self.n_node), r(e, self.n_edge), r(xb, self.n_node), r(eb, self.n_edge), **kw)
             return xs.reshape(nb, T, self.n_node, -1), es.reshape(nb, T, self.n_edge, -1)
 

@@ -166,10 +166,12 @@ class GATConv(nn.Module):
         self.attn_kernel_neighs = _param(_glorot_uniform((c, 1, 1), device, self._gen))
         self.bias = _param(torch.zeros(c, device=device)) if self.use_bias else None
 
-    def forward(self, inputs, xb=None, edge_mask=None):
+    def forward(self, inputs, xb=None, edge_mask=None, attn_dropout=None):
         """edge_mask (..., nnz): per-snapshot 0/1 over the entries of the pattern `a` (`use_adj`, emulator.py:268-271: the
         reference feeds a (S, N, N) adjacency here; the mask is that adjacency gathered at the static pattern's entries --
-        `Emulator.get_adj_action`).  The diagonal always takes part (set_diag).  Inference only."""
+        `Emulator.get_adj_action`).  The diagonal always takes part (set_diag).  Inference only.
+        attn_dropout: a DropoutStream = the layer runs in Keras' training mode and `dropout_rate` > 0: Spektral's dropout on the
+        normalised attention coefficients (`attn_coef_drop = self.dropout(attn_coef)`), one mask entry per (snapshot, pattern entry)."""
         x, a = inputs
         if self.kernel is None:
             self.build(x.shape[-1] + (0 if xb is None else xb.shape[-1]), x.device)
@@ -185,9 +187,15 @@ class GATConv(nn.Module):
             mk = edge_mask.reshape(-1, edge_mask.shape[-1]).to(torch.float32).contiguous()
             out = _lib.gat_aggregate(h, hx, s_self, s_nbr, self.bias, self.activation, edge_mask=mk)
             return out.reshape(lead + out.shape[-2:])
-        if _ag.grad_on(xs, xbs, self.kernel, self.attn_kernel_self, self.attn_kernel_neighs, self.bias):
+        coef = None
+        if attn_dropout is not None and self.dropout_rate:
+            if edge_mask is not None:
+                raise NotImplementedError('attention dropout together with a per-snapshot edge mask (use_adj) is not built')
+            ones = torch.ones((xs.shape[0], h.nnz), device=xs.device, dtype=torch.float32)
+            coef = _lib.dropout(ones, self.dropout_rate, attn_dropout.seed, attn_dropout.take(ones.numel()))
+        if coef is not None or _ag.grad_on(xs, xbs, self.kernel, self.attn_kernel_self, self.attn_kernel_neighs, self.bias):
             out = _ag.GatFn.apply(xs, xbs, self.kernel, self.attn_kernel_self, self.attn_kernel_neighs, self.bias,
-                                  self.activation, h, self.precision)
+                                  self.activation, h, self.precision, coef)
             return out.reshape(lead + out.shape[-2:])
         fin = xs.shape[-1] + (0 if xbs is None else xbs.shape[-1])
         if self.precision == 'bf16x3' and fin % 32 == 0 and self.channels % 16 == 0 and xs.shape[0] * xs.shape[1] >= 4096:
@@ -551,11 +559,14 @@ class SpatialLayer(nn.Module):
                 p['ne_%s_w' % tag], p['ne_%s_b' % tag] = c(ne.weight), c(ne.bias)
         return p
 
-    def forward(self, x, e, xb=None, eb=None, adj_mask=None):
+    def forward(self, x, e, xb=None, eb=None, adj_mask=None, attn_dropout=None):
         """xb / eb: 32 extra columns appended to a 64-wide x / e (`concat([x, b])`, emulator.py:260-262) -- read in place
         by the fused kernel; every other path concatenates.  adj_mask (..., nnz of the node adjacency): the per-snapshot
-        adjacency of `use_adj` (emulator.py:268-271,282) -- node side through the masked aggregation kernel."""
+        adjacency of `use_adj` (emulator.py:268-271,282) -- node side through the masked aggregation kernel.
+        attn_dropout: a DropoutStream = Keras' training mode for the two GATConv layers (Spektral's attention dropout, rate 0.5)."""
         if adj_mask is not None:
+            if attn_dropout is not None:
+                raise NotImplementedError('use_adj in training mode (attention dropout) is not built')
             if self.conv != 'GAT':
                 raise NotImplementedError('use_adj is built for conv=GAT (GCN / Diffusion would re-normalise the filter per snapshot)')
             if xb is not None:
@@ -590,12 +601,12 @@ class SpatialLayer(nn.Module):
             ox = self.gcn_x([torch.cat([xs, self.node_edge_n(x_e)], dim=-1), self.filters[0]])
             oe = self.gcn_e([torch.cat([es, self.node_edge_e(e_x)], dim=-1), self.filters[1]])
             return ox.reshape(lead_x + ox.shape[-2:]), oe.reshape(lead_e + oe.shape[-2:])
-        if _ag.grad_on(xs, es, *self.parameters()):
+        if attn_dropout is not None or _ag.grad_on(xs, es, *self.parameters()):
             # training: the unfused chain, every operator with its own HIP backward (autograd.py)
             net = self.network()
             x_e, e_x = self.dense_xe(es), self.dense_ex(xs)
-            ox = self.gat_x([xs, net.adj], xb=self.node_edge_n(x_e))
-            oe = self.gat_e([es, net.edge_adj], xb=self.node_edge_e(e_x))
+            ox = self.gat_x([xs, net.adj], xb=self.node_edge_n(x_e), attn_dropout=attn_dropout)
+            oe = self.gat_e([es, net.edge_adj], xb=self.node_edge_e(e_x), attn_dropout=attn_dropout)
             return ox.reshape(lead_x + ox.shape[-2:]), oe.reshape(lead_e + oe.shape[-2:])
         vn, rest_n = self.node_edge_n.support_values()
         ve, rest_e = self.node_edge_e.support_values()
@@ -709,7 +720,7 @@ class GraphBaseBlock(nn.Module):
             if conv == 'GAT':
                 ly.precision = precision
 
-    def forward(self, x, e, xb=None, eb=None, adj_mask=None, dropout=None):
+    def forward(self, x, e, xb=None, eb=None, adj_mask=None, dropout=None, attn_dropout=None):
         if xb is not None:
             x = torch.cat([x, xb], dim=-1)
         if eb is not None:
@@ -720,7 +731,10 @@ class GraphBaseBlock(nn.Module):
             raise NotImplementedError('use_adj is built for conv=GAT')
         z = torch.cat([x, e], dim=-2)
         for ly in self.layers:
-            z = ly([z, self.filt], edge_mask=adj_mask) if adj_mask is not None else ly([z, self.filt])
+            if attn_dropout is not None and self.conv == 'GAT':
+                z = ly([z, self.filt], edge_mask=adj_mask, attn_dropout=attn_dropout)
+            else:
+                z = ly([z, self.filt], edge_mask=adj_mask) if adj_mask is not None else ly([z, self.filt])
             if dropout is not None:      # Dropout on the node rows and on the link rows (emulator.py:234-235): one elementwise mask
                 z = dropout(z)
         return z[..., :self.n_node, :].contiguous(), z[..., self.n_node:, :].contiguous()
@@ -802,14 +816,16 @@ class SpatialBlock(nn.Module):
         replay.graph = graph
         return replay
 
-    def forward(self, x, e, xb=None, eb=None, adj_mask=None, dropout=None):
+    def forward(self, x, e, xb=None, eb=None, adj_mask=None, dropout=None, attn_dropout=None):
         """xb / eb: extra input columns of the FIRST layer (`concat([x, b])` before block 2, emulator.py:260-262);
         adj_mask: the per-snapshot node adjacency of `use_adj`, seen by every layer of the block (emulator.py:268-282);
-        dropout: callable applied to x and e after every layer (`Dropout(self.dropout)`, emulator.py:234-235,287-288), training only."""
+        dropout: callable applied to x and e after every layer (`Dropout(self.dropout)`, emulator.py:234-235,287-288), training only;
+        attn_dropout: DropoutStream for Spektral's attention dropout inside the GATConv layers, training only."""
         net = self.layers[0].network() if self.layers[0].conv == 'GAT' else None
         for i, layer in enumerate(self.layers):
             layer._net = net
-            x, e = layer(x, e, xb if i == 0 else None, eb if i == 0 else None, adj_mask=adj_mask)
+            kw = {'attn_dropout': attn_dropout} if attn_dropout is not None and layer.conv == 'GAT' else {}
+            x, e = layer(x, e, xb if i == 0 else None, eb if i == 0 else None, adj_mask=adj_mask, **kw)
             if dropout is not None:
                 x, e = dropout(x), dropout(e)
         return x, e

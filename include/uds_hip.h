@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 20
+#define UDS_ABI_VERSION 21
 
 enum {
   UDS_OK = 0,
@@ -292,6 +292,18 @@ int uds_gat_backward(const uds_csr_t *graph, const uds_csr_t *graph_t, const int
                      const float *hx, const float *s_self, const float *s_nbr, const float *a_self,
                      const float *a_nbr, int64_t S, int64_t d, float *alpha_ws, float *de_ws, float *d_hx,
                      float *ds_self, float *ds_nbr, uds_stream_t stream);
+
+/* The two entries above with Spektral's ATTENTION DROPOUT (GATConv: `attn_coef_drop = dropout(softmax(...))`, rate 0.5, which the
+ * reference switches on together with the model's Dropout layers: `self.model(inp, training=fit)`, emulator.py:411,434):
+ * coef (S, nnz) multiplies the normalised coefficient of entry p of snapshot s (0 or 1 / (1 - rate); uds_dropout on a tensor of
+ * ones makes it).  Forward: out_i = act(sum_j alpha_ij coef_ij hx_j + bias); backward: the same workspace and outputs as
+ * uds_gat_backward.  Training path only. */
+int uds_gat_aggregate_coef(const uds_csr_t *g, const float *hx, const float *s_self, const float *s_nbr, const float *bias,
+                           const float *coef, int64_t S, int64_t d, int act, float *out, uds_stream_t stream);
+int uds_gat_backward_coef(const uds_csr_t *g, const uds_csr_t *gt, const int32_t *perm_t, const float *grad, const float *hx,
+                          const float *s_self, const float *s_nbr, const float *a_self, const float *a_nbr, const float *coef,
+                          int64_t S, int64_t d, float *alpha_ws, float *de_ws, float *d_hx, float *ds_self, float *ds_nbr,
+                          uds_stream_t stream);
 
 /* out[k] = sum_s <a[s, row(k), :], b[s, col(k), :]> for every entry k of the pattern (row-major order): the gradient
  * of the per-entry values of uds_csr_spmm (a = dL/dout (S,n_rows,F), b = x (S,n_cols,F)) -- NodeEdge.weight / bias

@@ -40,14 +40,19 @@ def dense(x, kernel, bias, act='linear'):
     return activation(act)(y)
 
 
+# None = inference.  A test sets it to a callable (coef (...,N,H,N), a_hat (N,N) with the diagonal set) -> coef that applies the
+# mask stream it compares with (tests/test_gpu_dropout.py; Spektral draws its mask from TensorFlow's generator: statistical parity only).
+ATTN_DROPOUT = None
+
+
 def gat_conv_dense(x, a, kernel, attn_kernel_self, attn_kernel_neighs, bias,
                    act='relu', add_self_loops=True, concat_heads=True, return_attn=False):
     """spektral.layers.GATConv._call_dense + call() tail, as used through `MixedGAT`
     (`emulator.py:18-25,229-230,282-283`).  Mixed mode: `x:(...,N,F)`, `a:(N,N)`.
 
     kernel (F,H,C); attn_kernel_self/neighs (C,H,1); bias (H*C) if concat else (C).
-    Dropout on the coefficients is inactive (the emulator never passes training=True
-    unless self.dropout>0, `emulator.py:411,434`).
+    Dropout on the coefficients (`attn_coef_drop = self.dropout(attn_coef)`, rate dropout_rate = 0.5) is inactive unless the
+    emulator passes training=True, which it does only when self.dropout > 0 (`emulator.py:411,434`): ATTN_DROPOUT below.
     """
     a = a.to(x.dtype).clone()
     n = a.shape[-1]
@@ -63,6 +68,8 @@ def gat_conv_dense(x, a, kernel, attn_kernel_self, attn_kernel_neighs, bias,
     mask = torch.where(a == 0.0, torch.tensor(MASK_VALUE, dtype=x.dtype), torch.tensor(0.0, dtype=x.dtype))
     coef = coef + mask[..., None, :]                                       # (N,1,N) broadcast
     coef = torch.softmax(coef, dim=-1)
+    if ATTN_DROPOUT is not None:                                           # training=True: dropout on the normalised coefficients
+        coef = ATTN_DROPOUT(coef, a)
     out = torch.einsum('...nhm,...mhi->...nhi', coef, hx)                  # (...,N,H,C)
     if concat_heads:
         out = out.reshape(out.shape[:-2] + (out.shape[-2] * out.shape[-1],))

@@ -5,8 +5,10 @@
   generator's published known-answer vectors in tests/test_dropout.py): aligned and unaligned offsets, ragged sizes, in place;
 * statistical parity with keras Dropout: keep fraction within 5 sigma of 1 - rate, expectation preserved, identity at inference;
 * the backward pass applies the same mask (recomputed from (seed, offset));
+* Spektral's attention dropout (GATConv in training mode: dropout on the softmax coefficients, rate 0.5 -- what `training=True` also
+  switches on in the reference): layer values and gradients against the dense restatement fed the same mask;
 * the gradients of every Emulator parameter under dropout equal torch autograd over the fp64 oracle fed the same mask stream
-  (oracle.emulator_ref.DROPOUT hook) within the whole-model tolerance of tests/test_gpu_train.py."""
+  (oracle.emulator_ref.DROPOUT and oracle.spektral_dense.ATTN_DROPOUT hooks) within the whole-model tolerance of tests/test_gpu_train.py."""
 import numpy as np
 import pytest
 import torch
@@ -100,12 +102,60 @@ class _RefStream:
     def __init__(self, seed):
         self.seed, self.offset = seed, 0
 
-    def __call__(self, t, rate):
-        n = t.numel()
-        m = DR.dropout_mask(n, rate, self.seed, self.offset).reshape(tuple(t.shape))
+    def _mask(self, n, rate):
+        m = DR.dropout_mask(n, rate, self.seed, self.offset)
         self.offset += (n + 3) // 4 * 4
-        scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate)))
-        return t * torch.from_numpy(m.astype(np.float64) * scale)
+        return m.astype(np.float64) * float(np.float32(1.0) / (np.float32(1.0) - np.float32(rate)))
+
+    def __call__(self, t, rate):
+        return t * torch.from_numpy(self._mask(t.numel(), rate).reshape(tuple(t.shape)))
+
+    def attn(self, coef, a_hat, rate=0.5):
+        """Spektral's attention dropout on the dense coefficients (S, N, 1, N): the engine draws one mask entry per snapshot and
+        entry of the CSR pattern (rows in order, columns ascending = the row-major order of the non-zeros of a_hat)."""
+        S = int(np.prod(coef.shape[:-3])) if coef.dim() > 3 else 1
+        rows, cols = np.nonzero(a_hat.numpy() != 0)
+        m = self._mask(S * len(rows), rate).reshape(S, len(rows))
+        dense = np.zeros((S,) + tuple(a_hat.shape))
+        dense[:, rows, cols] = m
+        return coef * torch.from_numpy(dense).reshape(tuple(coef.shape[:-3]) + (a_hat.shape[0], 1, a_hat.shape[1]))
+
+
+def test_attention_dropout_layer_matches_the_dense_restatement(dev, networks):
+    """GATConv in Keras' training mode (Spektral: dropout on the softmax coefficients, rate 0.5) against the dense restatement fed
+    the same mask: forward values and the gradients of input, kernel, both attention kernels and the bias."""
+    from oracle import spektral_dense as OD
+    net = networks['shunqing']
+    gph = U.DrainageGraph.from_edges(np.array(net['edges']), net['n_node'])
+    g = torch.Generator().manual_seed(4)
+    S, F, C = 3, 24, 16
+    x = torch.randn(S, gph.n_node, F, generator=g, dtype=torch.float64)
+    layer = U.GATConv(C, activation='tanh', in_channels=F, generator=g).to(dev)
+    with torch.no_grad():
+        layer.bias.normal_(0.0, 0.1, generator=None)
+    st = DropoutStream(seed=99)
+    xd = x.float().to(dev).requires_grad_(True)
+    layer.requires_grad_(True)
+    a_dense = gph.adj.to_dense()
+    out = layer([xd, a_dense], attn_dropout=st)
+    gy = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    (out * gy.float().to(dev)).sum().backward()
+    ref_p = [p.detach().double().cpu().requires_grad_(True) for p in (layer.kernel, layer.attn_kernel_self, layer.attn_kernel_neighs, layer.bias)]
+    xr = x.clone().requires_grad_(True)
+    rs = _RefStream(99)
+    OD.ATTN_DROPOUT = rs.attn
+    try:
+        ref = OD.gat_conv_dense(xr, torch.from_numpy(a_dense), *ref_p, 'tanh')
+    finally:
+        OD.ATTN_DROPOUT = None
+    (ref * gy).sum().backward()
+    assert st.offset == rs.offset
+    close(out.detach(), ref.detach(), 2e-5)
+    plain = layer([xd.detach(), a_dense])
+    assert float((plain - out.detach()).abs().max()) > 1e-2          # the mask does something
+    for got, want in [(xd.grad, xr.grad)] + [(p.grad, r.grad) for p, r in zip((layer.kernel, layer.attn_kernel_self, layer.attn_kernel_neighs, layer.bias), ref_p)]:
+        err, scale = float((got.double().cpu() - want).abs().max()), float(want.abs().max())
+        assert err <= 1e-4 * scale + 1e-7, (err, scale)
 
 
 @pytest.mark.parametrize('name,over', [('astlingen', dict(dropout=0.1)),
@@ -116,12 +166,14 @@ def test_emulator_gradients_under_dropout(dev, networks, name, over):
     args, norms, params, emul, cpu_in, dev_in = _problem(networks, name, dev, **over)
     assert emul.dropout and emul.dropout_stream is not None
     x, a, b, y, ex, ey = cpu_in
+    from oracle import spektral_dense as OD
     emul.dropout_stream.reseed(2024)
     OE.DROPOUT = _RefStream(2024)
+    OD.ATTN_DROPOUT = OE.DROPOUT.attn          # training=True reaches the GATConv layers too (same stream, the engine's order)
     try:
         ref_losses, ref_grads = OT.grads(args, params, norms, x, a, b, y, ex, ey)
     finally:
-        OE.DROPOUT = None
+        OE.DROPOUT = OD.ATTN_DROPOUT = None
     emul.requires_grad_(True)
     xd, ad, bd, yd, exd, eyd = dev_in
     ae = emul.get_edge_action(ad, True) if emul.act else None
