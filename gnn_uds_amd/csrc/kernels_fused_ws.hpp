@@ -667,7 +667,8 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
     // LDS crossbar).  Rows are degree-sorted inside the tile and dealt in octets: unit u (0..3) of wave xw -> octet NX u + xw.
     const int ro = lane >> 3, c8 = lane & 7, hf8 = ro & 1;      // hf8: which 128-B half of a row this lane takes first (see phase3o)
     int p3_dmax[U];
-    unsigned p3_pk[U][4];      // (the row's own slot byte and its output row are re-read from the tile block per snapshot: registers are short)
+    unsigned p3_pk[U][4];      // (the row's output row is re-read from the tile block per snapshot: registers are short)
+    unsigned p3_jb4 = 0;          // this lane's own slot byte of the four octets, 8 bits each: the index of the score it gathers
     int n_st = 0;                 // output-store instructions this wave issues per snapshot (two per octet that has a row)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -695,6 +696,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
         }
         p3_pk[u][k2] = pk;
       }
+      p3_jb4 |= (i < n_own ? (unsigned)adj_b[i * ELL_ADJ + c8] : 0xFFu) << (8 * u);
       if (8 * (NX * u + xw) < n_own) n_st += 2;
     }
     const float *bias_l = attn + 2 * FUSED_D + FUSED_H + 4 * c8;      // + 32 hf8 / + 32 - 32 hf8 for the lane's first / second piece      // the output bias, read back per snapshot (registers are short)
@@ -856,10 +858,9 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
         // every LDS read of this prologue is unconditional (a row past n_own reads some other word of the tile block, a missing
         // slot the score of row 255; the selects below discard both): under a condition the compiler branches around each read
         // and waits for it alone
-        jb0[u] = adj_b[(8 * (NX * u + xw) + ro) * ELL_ADJ + c8];
+        jb0[u] = (p3_jb4 >> (8 * u)) & 0xFFu;      // static per tile (one packed register): no LDS round trip in front of the score gather
         ss[u] = ssr[8 * (NX * u + xw) + ro];
       }
-      asm volatile("" : "+v"(jb0[0]), "+v"(jb0[1]), "+v"(jb0[2]), "+v"(jb0[3]));      // the four reads are issued, then waited for together
 #pragma unroll
       for (int u = 0; u < U; ++u) has0[u] = ok[u] && jb0[u] != 0xFFu;
       f32x4 acc0[U], acc1[U];

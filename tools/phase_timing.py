@@ -49,3 +49,12 @@ ok = rt > 0
 print('in-kernel clock: median %.3f GHz (shader cycles / 100 MHz real-time ticks per workgroup), workgroup life %.1f us median'
       % (float(np.median(mt[ok] / rt[ok])) * 0.1, float(np.median(rt[ok])) * 0.01))
 print('shares:', {n: round(float(rows[:, k].sum() / tot), 3) for k, n in enumerate(names)})
+# workgroup life by side and size (wave 0 of every workgroup): how uneven the (tile, chunk) items are
+w0 = rows[rows[:, 12] == 0]
+life = (w0[:, 15] >> 32).astype(np.float64) * 0.01
+sd, n_own = (w0[:, 7] >> 8) & 0xff, (w0[:, 7] >> 16) & 0xffff
+for side in (0, 1):
+    l = life[(sd == side) & (life > 0)]
+    if len(l):
+        print('side %d: %d workgroups, life us min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f' % (side, len(l), l.min(), np.percentile(l, 10), np.median(l), np.percentile(l, 90), l.max()))
+print('sum of workgroup lives / 256 CUs = %.1f us (the launch if perfectly packed)' % (life.sum() / 256))
