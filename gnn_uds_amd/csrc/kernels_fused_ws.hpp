@@ -848,6 +848,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
       asm volatile("" : "+s"(d0), "+s"(d1), "+s"(d2), "+s"(d3));      // keep the slot tests on the scalar unit
       const int e3 = d3, e2 = max(e3, d2), e1 = max(e2, d1), e0 = max(e1, d0);
       if (e0 == 0) return;            // this wave has no row in the tile
+
       float ss[U], lg0[U], lg1[U], w0[U], w1[U], den[U];
       bool ok[U], has0[U], has1[U];
       unsigned jb0[U], jb1[U];
@@ -1008,7 +1009,17 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
           }
         }
       }
-      const f32x4 bo0 = *reinterpret_cast<const f32x4 *>(bias_l + 32 * hf8), bo1 = *reinterpret_cast<const f32x4 *>(bias_l + 32 - 32 * hf8);
+      // Epilogue.  The six LDS reads it needs (bias pieces, the four output row ids) are issued together and waited for once, and the
+      // snapshot's output base is formed once: written the plain way the compiler put an id read + its wait, a reload of the output
+      // pointer from the kernel arguments and a 64-bit multiply inside each of the four exec-masked store branches -- five dependent
+      // round trips per snapshot.
+      f32x4 bo0 = *reinterpret_cast<const f32x4 *>(bias_l + 32 * hf8), bo1 = *reinterpret_cast<const f32x4 *>(bias_l + 32 - 32 * hf8);
+      int pid[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) pid[u] = prim_ids[8 * (NX * u + xw) + ro];      // rows past n_own: some other word of the tile block, unused
+      asm volatile("" : "+v"(pid[0]), "+v"(pid[1]), "+v"(pid[2]), "+v"(pid[3]), "+v"(bo0), "+v"(bo1));
+      float *out_s = S_.out + (int64_t)s * S_.n_prim_glob * FUSED_D + (4 * c8 + 32 * hf8);      // (pinned at the top of the phase instead: -2.5 %)
+      const int o1_off = 32 - 64 * hf8;      // the second piece relative to the first
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (ok[u]) {
@@ -1019,9 +1030,9 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
             o0[q] = fused_act<ACT>(fmaf(acc0[u][q], inv, bo0[q]), a.act);
             o1[q] = fused_act<ACT>(fmaf(acc1[u][q], inv, bo1[q]), a.act);
           }
-          float *orow = S_.out + ((int64_t)s * S_.n_prim_glob * FUSED_D + (prim_ids[8 * (NX * u + xw) + ro] * FUSED_D + 4 * c8));
-          *reinterpret_cast<f32x4 *>(orow + 32 * hf8) = o0;
-          *reinterpret_cast<f32x4 *>(orow + 32 - 32 * hf8) = o1;
+          float *orow = out_s + (int64_t)pid[u] * FUSED_D;
+          *reinterpret_cast<f32x4 *>(orow) = o0;
+          *reinterpret_cast<f32x4 *>(orow + o1_off) = o1;
         }
       }
     };
