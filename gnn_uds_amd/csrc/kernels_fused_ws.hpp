@@ -610,8 +610,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
 #pragma unroll
     for (int j = 0; j < SJ32; ++j) srow[j] = ((unsigned)sec_ids[min((xw + NX * j) * 32 + n32, n_sec - 1)] * FS + 8u * hf) * 4u;
     f32x4 sp[SJ32][2 * KS32];         // the secondary rows of the snapshot P1 multiplies next (asm loads: see the header)
-    auto load_sec = [&](int s) __attribute__((always_inline)) {      // unconditional (rows are clamped): a fixed number of loads
-      const float *base = S_.sec_in + s * sec_stride;
+    auto load_sec_at = [&](const float *base) __attribute__((always_inline)) {      // unconditional (rows are clamped): a fixed number of loads
       static_for<SJ32>([&](auto j_) {
         constexpr int j = decltype(j_)::value;
         ws_gld16<0>(sp[j][0], base, srow[j]);
@@ -624,6 +623,8 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
         ws_gld16<208>(sp[j][7], base, srow[j]);
       });
     };
+    auto load_sec = [&](int s) __attribute__((always_inline)) { load_sec_at(S_.sec_in + s * sec_stride); };
+#define UDS_WS_RUNNING_PTRS 1
 #else
     bf16x8 wsh[KT_S][MB_S], wsl[KT_S][MB_S];      // 32 VGPRs
 #pragma unroll
@@ -841,7 +842,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
 
 #ifndef UDS_WS_P3_GROUPS
     // ---------------- P3 (octets): segmented softmax + neighbour sum -> HBM, the wave's four octets in one pass ----------------
-    auto phase3o = [&](int s, int buf) __attribute__((always_inline)) {
+    auto phase3o = [&](float *out_snap, int buf) __attribute__((always_inline)) {      // out_snap: the snapshot's (n_prim_glob, 64) output
       const float *hxr = hx + buf * hx_buf;
       const float *ssr = s_self + buf * a.p_cap, *snr = s_nbr + buf * a.p_cap;
       int d0 = p3_dmax[0], d1 = p3_dmax[1], d2 = p3_dmax[2], d3 = p3_dmax[3];
@@ -1018,7 +1019,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
 #pragma unroll
       for (int u = 0; u < U; ++u) pid[u] = prim_ids[8 * (NX * u + xw) + ro];      // rows past n_own: some other word of the tile block, unused
       asm volatile("" : "+v"(pid[0]), "+v"(pid[1]), "+v"(pid[2]), "+v"(pid[3]), "+v"(bo0), "+v"(bo1));
-      float *out_s = S_.out + (int64_t)s * S_.n_prim_glob * FUSED_D + (4 * c8 + 32 * hf8);      // (pinned at the top of the phase instead: -2.5 %)
+      float *out_s = out_snap + (4 * c8 + 32 * hf8);
       const int o1_off = 32 - 64 * hf8;      // the second piece relative to the first
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1188,6 +1189,13 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
     };
 
 #endif
+#ifdef UDS_WS_RUNNING_PTRS
+    // the base of the rows requested next and of the snapshot P3 writes next, as running pointers: formed from the kernel arguments
+    // inside the loop, each costs a scalar load + s_waitcnt lgkmcnt(0) per interval -- a wait that also drains the wave's LDS queue
+    const float *sec_next = S_.sec_in + (int64_t)(s_begin + 2) * sec_stride;
+    float *out_next = S_.out + (int64_t)s_begin * S_.n_prim_glob * FUSED_D;
+    const int64_t out_stride = (int64_t)S_.n_prim_glob * FUSED_D;
+#endif
     for (int k = 0; k <= n_snap; ++k) {
       const int s = s_begin + k;
       if (k + 1 < n_snap) {
@@ -1200,13 +1208,23 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
 #ifndef UDS_WS_ABL_NO_P1
         phase1((k + 1) & 1);
 #endif
+#ifdef UDS_WS_RUNNING_PTRS
+        if (k + 2 < n_snap) load_sec_at(sec_next);
+        sec_next += sec_stride;
+#else
         if (k + 2 < n_snap) load_sec(s + 2);
+#endif
       }
       WS_STAMP(3);
 #ifndef UDS_WS_ABL_NO_P3
       if (k >= 1) {
 #ifndef UDS_WS_P3_GROUPS
-        phase3o(s - 1, (k - 1) & 1);
+#ifdef UDS_WS_RUNNING_PTRS
+        phase3o(out_next, (k - 1) & 1);
+        out_next += out_stride;
+#else
+        phase3o(S_.out + (int64_t)(s - 1) * S_.n_prim_glob * FUSED_D, (k - 1) & 1);
+#endif
         WS_STAMP(4);
 #elif defined(UDS_WS_P3_LOOP)
 #pragma nounroll
