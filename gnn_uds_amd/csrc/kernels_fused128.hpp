@@ -219,7 +219,11 @@ __global__ __launch_bounds__(NW * 64) void k_fused_cs(FusedArgs a) {
   int n_st = 0;
   UDS_STAMP128(0);
 
-  for (int s = s_begin; s < s_end; ++s) {
+  // the snapshot's output base as a running pointer: formed from the kernel arguments at the stores, the compiler reloads the pointer
+  // and the row count inside EACH exec-masked store branch (scalar load + s_waitcnt lgkmcnt(0) + a 64-bit multiply per row group)
+  float *out_snap = S_.out + (int64_t)s_begin * S_.n_prim_glob * D;
+  const int64_t out_stride = (int64_t)S_.n_prim_glob * D;
+  for (int s = s_begin; s < s_end; ++s, out_snap += out_stride) {
     wait_all_but(n_st);       // this wave's DMA pieces of snapshot s have landed (the P3 stores are younger)
     f128_pin2(rm0, rm1);      // ... and its remainder piece
     UDS_STAMP128(1);
@@ -482,7 +486,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused_cs(FusedArgs a) {
         if (p3_dmax[u] > 0) n_st += CH;       // wave-uniform: CH store instructions per row group that has a valid row
         if (ok[u]) {
           const float inv = __builtin_amdgcn_rcpf(den[u]);
-          float *dst = S_.out + ((int64_t)s * S_.n_prim_glob * D + orow[u]);
+          float *dst = out_snap + orow[u];
 #pragma unroll
           for (int ch = 0; ch < CH; ++ch) {
             f32x4 o;
