@@ -141,12 +141,19 @@ __global__ __launch_bounds__(NW * 64) void k_fused_cs(FusedArgs a) {
         dma_block(std::integral_constant<int, KT_X>{}, S_.prim_in + (int64_t)s * S_.n_prim_glob * FP, prim_ids[min(blk * 16 + r16, n_prim - 1)], stage_p, blk);
   };
 
-  int p3_dmax[U];
+  // P3 statics of this lane's row groups: degree, the local row of the neighbour this lane scores (slot c16, clamped), the output
+  // row.  Per tile, not per snapshot: read inside the snapshot loop they were two dependent LDS round trips (adj_ptr -> adj_loc) in
+  // front of the score gather of every snapshot.
+  int p3_dmax[U], p3_deg[U], p3_jn[U], p3_orow[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int i = wave * 4 + 4 * NW * u + rs;
     const int ic = min(i, n_own - 1);
-    int dmx = i < n_own ? adj_ptr[ic + 1] - adj_ptr[ic] : 0;
+    const int b0 = adj_ptr[ic];
+    int dmx = i < n_own ? adj_ptr[ic + 1] - b0 : 0;
+    p3_deg[u] = dmx;
+    p3_jn[u] = adj_loc[b0 + min(lane & 15, max(dmx - 1, 0))];
+    p3_orow[u] = prim_ids[ic] * D + 4 * (lane & 15);
     dmx = max(dmx, __shfl_xor(dmx, 16));
     dmx = max(dmx, __shfl_xor(dmx, 32));
     p3_dmax[u] = __builtin_amdgcn_readfirstlane(dmx);
@@ -391,10 +398,9 @@ __global__ __launch_bounds__(NW * 64) void k_fused_cs(FusedArgs a) {
         const int i = wave * 4 + 4 * NW * u + rs;
         const int ic = min(i, n_own - 1);
         ok[u] = i < n_own;
-        const int b0 = adj_ptr[ic];
-        deg[u] = ok[u] ? adj_ptr[ic + 1] - b0 : 0;
-        jn[u] = adj_loc[b0 + min(c16, max(deg[u] - 1, 0))];          // clamped, unconditional: slots past the degree get weight 0
-        orow[u] = prim_ids[ic] * D + 4 * c16;
+        deg[u] = p3_deg[u];
+        jn[u] = p3_jn[u];          // slot c16 of the row, clamped: slots past the degree get weight 0
+        orow[u] = p3_orow[u];
         // the NSP per-column-block partials of a score, added in a fixed order: lanes 0..NSP-1 of the row group hold one each
         ss[u] = row16_sum(c16 < NSP ? sp_self[ic * NSP + c16] : 0.f);
         const f32x4 q0 = *reinterpret_cast<const f32x4 *>(sp_nbr + jn[u] * NSP);
