@@ -192,7 +192,10 @@ __device__ __forceinline__ void gemm2_dma(const __bf16 *base, unsigned voff, uns
                : "memory");
 }
 
-template <int WRN>
+// M32: the wave tile as 4 x 2 tiles of 32 x 32 on v_mfma_f32_32x32x16_bf16 (two per 32-wide k-step) instead of 8 x 4 tiles of 16 x 16 on
+// v_mfma_f32_16x16x32_bf16: the same matrix-pipe cycles and LDS reads, half the MFMA instructions and half the operand-register reads
+// per flop (WRN = 2 only).  Lane l: row l & 31 of the tile, k half l >> 5; accumulator register 4 g + e <-> X row 8 g + 4 (l >> 5) + e.
+template <int WRN, bool M32 = false>
 __global__ __launch_bounds__(512) void k_remainder_gemm2(const __bf16 *__restrict__ Xh, const __bf16 *__restrict__ Xl,
                                                          const __bf16 *__restrict__ Wh, const __bf16 *__restrict__ Wl, int64_t Nc, int64_t R,
                                                          int64_t Kp, int h, int n_ctile, float *__restrict__ out, int tile_base, int ksplit,
@@ -245,11 +248,23 @@ __global__ __launch_bounds__(512) void k_remainder_gemm2(const __bf16 *__restric
 #pragma unroll
     for (int p = 0; p < NXB + NWB; ++p) issue_part(kt, p);
   };
-  f32x4 acc[C::TI][4];
+  static_assert(!M32 || WRN == 2, "the 32 x 32 form is written for the 128 x 64 wave tile");
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  f32x4 acc[M32 ? 1 : C::TI][4];
+  f32x16 acc32[M32 ? 4 : 1][2];
+  if constexpr (M32) {
 #pragma unroll
-  for (int i = 0; i < C::TI; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < C::TI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const int fr = lane & 15, q = lane >> 4;
   const int f_off = fr * 64 + ((q ^ ((4 - (fr >> 2)) & 3)) << 4);          // this lane's 16 bytes inside a 1-KiB block
   const unsigned char *xbase = lds2 + (C::TI * wr) * 1024 + f_off;
@@ -265,6 +280,41 @@ __global__ __launch_bounds__(512) void k_remainder_gemm2(const __bf16 *__restric
     // the start of every step; behind the MFMAs the pipe works through them meanwhile.
     const bool more = kt + 1 < n_k;
     const int bo = (int)(kt & 1) * C::BUF;
+    if constexpr (M32) {
+      const int n32 = lane & 31, hf = lane >> 5;
+      const int off0 = (n32 >> 4) * 1024 + fr * 64 + ((hf ^ ((4 - (fr >> 2)) & 3)) << 4);      // k chunk hf of row n32; chunk 2 + hf: ^ 32
+      const unsigned char *xb = lds2 + bo + (8 * wr) * 1024, *wb = lds2 + bo + 2 * C::X_PLANE + (4 * wc) * 1024;
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        const int off = off0 ^ (kh << 5);
+        bf16x8 wh2[2], wl2[2], xh4[4], xl4[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          wh2[j] = *reinterpret_cast<const bf16x8 *>(wb + j * 2048 + off);
+          wl2[j] = *reinterpret_cast<const bf16x8 *>(wb + C::W_PLANE + j * 2048 + off);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          xh4[i] = *reinterpret_cast<const bf16x8 *>(xb + i * 2048 + off);
+          xl4[i] = *reinterpret_cast<const bf16x8 *>(xb + C::X_PLANE + i * 2048 + off);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh4[i], wl2[j], acc32[i][j], 0, 0, 0);
+            acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl4[i], wh2[j], acc32[i][j], 0, 0, 0);
+            acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh4[i], wh2[j], acc32[i][j], 0, 0, 0);
+          }
+          if (kh == 0 && i < NXB + NWB) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) issue_part(kt + 1, i);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      continue;
+    }
     bf16x8 wh[4], wl[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -296,6 +346,37 @@ __global__ __launch_bounds__(512) void k_remainder_gemm2(const __bf16 *__restric
         if (more) issue_part(kt + 1, p);
     }
   }
+  if constexpr (M32) {
+    const int n32 = lane & 31, hf = lane >> 5;
+    if (cut) {
+      const int n_t = nblk / ksplit;
+      f32x4 *dst = reinterpret_cast<f32x4 *>(partial) + ((int64_t)piece * n_t + wi / ksplit) * (32 * 512) + tid;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            dst[((i * 2 + j) * 4 + g) * 512] = f32x4{acc32[i][j][4 * g], acc32[i][j][4 * g + 1], acc32[i][j][4 * g + 2], acc32[i][j][4 * g + 3]};
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t c = c0 + 128 * wr + 32 * i + 8 * g + 4 * hf;
+        if (c >= Nc) continue;
+        const int64_t sn = c / h, f = c - sn * h;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int64_t r = r0 + wc * 64 + j * 32 + n32;
+          if (r < r_lim)
+            *reinterpret_cast<f32x4 *>(out + (sn * R + r) * h + f) =
+                f32x4{acc32[i][j][4 * g], acc32[i][j][4 * g + 1], acc32[i][j][4 * g + 2], acc32[i][j][4 * g + 3]};
+        }
+      }
+    return;
+  }
   if (cut) {          // piece `piece` of cut tile wi / ksplit: [(piece, tile)][i][j][thread] float4
     const int n_t = nblk / ksplit;
     f32x4 *dst = reinterpret_cast<f32x4 *>(partial) + ((int64_t)piece * n_t + wi / ksplit) * (C::TI * 4 * 512) + tid;
@@ -322,7 +403,7 @@ __global__ __launch_bounds__(512) void k_remainder_gemm2(const __bf16 *__restric
 
 // Sum of the ksplit accumulator pieces of the cut tiles (tile t of the n_t of that launch = tile tile_base + t of the matrix), in
 // piece order, stored as k_remainder_gemm2's own epilogue would (same thread -> element mapping).
-template <int WRN>
+template <int WRN, bool M32 = false>
 __global__ __launch_bounds__(512) void k_remainder_gemm2_reduce(const float *__restrict__ partial, int ksplit, int tile_base, int64_t Nc, int64_t R,
                                                                 int h, int n_ctile, float *__restrict__ out) {
   using C = Gemm2Cfg<WRN>;
@@ -331,6 +412,30 @@ __global__ __launch_bounds__(512) void k_remainder_gemm2_reduce(const float *__r
   const int t = blockIdx.x, n_t = gridDim.x, w = tile_base + t;
   const int64_t c0 = (int64_t)(w % n_ctile) * C::BM, r0 = (int64_t)(w / n_ctile) * C::BN;
   const f32x4 *src = reinterpret_cast<const f32x4 *>(partial) + (int64_t)t * (C::TI * 4 * 512) + tid;
+  if constexpr (M32) {
+    const int n32 = lane & 31, hf = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t c = c0 + 128 * wr + 32 * i + 8 * g + 4 * hf;
+        if (c >= Nc) continue;
+        const int64_t sn = c / h, f = c - sn * h;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int64_t r = r0 + wc * 64 + j * 32 + n32;
+          if (r >= R) continue;
+          const int idx = ((i * 2 + j) * 4 + g) * 512;
+          f32x4 v = src[idx];
+          for (int p = 1; p < ksplit; ++p) {
+            const f32x4 u = src[(int64_t)p * n_t * (32 * 512) + idx];
+            v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+          }
+          *reinterpret_cast<f32x4 *>(out + (sn * R + r) * h + f) = v;
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < C::TI; ++i) {
     const int64_t c = c0 + (C::TI * wr + i) * 16 + (lane >> 4) * 4;

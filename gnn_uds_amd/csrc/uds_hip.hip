@@ -498,15 +498,20 @@ int uds_remainder_forward(const void *packed, int64_t R, int64_t M, const float 
   const RemainderPlan plan = remainder_plan(R, Nc, Kp);
   if (plan.v2) {
     using C = uds::Gemm2Cfg<2>;
+#ifdef UDS_GEMM_M32
+    constexpr bool M32 = true;       // the 32 x 32 x 16 form: measured 3 % slower than 16 x 16 x 32 here (profiles/r03_gemm2.md)
+#else
+    constexpr bool M32 = false;
+#endif
     static unsigned long long done = 0;
-    if ((e = uds::set_max_lds_once(reinterpret_cast<const void *>(&uds::k_remainder_gemm2<2>), C::LDS_BYTES, done)) != hipSuccess)
+    if ((e = uds::set_max_lds_once(reinterpret_cast<const void *>(&uds::k_remainder_gemm2<2, M32>), C::LDS_BYTES, done)) != hipSuccess)
       return fail(UDS_EHIP, "uds_remainder_forward: LDS attribute -> %s", hipGetErrorString(e));
     const int64_t n_ctile = plan.n_ctile, t_main = plan.t_main, t_rest = plan.t_rest, ks = plan.ks;
     float *partial = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + 2 * Nc * Kp * 2);
-    hipLaunchKernelGGL(uds::k_remainder_gemm2<2>, dim3((unsigned)(t_main + t_rest * ks)), dim3(512), C::LDS_BYTES, st, xh, xl, wh, wl, Nc, R, Kp, (int)h,
+    hipLaunchKernelGGL((uds::k_remainder_gemm2<2, M32>), dim3((unsigned)(t_main + t_rest * ks)), dim3(512), C::LDS_BYTES, st, xh, xl, wh, wl, Nc, R, Kp, (int)h,
                        (int)n_ctile, out, (int)t_main, (int)ks, partial);
     if (t_rest)
-      hipLaunchKernelGGL(uds::k_remainder_gemm2_reduce<2>, dim3((unsigned)t_rest), dim3(512), 0, st, partial, (int)ks, (int)t_main, Nc, R, (int)h,
+      hipLaunchKernelGGL((uds::k_remainder_gemm2_reduce<2, M32>), dim3((unsigned)t_rest), dim3(512), 0, st, partial, (int)ks, (int)t_main, Nc, R, (int)h,
                          (int)n_ctile, out);
     if ((e = hipGetLastError()) != hipSuccess) return fail(UDS_EHIP, "uds_remainder_forward: launch -> %s", hipGetErrorString(e));
     return UDS_OK;
