@@ -614,7 +614,7 @@ def main():
                                    ' (one launch per layer over S snapshots)' if args.precision == 'bf16x3' else
                                    'uds_spatial_layer_forward, unfused (8 launches per layer over S snapshots)',
                          'algorithmic_bytes_per_graph_step': bytes_gs, 'device_ms_per_step': dev_ms,
-                         'timed_region_ms': wall * 1e3, 'run_to_run_spread': '2-3 % between boxes and runs (DESIGN.md section 7)'},
+                         'timed_region_ms': wall * 1e3, 'run_to_run_spread': 'up to 10 % between the boxes of the pool (268-299 k graph-steps/s for the same code), 1-2 % run to run on one box; the first ~50 launches behind an idle moment run 15 % slower (clock ramp): the default region is 200 steps, --steps 20 --warmup 3 reproduces the region of rounds 1-2 (DESIGN.md 7.00)'},
         }
         if c4 is not None:
             out['c4_partitioned'] = {k: c4[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'ms_per_step', 'scaling', 'config', 'halo', 'roofline')}
