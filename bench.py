@@ -454,7 +454,15 @@ def bench_c5(args, U, dist, world, rank, dev):
             'config': {'workload': 'C5 training: %d mini-graphs x (N=%d, E=%d) per GPU as one block-diagonal batch, %d-layer GAT spatial '
                                    'block d=%d, MSE loss, backward, gradient all-reduce, Adam(clipnorm=1)' % (G, n1, e1, L, d),
                        'precision': args.precision, 'final_loss': float(loss)},
-            'roofline': None}))
+            # a training graph-step must at least read the layer's inputs and write its outputs (forward), read them again with the
+            # output gradients and write the input gradients (backward): 3 x the forward's algorithmic bytes per mini-graph and layer.
+            # The training path is the unfused chain (every operator with its own backward kernel), so it sits far from that bound.
+            'roofline': {'bound': 'hbm', 'achieved': 3 * algorithmic_bytes_per_graph_step(g, d, d) / G * (units / world / wall) / 1e9,
+                         'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': 3 * algorithmic_bytes_per_graph_step(g, d, d) / G * (units / world / wall) / 1e9 / HBM_PEAK_GBPS, 'traffic': None,
+                         'algorithmic_bytes_per_graph_step': 3 * algorithmic_bytes_per_graph_step(g, d, d) / G,
+                         'kernel': 'unfused training chain (row GEMMs, k_gat_aggregate / k_gat_bwd_rows / k_gat_bwd_cols, k_csr_spmm, '
+                                   'k_csr_sddmm, k_wgrad_mfma: profiles/r03h_c5_kernel_stats.csv -- no kernel above 10 % of the step)'}}))
     if dist is not None:
         dist.destroy_process_group()
 
