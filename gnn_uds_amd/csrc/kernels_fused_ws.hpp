@@ -46,6 +46,9 @@ constexpr int WS_SLOTS = UDS_WS_SLOTS;                              // neighbour
 #endif
 constexpr int WS_PRE = UDS_WS_PRE;      // P3: neighbour slots whose hx rows are fetched BEFORE the softmax chain (their addresses are static)
 static_assert(WS_PRE % WS_SLOTS == 0, "WS_PRE must be a multiple of WS_SLOTS");
+#ifndef UDS_WS_XPRIO
+#define UDS_WS_XPRIO 1      // s_setprio of the X team's waves (the Y team stays at 0)
+#endif
 static_assert(WS_NY >= 2 && WS_NY <= 4, "2 .. 4 waves multiply the primary rows");
 
 // LDS bytes: tile block + 2 x (s_self, s_nbr) + attention vectors / bias + 2 x sec rows + 2 x hx rows
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 2) void k_fused_ws(FusedArgs a) {
   } else {
     // =========================== X team: P1 and P3 ===========================
 #ifndef UDS_WS_NO_PRIO
-    __builtin_amdgcn_s_setprio(1);      // the longer instruction stream of the two, and the younger half of the workgroup (-2 %)
+    __builtin_amdgcn_s_setprio(UDS_WS_XPRIO);      // the longer instruction stream of the two, and the younger half of the workgroup (-2 %)
 #endif
 #ifndef UDS_WS_MFMA16
     // P1 on v_mfma_f32_32x32x16_bf16 too: half as many matrix instructions in this team's (issue-bound) stream.  32-row blocks
