@@ -37,3 +37,41 @@ def test_mask_statistics_and_stream_properties():
     x = np.random.default_rng(0).standard_normal(n)
     y = DR.dropout(x + 3.0, 0.2, 99, 0)
     assert abs(y.mean() - 3.0) < 0.02           # E[dropout(x)] = x
+
+
+def test_oracle_hooks_are_identity_at_inference_and_scale_in_training():
+    """The restatement's Dropout sites (oracle.emulator_ref.DROPOUT, oracle.spektral_dense.ATTN_DROPOUT): with no hook set a model
+    built with dropout > 0 computes exactly what the dropout-free model computes (Keras: Dropout is the identity unless
+    training=True); with an all-keep hook that only counts, every site of `build_network` is visited in the reference's order
+    (x, b, e, ae embeddings; x, e behind each spatial layer; the two resnet Dense outputs) and every GATConv once."""
+    import json, os
+    import torch
+    from oracle import emulator_ref as OE
+    from oracle import spektral_dense as OD
+    from tests.util import emulator_args
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'networks.json')) as fh:
+        net = json.load(fh)['astlingen']
+    edges = np.array(net['edges'])
+    a0 = emulator_args(edges, net['n_node'], n_sp_layer=2, seq_in=4, seq_out=2)
+    a1 = emulator_args(edges, net['n_node'], n_sp_layer=2, seq_in=4, seq_out=2, dropout=0.3)
+    params = OE.init_params(a0, seed=2)
+    c = OE.config(a0)
+    g = torch.Generator().manual_seed(0)
+    rnd = lambda *s: torch.rand(*s, generator=g, dtype=torch.float64)
+    X, B, E = rnd(2, c.seq_in, c.n_node, c.n_in), rnd(2, c.seq_out, c.n_node, c.b_in), rnd(2, c.seq_in, c.n_edge, c.e_in)
+    AE = rnd(2, c.seq_out, c.n_edge, 1) if c.act else None
+    y0, e0 = OE.forward(a0, params, X, B, E, AE)
+    y1, e1 = OE.forward(a1, params, X, B, E, AE)
+    assert torch.equal(y0, y1) and torch.equal(e0, e1)
+    seen, attn = [], []
+    OE.DROPOUT = lambda t, rate: (seen.append((tuple(t.shape), rate)), t)[1]
+    OD.ATTN_DROPOUT = lambda coef, a_hat: (attn.append(tuple(coef.shape)), coef)[1]
+    try:
+        y2, e2 = OE.forward(a1, params, X, B, E, AE)
+    finally:
+        OE.DROPOUT = OD.ATTN_DROPOUT = None
+    assert torch.equal(y0, y2) and torch.equal(e0, e2)
+    n_emb = 4 if c.act else 3
+    assert len(seen) == n_emb + 2 * 2 * c.L + 2, seen                          # embeddings, x and e behind each of the 2 L layers, two resnet outputs
+    assert [r for _, r in seen[:n_emb]] == [0.2] * n_emb and all(r == 0.3 for _, r in seen[n_emb:])
+    assert len(attn) == 2 * 2 * c.L                                             # gat_x and gat_e of every spatial layer
