@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # UDS_LIB_PATH: a differently built copy of the same library (kernel experiments: tools/variant_bench.py)
 LIB_PATH = os.environ.get('UDS_LIB_PATH') or os.path.join(_HERE, 'libuds_hip.so')
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 FLAG_EXACT_FP32, FLAG_REQUIRE_FUSED = 1, 2
 PRECISION_FLAGS = {'bf16x3': 0, 'fp32': FLAG_EXACT_FP32}
 
@@ -56,6 +56,7 @@ SYMBOLS = {
     'uds_remainder_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
     'uds_remainder_pack': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
     'uds_remainder_workspace_bytes': (_c_i64, [_c_i64, _c_i64, _c_i64, _c_i64]),
+    'uds_remainder_forward_dense': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_int, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr]),
     'uds_remainder_forward': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr]),
     'uds_rowgemm_forward': (_c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr]),
     'uds_rowgemm_forward_pair': (_c_int, [_c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64,
@@ -561,6 +562,25 @@ def remainder_forward(packed, shape, x):
     ws = torch.empty(lib.uds_remainder_workspace_bytes(R, M, S, h) // 4, device=x.device, dtype=torch.float32)
     _check(lib.uds_remainder_forward(packed.data_ptr(), R, M, _dev(x, 'x'), S, h, ws.data_ptr(), _dev(out, 'out'), _stream()),
            'uds_remainder_forward')
+    return out
+
+
+def remainder_forward_dense(packed, shape, e, packed_w, bias, act, h):
+    """rest @ act(e W + b) without the fp32 x_e in between (uds_remainder_forward_dense): e (..., M, F) with F 64 or 128, packed_w =
+    rowgemm_pack(W (F, h)), h 32 or 64 -> (..., R, h)."""
+    lib = load()
+    R, M = shape
+    if e.dim() < 2 or e.shape[-2] != M:
+        raise UdsError('remainder_forward_dense: e %r against rest (%d, %d)' % (tuple(e.shape), R, M))
+    F = e.shape[-1]
+    S = e.numel() // (M * F) if M * F else 0
+    out = torch.empty(tuple(e.shape[:-2]) + (R, h), device=e.device, dtype=torch.float32)
+    if S == 0:
+        _dev(e, 'e')
+        return out
+    ws = torch.empty(lib.uds_remainder_workspace_bytes(R, M, S, h) // 4, device=e.device, dtype=torch.float32)
+    _check(lib.uds_remainder_forward_dense(packed.data_ptr(), R, M, _dev(e, 'e'), F, packed_w.data_ptr(), _dev(bias, 'bias', True), ACT[act], S, h,
+                                           ws.data_ptr(), _dev(out, 'out'), _stream()), 'uds_remainder_forward_dense')
     return out
 
 

@@ -455,4 +455,59 @@ __global__ __launch_bounds__(512) void k_remainder_gemm2_reduce(const float *__r
   }
 }
 
+// x_e = act(e W + b) straight into the GEMM's operand image: the transposed bf16 hi / lo planes of k_split_transpose_bf16, without the
+// fp32 tensor in between.  In the trained-bias layer x_e exists only to be multiplied by `rest` (the fused kernel recomputes its own
+// secondary MLP), so Dense -> (S, M, h) fp32 -> split / transpose was a write and a read of the tensor for nothing.
+// One 256-thread workgroup per (snapshot, 64 rows): wave w multiplies rows 16 w .. + 15 (MFMA 16x16x32, split-bf16, the weight
+// fragments of uds_rowgemm_pack read from L2), turns its 16 x h block through LDS and the workgroup writes whole 128-byte runs
+// (64 consecutive rows of one feature).  Rows past M are written as zeros (the planes' padding must be zero).
+template <int KT>
+__global__ __launch_bounds__(256) void k_dense_split_planes(const float *__restrict__ e, int64_t M, int h, int64_t Mp, const uint4 *__restrict__ wq,
+                                                            const float *__restrict__ bias, int act, __bf16 *__restrict__ hi, __bf16 *__restrict__ lo) {
+  constexpr int F = 32 * KT;
+  __shared__ __attribute__((aligned(16))) __bf16 th[64][72], tl[64][72];      // [feature][row], 144-byte rows (16-B aligned, 4-bank skew)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, qd = lane >> 4;
+  const int64_t s = blockIdx.y, m0 = (int64_t)blockIdx.x * 64;
+  const int64_t m = m0 + 16 * wave + fr;
+  const float *row = e + (s * M + min(m, M - 1)) * F;
+  const int MB = h / 16;
+  f32x4 acc[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) acc[b] = bias && b < MB ? *reinterpret_cast<const f32x4 *>(bias + 16 * b + 4 * qd) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const int mbp = h <= 16 ? 1 : (h <= 32 ? 2 : 4);                            // block count of the packed image (rowgemm_mb)
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    const f32x4 u0 = *reinterpret_cast<const f32x4 *>(row + 32 * t + 4 * qd), u1 = *reinterpret_cast<const f32x4 *>(row + 32 * t + 16 + 4 * qd);
+    bf16x8 dh, dl;
+    split8(make_float4(u0[0], u0[1], u0[2], u0[3]), make_float4(u1[0], u1[1], u1[2], u1[3]), dh, dl);
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (b < MB) {
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[((t * mbp + b) * 2 + 0) * 64 + lane]), wl = __builtin_bit_cast(bf16x8, wq[((t * mbp + b) * 2 + 1) * 64 + lane]);
+        acc[b] = mfma3(wh, wl, dh, dl, acc[b]);
+      }
+  }
+  const bool live = m < M;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+    if (b < MB) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = live ? apply_act(acc[b][j], act) : 0.f;
+        const __bf16 vh = (__bf16)v;
+        th[16 * b + 4 * qd + j][16 * wave + fr] = vh;
+        tl[16 * b + 4 * qd + j][16 * wave + fr] = (__bf16)(v - (float)vh);
+      }
+    }
+  __syncthreads();
+  // 8 threads per feature run of 64 rows (128 bytes), 32 features per pass
+  for (int f = tid >> 3; f < h; f += 32) {
+    const int c = (tid & 7) * 8;
+    const int64_t o = (s * h + f) * Mp + m0 + c;
+    *reinterpret_cast<uint4 *>(hi + o) = *reinterpret_cast<const uint4 *>(&th[f][c]);
+    *reinterpret_cast<uint4 *>(lo + o) = *reinterpret_cast<const uint4 *>(&tl[f][c]);
+  }
+}
+
 }  // namespace uds

@@ -477,20 +477,11 @@ int64_t uds_remainder_workspace_bytes(int64_t R, int64_t M, int64_t S, int64_t h
   return 2 * S * h * pad_k(M) * 2 + (q.v2 ? q.t_rest * q.ks * 256 * 256 * 4 : 0);
 }
 
-int uds_remainder_forward(const void *packed, int64_t R, int64_t M, const float *x, int64_t S, int64_t h, void *workspace, float *out,
-                          uds_stream_t stream) {
-  UDS_REQUIRE(S >= 0 && R > 0 && M > 0, "uds_remainder_forward: bad shape");
-  if (S == 0) return UDS_OK;
-  UDS_REQUIRE(packed && x && workspace && out, "uds_remainder_forward: NULL argument");
-  UDS_REQUIRE(h > 0 && h <= 64 && h % 4 == 0, "uds_remainder_forward: h = %lld (needs h %% 4 == 0, h <= 64)", (long long)h);
-  UDS_REQUIRE(aligned16(packed) && aligned16(workspace) && aligned16(out), "uds_remainder_forward: buffers must be 16-byte aligned");
-  const int64_t Kp = pad_k(M), Nc = S * h;
-  UDS_REQUIRE(S <= 65535 && ((Nc + 127) / 128) * ((R + 127) / 128) < INT32_MAX, "uds_remainder_forward: shape exceeds the launch grid");
+namespace {
+// the GEMM of uds_remainder_forward on operand planes that are already in the workspace
+int remainder_gemm_from_planes(const void *packed, int64_t R, int64_t Kp, int64_t Nc, int64_t h, void *workspace, float *out, hipStream_t st) {
   const __bf16 *wh = reinterpret_cast<const __bf16 *>(packed), *wl = wh + R * Kp;
   __bf16 *xh = reinterpret_cast<__bf16 *>(workspace), *xl = xh + Nc * Kp;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(uds::k_split_transpose_bf16, dim3((unsigned)(Kp / 64 + (Kp % 64 != 0)), (unsigned)S), dim3(256), 0, st, x, M, (int)h, Kp,
-                     xh, xl);
   hipError_t e = hipSuccess;
   // k_remainder_gemm2<2> (256 x 256 tiles, LDS-DMA staged, one 8-wave workgroup per CU): the tiles that fill whole rounds of 256
   // workgroups go out as they are; the rest are cut along K into ks pieces each so that they fill (most of) one more round, their
@@ -524,6 +515,47 @@ int uds_remainder_forward(const void *packed, int64_t R, int64_t M, const float 
   e = hipGetLastError();
   if (e != hipSuccess) return fail(UDS_EHIP, "uds_remainder_forward: launch -> %s", hipGetErrorString(e));
   return UDS_OK;
+}
+}  // namespace
+
+int uds_remainder_forward(const void *packed, int64_t R, int64_t M, const float *x, int64_t S, int64_t h, void *workspace, float *out,
+                          uds_stream_t stream) {
+  UDS_REQUIRE(S >= 0 && R > 0 && M > 0, "uds_remainder_forward: bad shape");
+  if (S == 0) return UDS_OK;
+  UDS_REQUIRE(packed && x && workspace && out, "uds_remainder_forward: NULL argument");
+  UDS_REQUIRE(h > 0 && h <= 64 && h % 4 == 0, "uds_remainder_forward: h = %lld (needs h %% 4 == 0, h <= 64)", (long long)h);
+  UDS_REQUIRE(aligned16(packed) && aligned16(workspace) && aligned16(out), "uds_remainder_forward: buffers must be 16-byte aligned");
+  const int64_t Kp = pad_k(M), Nc = S * h;
+  UDS_REQUIRE(S <= 65535 && ((Nc + 127) / 128) * ((R + 127) / 128) < INT32_MAX, "uds_remainder_forward: shape exceeds the launch grid");
+  const __bf16 *wh = reinterpret_cast<const __bf16 *>(packed), *wl = wh + R * Kp;
+  __bf16 *xh = reinterpret_cast<__bf16 *>(workspace), *xl = xh + Nc * Kp;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(uds::k_split_transpose_bf16, dim3((unsigned)(Kp / 64 + (Kp % 64 != 0)), (unsigned)S), dim3(256), 0, st, x, M, (int)h, Kp,
+                     xh, xl);
+  return remainder_gemm_from_planes(packed, R, Kp, Nc, h, workspace, out, st);
+}
+
+int uds_remainder_forward_dense(const void *packed, int64_t R, int64_t M, const float *e, int64_t F, const void *packed_w, const float *bias,
+                                int act, int64_t S, int64_t h, void *workspace, float *out, uds_stream_t stream) {
+  UDS_REQUIRE(S >= 0 && R > 0 && M > 0, "uds_remainder_forward_dense: bad shape");
+  if (S == 0) return UDS_OK;
+  UDS_REQUIRE(packed && e && packed_w && workspace && out, "uds_remainder_forward_dense: NULL argument");
+  UDS_REQUIRE((F == 64 || F == 128) && (h == 32 || h == 64), "uds_remainder_forward_dense: F = %lld, h = %lld (F 64 or 128, h 32 or 64)", (long long)F,
+              (long long)h);
+  UDS_REQUIRE(act >= UDS_ACT_LINEAR && act <= UDS_ACT_HARD_SIGMOID, "uds_remainder_forward_dense: unknown activation %d", act);
+  UDS_REQUIRE(aligned16(packed) && aligned16(e) && aligned16(packed_w) && aligned16(bias) && aligned16(workspace) && aligned16(out),
+              "uds_remainder_forward_dense: buffers must be 16-byte aligned");
+  const int64_t Kp = pad_k(M), Nc = S * h;
+  UDS_REQUIRE(S <= 65535 && ((Nc + 127) / 128) * ((R + 127) / 128) < INT32_MAX, "uds_remainder_forward_dense: shape exceeds the launch grid");
+  __bf16 *xh = reinterpret_cast<__bf16 *>(workspace), *xl = xh + Nc * Kp;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)(Kp / 64), (unsigned)S);
+  if (F == 64)
+    hipLaunchKernelGGL(uds::k_dense_split_planes<2>, grid, dim3(256), 0, st, e, M, (int)h, Kp, reinterpret_cast<const uint4 *>(packed_w), bias, act, xh, xl);
+  else
+    hipLaunchKernelGGL(uds::k_dense_split_planes<4>, grid, dim3(256), 0, st, e, M, (int)h, Kp, reinterpret_cast<const uint4 *>(packed_w), bias, act, xh, xl);
+  if (hipError_t er = hipGetLastError(); er != hipSuccess) return fail(UDS_EHIP, "uds_remainder_forward_dense: launch -> %s", hipGetErrorString(er));
+  return remainder_gemm_from_planes(packed, R, Kp, Nc, h, workspace, out, st);
 }
 
 int uds_rowgemm_forward(const float *x, int64_t B, int64_t T, int64_t R, int64_t F, const void *packed, const float *bias,

@@ -16,6 +16,7 @@ Parameters are created with requires_grad=False (inference: no autograd graph is
 C ABI (gnn_uds_amd/_lib.py); CPU tensors raise.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -406,6 +407,17 @@ class NodeEdge(nn.Module):
             self._rest_packed = _lib.remainder_pack(rest)
         return _lib.remainder_forward(self._rest_packed, tuple(rest.shape), xs)
 
+    def remainder_of_dense(self, es, dense):
+        """`rest @ dense(es)` with the Dense layer's output written straight into the GEMM's operand planes (uds_remainder_forward_dense);
+        None when the shapes are not the ones that entry takes -- the caller then materialises dense(es) and calls remainder()."""
+        rest = self.support_values()[1]
+        if rest is None or dense.precision != 'bf16x3' or es.shape[-1] not in (64, 128) or dense.units not in (32, 64) or not es.is_cuda:
+            return None
+        if self._rest_packed is None:
+            self._rest_packed = _lib.remainder_pack(rest)
+        return _lib.remainder_forward_dense(self._rest_packed, tuple(rest.shape), es.contiguous(), _packed_kernel(dense, dense.kernel), dense.bias,
+                                            dense.activation, dense.units)
+
     def handle(self):
         if self._handle is None:
             self._handle = _lib.CsrHandle(self.csr)
@@ -621,11 +633,29 @@ class SpatialLayer(nn.Module):
             # trained dense NodeEdge bias (every checkpoint the reference trains, emulator.py:36-45): secondary MLP on the
             # row-GEMM kernel, the dense remainder on the MFMA GEMM, everything else in the fused kernel
             net = self.network()
-            x_e, e_x = self.dense_xe(es), self.dense_ex(xs)
+
+            def remainders():
+                # rest_n @ Dense_xe(es) and rest_e @ Dense_ex(xs): the Dense outputs exist only for these products (the fused kernel has
+                # its own secondary MLP), so they go straight into the GEMM's operand planes (uds_remainder_forward_dense) when the
+                # shapes allow; else they are materialised first
+                S_, N_, E_ = xs.shape[0], xs.shape[1], es.shape[1]
+                if rest_n is None:
+                    rem_n = torch.zeros((S_, N_, self.h), device=xs.device, dtype=torch.float32)
+                else:
+                    rem_n = self.node_edge_n.remainder_of_dense(es, self.dense_xe) if not os.environ.get('UDS_REMAINDER_MATERIALISE') else None
+                    if rem_n is None:
+                        rem_n = self.node_edge_n.remainder(self.dense_xe(es))
+                if rest_e is None:
+                    rem_e = torch.zeros((S_, E_, self.h), device=xs.device, dtype=torch.float32)
+                else:
+                    rem_e = self.node_edge_e.remainder_of_dense(xs, self.dense_ex) if not os.environ.get('UDS_REMAINDER_MATERIALISE') else None
+                    if rem_e is None:
+                        rem_e = self.node_edge_e.remainder(self.dense_ex(xs))
+                return rem_n, rem_e
+
             if self.precision == 'bf16x3' and self.h == 32 and self.d == 64 and xs.shape[-1] == 64 and es.shape[-1] == 64 \
                     and xbs is None and ebs is None:
-                rem_n = self.node_edge_n.remainder(x_e) if rest_n is not None else torch.zeros_like(e_x)
-                rem_e = self.node_edge_e.remainder(e_x) if rest_e is not None else torch.zeros_like(x_e)
+                rem_n, rem_e = remainders()
                 ox = None
                 if getattr(self, '_ws_rem_ok', True):
                     # the wave-specialised kernel adds the remainder to its NodeEdge aggregate (uds_spatial_layer_forward_rem); it
@@ -645,13 +675,13 @@ class SpatialLayer(nn.Module):
             elif self._d128_remainder_ok(xs, es, xbs, ebs):
                 # the reference's stock model after training (embed_size 128, dense bias): the remainder is added to the support
                 # aggregate inside the column-split kernel (uds_spatial_layer_forward_rem)
-                rem_n = self.node_edge_n.remainder(x_e) if rest_n is not None else torch.zeros_like(e_x)
-                rem_e = self.node_edge_e.remainder(e_x) if rest_e is not None else torch.zeros_like(x_e)
+                rem_n, rem_e = remainders()
                 packed = self._packed_weights(p, 128, es.shape[-1])[0]
                 ox, oe = _lib.spatial_layer_forward(net, dict(p, packed=packed), xs, es, self.h, self.d, self.activation,
                                                     _lib.PRECISION_FLAGS[self.precision], rem_x=rem_n, rem_e=rem_e)
                 self.last_path = 'fused+remainder'
             else:
+                x_e, e_x = self.dense_xe(es), self.dense_ex(xs)
                 ox = self.gat_x([xs, net.adj], xb=self.node_edge_n(x_e))
                 oe = self.gat_e([es, net.edge_adj], xb=self.node_edge_e(e_x))
         else:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define UDS_ABI_VERSION 21
+#define UDS_ABI_VERSION 22
 
 enum {
   UDS_OK = 0,
@@ -190,6 +190,14 @@ int uds_remainder_pack(const float *rest, int64_t R, int64_t M, void *packed, ud
 int64_t uds_remainder_workspace_bytes(int64_t R, int64_t M, int64_t S, int64_t h);
 int uds_remainder_forward(const void *packed, int64_t R, int64_t M, const float *x, int64_t S, int64_t h, void *workspace,
                           float *out, uds_stream_t stream);
+
+/* The same with the activations computed on the way: out = rest @ act(e W + b) for e (S, M, F), F = 64 or 128, W (F x h, packed by
+ * uds_rowgemm_pack), h = 32 or 64.  In a trained layer x_e = Dense(e) exists only to be multiplied by `rest` (emulator.py:225-228 with
+ * :36-45): this entry writes it straight into the GEMM's bf16 operand planes instead of an fp32 tensor that is then read back, split
+ * and transposed.  Same workspace as uds_remainder_forward. */
+int uds_remainder_forward_dense(const void *packed, int64_t R, int64_t M, const float *e, int64_t F, const void *packed_w,
+                                const float *bias, int act, int64_t S, int64_t h, void *workspace, float *out,
+                                uds_stream_t stream);
 
 /* keras Dense(64) (64 inputs) + prefix sum over time + residual + activation in one pass (matrix cores, split-bf16):
  *   out[b,t,r,:] = act( sum_{t' <= t} (x[b,t',r,:] @ kernel + bias) + res[b,0,r,:] ),   x, out: (B,T,R,64), res: (B,1,R,64) or NULL.

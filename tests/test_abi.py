@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert _lib.load().uds_abi_version() == _lib.ABI_VERSION == 21
+    assert _lib.load().uds_abi_version() == _lib.ABI_VERSION == 22
 
 
 def test_argument_errors_are_reported_not_thrown():

@@ -535,3 +535,25 @@ def test_small_network_snapshots_share_a_tile(dev, d):
     px, pe = layer(x.to(dev), e.to(dev))
     assert layer.pack_factor() == 1
     assert float((px - ox).abs().max()) <= 4e-6 * max(1.0, float(rx.abs().max())) and float((pe - oe).abs().max()) <= 4e-6 * max(1.0, float(re.abs().max()))
+
+
+@pytest.mark.parametrize('R,M,S,F,h,act', [(130, 77, 3, 64, 32, 'relu'), (443, 444, 9, 128, 64, 'tanh'), (300, 1000, 5, 64, 32, 'linear'),
+                                          (1000, 129, 4, 128, 64, 'relu')])
+def test_remainder_gemm_with_the_dense_layer_on_the_way(dev, R, M, S, F, h, act):
+    """uds_remainder_forward_dense: rest @ act(e W + b) with the Dense output written straight into the GEMM's bf16 operand planes
+    (no fp32 x_e in between), against the fp64 product and against the two-step path it replaces (Dense, then uds_remainder_forward:
+    the same split values reach the same GEMM -- equal bit for bit); M not a multiple of 64 (zero padding of the planes), ragged R."""
+    g = torch.Generator().manual_seed(R + M)
+    rest, e = rnd(g, R, M), rnd(g, S, M, F)
+    W, b = rnd(g, F, h) * 0.2, rnd(g, h) * 0.1
+    ref = torch.matmul(rest, OD.activation(act)(e @ W + b))
+    dense = U.Dense(h, activation=act, in_features=F, precision='bf16x3').to(dev)
+    dense.kernel.data, dense.bias.data = W.float().to(dev), b.float().to(dev)
+    packed = _lib.remainder_pack(rest.float().to(dev))
+    from gnn_uds_amd.layers import _packed_kernel
+    ed = e.float().to(dev)
+    out = _lib.remainder_forward_dense(packed, (R, M), ed, _packed_kernel(dense, dense.kernel), dense.bias, act, h)
+    assert tuple(out.shape) == (S, R, h)
+    close(out, ref, TOL_BF16X3)
+    two_step = _lib.remainder_forward(packed, (R, M), dense(ed))
+    close(out, two_step.double().cpu(), 2e-6)      # (the Dense module may take another kernel at small sizes: not always bit-equal)
