@@ -411,7 +411,8 @@ class NodeEdge(nn.Module):
         """`rest @ dense(es)` with the Dense layer's output written straight into the GEMM's operand planes (uds_remainder_forward_dense);
         None when the shapes are not the ones that entry takes -- the caller then materialises dense(es) and calls remainder()."""
         rest = self.support_values()[1]
-        if rest is None or dense.precision != 'bf16x3' or es.shape[-1] not in (64, 128) or dense.units not in (32, 64) or not es.is_cuda:
+        if rest is None or dense.precision != 'bf16x3' or es.shape[-1] not in (64, 128) or dense.units not in (32, 64) or not es.is_cuda \
+                or rest.shape[1] < 64:      # (a 30-row network fills half of that kernel's 64-row blocks: the flattened row GEMM is the better Dense there)
             return None
         if self._rest_packed is None:
             self._rest_packed = _lib.remainder_pack(rest)
